@@ -1,0 +1,159 @@
+"""CPU: numpy layer oracle (oracle/bcl_oracle.py) against the reference-generated golden
+vectors F4/F5 (tests/golden/layers.npz, models.npz).  Tolerance: 1e-5 relative to the
+tensor's max-abs (fp32 summation order differs between numpy/BLAS and torch conv)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from common import GOLD, oracle_lattice, rel_err
+from hplflownet_amd.synthetic import MODEL_GAIN, closed_form_fill, subsample
+from oracle import bcl_oracle as BO
+
+TOL = 1e-5
+# reductions over all vertices (bias / weight grads) cancel heavily: the reference's own fp32
+# sums carry ~1e-4 relative error w.r.t. the result, so those are compared more loosely
+RTOL = 3e-4
+
+
+def bcl_params(cin, couts, do_slice):
+    """Closed-form parameters exactly as tools/make_fixtures.py fills the reference module."""
+    convs = []
+    c = cin
+    for i, o in enumerate(couts):
+        F = 15 if i == 0 else 1
+        last = i == len(couts) - 1
+        base = 'blur_conv.%d.' % i + ('' if last else 'composed_module.0.')   # last_relu False -> bare conv
+        W = closed_form_fill(base + 'weight', (o, c, F, 1))[..., 0]
+        b = closed_form_fill(base + 'bias', (o,))
+        convs.append((W, b))
+        c = o
+    bias = closed_form_fill('slice_bias', (couts[-1],)) if do_slice else None
+    return convs, bias
+
+
+CASES = [  # tag, n, level_in, cin, couts, do_splat, do_slice, last_relu, use_norm
+    ('cfg1', 1024, 0, 68, [64, 64], True, True, False, True),
+    ('down0', 256, 0, 68, [64, 64], True, False, False, True),
+    ('down2', 256, 2, 68, [64, 64], True, False, False, True),
+    ('up2', 256, 2, 36, [32, 32], False, True, False, True),
+    ('down1_single', 256, 1, 68, [64], True, False, False, True),
+    ('up1_single_relu', 256, 1, 20, [32], False, True, True, True),
+    ('cfg_nonorm', 256, 0, 12, [16, 16], True, True, False, False),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_bilateral_conv_F4(case):
+    tag, n, lvl, cin, couts, do_splat, do_slice, last_relu, use_norm = case
+    z = np.load(os.path.join(GOLD, 'layers.npz'))
+    _, _, _, gd = oracle_lattice(n)
+    g = gd[lvl]
+    convs, bias = bcl_params(cin, couts, do_slice)
+    if last_relu:   # reference wraps the last conv in Conv2dReLU -> composed_module names
+        W = closed_form_fill('blur_conv.0.composed_module.0.weight', (couts[0], cin, 15, 1))[..., 0]
+        b = closed_form_fill('blur_conv.0.composed_module.0.bias', (couts[0],))
+        convs = [(W, b)]
+    H = g['pc1_hash_cnt']
+    nfeat = g['pc1_barycentric'].shape[1] if do_splat else H
+    x = closed_form_fill(tag + '_x', (1, cin, nfeat))[0] * np.float32(np.sqrt(cin))
+    args = (x, convs, bias,
+            g['pc1_barycentric'] if do_splat else None, g['pc1_lattice_offset'] if do_splat else None,
+            g['pc1_blur_neighbors'],
+            g['pc1_barycentric'] if do_slice else None, g['pc1_lattice_offset'] if do_slice else None,
+            do_splat, do_slice, use_norm, True)
+    y, cache = BO.bilateral_conv_forward(*args, last_relu=last_relu)
+    assert rel_err(subsample(y), z[tag + '_y']) < TOL
+    go = closed_form_fill(tag + '_g', (1,) + y.shape)[0] * np.float32(np.sqrt(y.shape[0]))
+    grads = BO.bilateral_conv_backward(go, cache, *args)
+    assert rel_err(subsample(grads['features']), z[tag + '_gx']) < 5 * TOL
+    if do_slice:
+        assert rel_err(grads['bias'], z[tag + '_g_bias']) < RTOL
+    for i, (gW, gb) in enumerate(grads['convs']):
+        last = i == len(couts) - 1 and not last_relu
+        base = tag + '_g_blur_conv.%d.' % i + ('' if last else 'composed_module.0.')
+        assert rel_err(subsample(gW), z[base + 'weight'].reshape(-1)) < RTOL
+        assert rel_err(gb, z[base + 'bias']) < RTOL
+
+
+def corr_params(prev_dim, corr_outs, outs):
+    cc, c = [], 128 + prev_dim
+    for i, o in enumerate(corr_outs):
+        K = 15 if i == 0 else 1
+        W = closed_form_fill('corr_conv.%d.composed_module.0.weight' % i, (o, c, 1, K, 1))[:, :, 0, :, 0]
+        cc.append((W, closed_form_fill('corr_conv.%d.composed_module.0.bias' % i, (o,))))
+        c = o
+    bc, _ = [], None
+    for i, o in enumerate(outs):
+        F = 15 if i == 0 else 1
+        last = i == len(outs) - 1
+        base = 'blur_conv.%d.' % i + ('' if last else 'composed_module.0.')
+        bc.append((closed_form_fill(base + 'weight', (o, c, F, 1))[..., 0], closed_form_fill(base + 'bias', (o,))))
+        c = o
+    return cc, bc
+
+
+@pytest.mark.parametrize('tag,lvl,prev_dim,corr_outs,outs', [
+    ('corr_noprev', 2, 0, [32, 32], [64, 64]),
+    ('corr_prev', 3, 64, [32, 32], [64, 64]),
+    ('corr_shallow', 4, 64, [32], [32])])
+def test_bilateral_corr_F4(tag, lvl, prev_dim, corr_outs, outs):
+    z = np.load(os.path.join(GOLD, 'layers.npz'))
+    _, _, _, gd = oracle_lattice(256)
+    g = gd[lvl]
+    H1, H2 = g['pc1_hash_cnt'], g['pc2_hash_cnt']
+    f1 = closed_form_fill(tag + '_f1', (1, 64, H1))[0] * 8
+    f2 = closed_form_fill(tag + '_f2', (1, 64, H2))[0] * 8
+    prev = None
+    if prev_dim:
+        prev = closed_form_fill(tag + '_prev', (1, prev_dim, g['pc1_barycentric'].shape[1]))[0] * 8
+    cc, bc = corr_params(prev_dim, corr_outs, outs)
+    y = BO.bilateral_corr_forward(f1, f2, prev, g['pc1_barycentric'], g['pc1_lattice_offset'],
+                                  g['pc1_corr_indices'], g['pc2_corr_indices'], cc, bc)
+    assert rel_err(subsample(y), z[tag + '_y']) < TOL
+
+
+def test_sparse_sum_F4():
+    z = np.load(os.path.join(GOLD, 'layers.npz'))
+    _, _, _, gd = oracle_lattice(256)
+    idx = (gd[0]['pc1_lattice_offset'] + 1).reshape(-1)
+    vals = closed_form_fill('ss_vals', (idx.size, 5))
+    y = BO.sparse_sum(idx, vals, (gd[0]['pc1_hash_cnt'] + 1, 5))
+    assert rel_err(y, z['ss_y']) < TOL
+    assert rel_err(BO.sparse_sum_backward(idx, 2 * y), z['ss_gvals']) < TOL
+
+
+def model_state(manifest, gain=MODEL_GAIN):
+    sd = {}
+    for k, (dt, *shape) in manifest.items():
+        if dt != 'float32':
+            continue
+        v = closed_form_fill(k, tuple(shape))
+        sd[k] = v * np.float32(gain) if len(shape) >= 2 else v
+    return sd
+
+
+@pytest.mark.parametrize('tag,cls,n,shallow', [('shallow_n256', 'HPLFlowNetShallow', 256, True),
+                                               ('full_n256', 'HPLFlowNet', 256, False),
+                                               ('shallow_n1024', 'HPLFlowNetShallow', 1024, True)])
+def test_whole_model_F5(tag, cls, n, shallow):
+    z = np.load(os.path.join(GOLD, 'models.npz'))
+    manifest = json.load(open(os.path.join(GOLD, 'state_dict.json')))[cls]
+    pc1, pc2, sf, gd = oracle_lattice(n)
+    sd = model_state(manifest)
+    flow = BO.hplflownet_forward(sd, pc1.T, pc2.T, gd, shallow=shallow)
+    ref = z[tag + '_flow']
+    # end-to-end bar of the north star: EPE3D delta < 1e-4 on fixed inputs
+    assert abs(BO.epe3d(flow, sf.T) - float(z[tag + '_loss'])) < 1e-4
+    assert np.abs(flow - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_state_dict_manifest_F6():
+    m = json.load(open(os.path.join(GOLD, 'state_dict.json')))
+    full = m['HPLFlowNet']
+    assert len(full) == 150
+    nparam = sum(int(np.prod(s[1:])) for s in full.values() if s[0] == 'float32')
+    assert nparam == 19303843
+    assert full['bcn1_.blur_conv.0.composed_module.0.weight'][1:] == [1024, 580, 15, 1]
+    assert full['corr2.corr_conv.0.composed_module.0.weight'][1:] == [32, 192, 1, 15, 1]
