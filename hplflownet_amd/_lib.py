@@ -1,0 +1,100 @@
+"""ctypes binding of libhplbcl.so (include/hpl_bcl.h).
+
+torch is used for device memory and streams only: every call passes raw device
+pointers (tensor.data_ptr()) and the current HIP stream.  There is NO fallback: if the
+shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhplbcl.so')
+
+c_i64, c_i32, c_f32, c_vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p
+
+
+class HplError(RuntimeError):
+    pass
+
+
+class GConvDesc(ctypes.Structure):
+    """Mirror of `struct hpl_gconv_desc` (include/hpl_bcl.h)."""
+    _fields_ = [('A', c_vp), ('lda', c_i64), ('rows_a', c_i64),
+                ('nbr', c_vp), ('nbr_stride', c_i64), ('reg_stride', c_i64),
+                ('M', c_i64), ('C', c_i32), ('F', c_i32),
+                ('Wt', c_vp), ('ldw', c_i64), ('N', c_i32), ('act', c_i32), ('slope', c_f32),
+                ('bias', c_vp), ('res', c_vp), ('ldres', c_i64), ('res_mod', c_i64),
+                ('Y', c_vp), ('ldy', c_i64),
+                ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('reserved', c_i32)]
+
+
+_SIGNATURES = {
+    'hpl_version': (ctypes.c_int, []),
+    'hpl_last_error': (ctypes.c_char_p, []),
+    'hpl_device_info': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                       ctypes.c_char_p, ctypes.c_int]),
+    'hpl_index_narrow': (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    'hpl_corr2_permute': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_i64, c_vp]),
+    'hpl_corr2_permute32': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_i64, c_vp]),
+    'hpl_csr_build': (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'hpl_splat': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'hpl_slice': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'hpl_weight_relayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i64, c_i64,
+                                           c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,
+                                           c_i64, c_i64, c_i64, ctypes.c_int, c_vp]),
+    'hpl_gconv_forward': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
+    'hpl_gconv_forward_naive': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
+    'hpl_gconv_wgrad': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,
+                                       c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp]),
+    'hpl_colsum': (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
+    'hpl_leaky_bwd': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_i64, ctypes.c_int, c_vp]),
+    'hpl_transpose': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    'hpl_lattice_keys': (ctypes.c_int, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    'hpl_lattice_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'hpl_lattice_hash': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'hpl_lattice_neighbors': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'hpl_lattice_next_points': (ctypes.c_int, [c_vp, c_i64, c_i64, c_f32, c_vp, c_vp]),
+}
+
+#: every symbol include/hpl_bcl.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load libhplbcl.so; raises HplError if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HplError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError here = ABI/header mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HplError('%s failed (%d): %s' % (what, rc, load().hpl_last_error().decode()))
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HplError('expected a device tensor, got %s (the HIP path has no CPU fallback)' % t.device)
+    return t.data_ptr()

@@ -1,0 +1,289 @@
+// index_ops.hip -- library plumbing and the small integer/element-wise kernels:
+// table narrowing, corr-table permutation, the splat CSR build, transpose, column sums,
+// LeakyReLU backward.  All HBM-bound; written for 64-wide waves, 256-thread groups.
+#include "common.h"
+
+#include <string.h>
+
+namespace hpl {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace hpl
+
+using namespace hpl;
+
+extern "C" int hpl_version(void) { return 100; }
+extern "C" const char *hpl_last_error(void) { return hpl::g_err; }
+
+extern "C" int hpl_device_info(int device, int *cu_count, int *wave_size, char *arch, int arch_len) {
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, device);
+    if (e != hipSuccess) {
+        set_error("hpl_device_info: %s", hipGetErrorString(e));
+        return HPL_ENODEV;
+    }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (wave_size) *wave_size = p.warpSize;
+    if (arch && arch_len > 0) {
+        strncpy(arch, p.gcnArchName, arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return HPL_OK;
+}
+
+// ---------------------------------------------------------------- narrowing
+__global__ void k_narrow(const int64_t *__restrict__ src, int32_t *__restrict__ dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (int32_t)src[i];
+}
+
+extern "C" int hpl_index_narrow(const int64_t *src, int32_t *dst, int64_t n, hplStream stream) {
+    if (n == 0) return HPL_OK;
+    HPL_REQUIRE(src && dst && n > 0, "hpl_index_narrow: null pointer or negative size");
+    int grid = (int)imin(cdiv(n, 256), 2048);
+    k_narrow<<<grid, 256, 0, to_stream(stream)>>>(src, dst, n);
+    HPL_CHECK_LAUNCH("hpl_index_narrow");
+    return HPL_OK;
+}
+
+// src [F][K][H] -> dst [K][F*H]
+template <typename T>
+__global__ void k_corr2_permute(const T *__restrict__ src, int32_t *__restrict__ dst, int F, int K,
+                                int64_t H) {
+    int64_t total = (int64_t)F * K * H;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {   // i indexes dst: (k, f, h)
+        int64_t h = i % H;
+        int64_t t = i / H;
+        int f = (int)(t % F);
+        int k = (int)(t / F);
+        dst[i] = (int32_t)src[((int64_t)f * K + k) * H + h];
+    }
+}
+
+extern "C" int hpl_corr2_permute(const int64_t *src, int32_t *dst, int F, int K, int64_t H,
+                                 hplStream stream) {
+    HPL_REQUIRE(src && dst && F > 0 && K > 0 && H >= 0, "hpl_corr2_permute: bad arguments");
+    if (H == 0) return HPL_OK;
+    int grid = (int)imin(cdiv((int64_t)F * K * H, 256), 4096);
+    k_corr2_permute<int64_t><<<grid, 256, 0, to_stream(stream)>>>(src, dst, F, K, H);
+    HPL_CHECK_LAUNCH("hpl_corr2_permute");
+    return HPL_OK;
+}
+
+extern "C" int hpl_corr2_permute32(const int32_t *src, int32_t *dst, int F, int K, int64_t H,
+                                   hplStream stream) {
+    HPL_REQUIRE(src && dst && F > 0 && K > 0 && H >= 0, "hpl_corr2_permute32: bad arguments");
+    if (H == 0) return HPL_OK;
+    int grid = (int)imin(cdiv((int64_t)F * K * H, 256), 4096);
+    k_corr2_permute<int32_t><<<grid, 256, 0, to_stream(stream)>>>(src, dst, F, K, H);
+    HPL_CHECK_LAUNCH("hpl_corr2_permute32");
+    return HPL_OK;
+}
+
+// ---------------------------------------------------------------- CSR build
+__global__ void k_zero_i32(int32_t *p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = 0;
+}
+
+__global__ void k_csr_count(const int32_t *__restrict__ off, int64_t n_entries, int64_t H,
+                            int32_t *__restrict__ cnt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_entries; i += stride) {
+        int32_t v = off[i];
+        if (v >= 0 && v < H) atomicAdd(&cnt[v], 1);   // integer atomics: deterministic counts
+    }
+}
+
+// single-workgroup exclusive scan of cnt[0..n) into ptr[0..n], ptr[n] = total.
+// n <= ~150k here (vertices of one lattice level); one 1024-thread group is plenty.
+__global__ void __launch_bounds__(1024) k_exclusive_scan(const int32_t *__restrict__ cnt, int64_t n,
+                                                         int32_t *__restrict__ ptr) {
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b = (int64_t)t * per, e = imin(n, b + per);
+    int32_t s = 0;
+    for (int64_t i = b; i < e; ++i) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan over the partials
+        int32_t v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int32_t run = (t == 0) ? 0 : part[t - 1];
+    for (int64_t i = b; i < e; ++i) {
+        ptr[i] = run;
+        run += cnt[i];
+    }
+    if (t == 1023) ptr[n] = part[1023];
+}
+
+__global__ void k_csr_fill(const int32_t *__restrict__ off, int64_t n_entries, int64_t H,
+                           const int32_t *__restrict__ ptr, int32_t *__restrict__ cursor,
+                           int32_t *__restrict__ ent) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_entries; i += stride) {
+        int32_t v = off[i];
+        if (v >= 0 && v < H) {
+            int32_t slot = atomicAdd(&cursor[v], 1);
+            ent[ptr[v] + slot] = (int32_t)i;
+        }
+    }
+}
+
+// one thread per vertex: insertion-sort its (short) segment by entry id so the summation
+// order is fixed, then emit (point, weight) pairs and the density normaliser.
+__global__ void k_csr_finish(const int32_t *__restrict__ ptr, int32_t *__restrict__ ent,
+                             const float *__restrict__ bary, int64_t N, int64_t H,
+                             float *__restrict__ w_out, float *__restrict__ norm) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= H) return;
+    const int32_t b = ptr[v], e = ptr[v + 1];
+    for (int32_t i = b + 1; i < e; ++i) {
+        int32_t x = ent[i];
+        int32_t j = i - 1;
+        while (j >= b && ent[j] > x) {
+            ent[j + 1] = ent[j];
+            --j;
+        }
+        ent[j + 1] = x;
+    }
+    float s = 0.f;
+    for (int32_t i = b; i < e; ++i) {
+        int32_t en = ent[i];
+        float w = bary[en];
+        w_out[i] = w;
+        ent[i] = (int32_t)(en % N);   // entry e = r*N + n  ->  point n
+        s += w;
+    }
+    norm[v] = 1.0f / (s + 1e-5f);   // models/bilateralNN.py:183
+}
+
+extern "C" int hpl_csr_build(const int32_t *off, const float *bary, int64_t n_entries, int64_t pt_mod,
+                             int64_t H, int32_t *csr_ptr, int32_t *csr_pt, float *csr_w, float *norm,
+                             int32_t *scratch, hplStream stream) {
+    HPL_REQUIRE(off && bary && csr_ptr && csr_pt && csr_w && norm && scratch,
+                "hpl_csr_build: null pointer");
+    HPL_REQUIRE(n_entries > 0 && pt_mod > 0 && H > 0 && n_entries < (int64_t)INT32_MAX,
+                "hpl_csr_build: bad sizes n_entries=%lld H=%lld", (long long)n_entries, (long long)H);
+    hipStream_t s = to_stream(stream);
+    const int64_t ne = n_entries;
+    const int64_t N = pt_mod;
+    int gh = (int)imin(cdiv(H + 1, 256), 2048);
+    int ge = (int)imin(cdiv(ne, 256), 2048);
+    k_zero_i32<<<gh, 256, 0, s>>>(scratch, H + 1);
+    k_csr_count<<<ge, 256, 0, s>>>(off, ne, H, scratch);
+    k_exclusive_scan<<<1, 1024, 0, s>>>(scratch, H, csr_ptr);
+    k_zero_i32<<<gh, 256, 0, s>>>(scratch, H + 1);
+    k_csr_fill<<<ge, 256, 0, s>>>(off, ne, H, csr_ptr, scratch, csr_pt);
+    k_csr_finish<<<(int)cdiv(H, 256), 256, 0, s>>>(csr_ptr, csr_pt, bary, N, H, csr_w, norm);
+    HPL_CHECK_LAUNCH("hpl_csr_build");
+    return HPL_OK;
+}
+
+// ---------------------------------------------------------------- transpose
+// dst[m*ldd + c] = src[c*lds + m]; src is (rows_src = C) x (cols_src = M).
+__global__ void k_transpose(const float *__restrict__ src, int64_t lds, float *__restrict__ dst,
+                            int64_t ldd, int64_t rows, int64_t cols) {
+    __shared__ float tile[32][33];
+    const int64_t c0 = (int64_t)blockIdx.y * 32, m0 = (int64_t)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        int64_t c = c0 + r, m = m0 + tx;
+        tile[r][tx] = (c < rows && m < cols) ? src[c * lds + m] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int64_t m = m0 + r, c = c0 + tx;
+        if (m < cols && c < rows) dst[m * ldd + c] = tile[tx][r];
+    }
+}
+
+extern "C" int hpl_transpose(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t rows_src,
+                             int64_t cols_src, hplStream stream) {
+    HPL_REQUIRE(src && dst && rows_src > 0 && cols_src > 0, "hpl_transpose: bad arguments");
+    dim3 grid((unsigned)cdiv(cols_src, 32), (unsigned)cdiv(rows_src, 32));
+    k_transpose<<<grid, 256, 0, to_stream(stream)>>>(src, lds, dst, ldd, rows_src, cols_src);
+    HPL_CHECK_LAUNCH("hpl_transpose");
+    return HPL_OK;
+}
+
+// ---------------------------------------------------------------- column sums
+// out[n] = sum_m X[m*ld + n].  Two-stage: each block sums a slab of rows into LDS partials,
+// then one atomicAdd per (block, column).  `out` must be zeroed by the launcher.
+__global__ void k_colsum(const float *__restrict__ X, int64_t ld, int64_t M, int N, int64_t rows_per_block,
+                         float *__restrict__ out) {
+    const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t m1 = imin(M, m0 + rows_per_block);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.f;
+        for (int64_t m = m0; m < m1; ++m) s += X[m * ld + n];
+        atomicAdd(&out[n], s);
+    }
+}
+
+__global__ void k_zero_f32(float *p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+extern "C" int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStream stream) {
+    HPL_REQUIRE(X && out && M >= 0 && N > 0, "hpl_colsum: bad arguments");
+    hipStream_t s = to_stream(stream);
+    k_zero_f32<<<(int)cdiv(N, 256), 256, 0, s>>>(out, N);
+    if (M > 0) {
+        int64_t rpb = 64;
+        int threads = N >= 256 ? 256 : (int)(cdiv(N, 64) * 64);
+        k_colsum<<<(int)cdiv(M, rpb), threads, 0, s>>>(X, ld, M, N, rpb, out);
+    }
+    HPL_CHECK_LAUNCH("hpl_colsum");
+    return HPL_OK;
+}
+
+// ---------------------------------------------------------------- LeakyReLU backward
+__global__ void k_leaky_bwd(const float *__restrict__ dY, int64_t lddy, const float *__restrict__ Y,
+                            int64_t ldy, float slope, float *__restrict__ dX, int64_t lddx, int64_t M,
+                            int N) {
+    int64_t total = M * N;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        int64_t m = i / N;
+        int n = (int)(i - m * N);
+        float y = Y[m * ldy + n];
+        dX[m * lddx + n] = dY[m * lddy + n] * (y > 0.f ? 1.0f : slope);
+    }
+}
+
+extern "C" int hpl_leaky_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, float slope,
+                             float *dX, int64_t lddx, int64_t M, int N, hplStream stream) {
+    HPL_REQUIRE(dY && Y && dX && M >= 0 && N > 0, "hpl_leaky_bwd: bad arguments");
+    if (M == 0) return HPL_OK;
+    int grid = (int)imin(cdiv(M * N, 256), 4096);
+    k_leaky_bwd<<<grid, 256, 0, to_stream(stream)>>>(dY, lddy, Y, ldy, slope, dX, lddx, M, N);
+    HPL_CHECK_LAUNCH("hpl_leaky_bwd");
+    return HPL_OK;
+}
+
+// shared with lattice.hip
+namespace hpl {
+int exclusive_scan_i32(const int32_t *cnt, int64_t n, int32_t *ptr, hipStream_t s) {
+    k_exclusive_scan<<<1, 1024, 0, s>>>(cnt, n, ptr);
+    HPL_CHECK_LAUNCH("exclusive_scan_i32");
+    return HPL_OK;
+}
+}  // namespace hpl

@@ -1,0 +1,470 @@
+// lattice.hip -- permutohedral lattice construction on gfx950.
+//
+// Replaces the reference's CPU half of the hot path: torch-CPU float ops
+// (transforms/transforms.py:300-353), a Python `set` (:387-391), the Numba loops of
+// build_unsymmetric (:133-261) and the klib khash behind CFFI (models/khash_int2int.h).
+//
+//  * keys kernel: one lane per point, the exact op sequence of oracle/lattice_oracle.c
+//    (k-ordered fmaf chain, v_rndne, stable descending rank) -> bit-identical keys,
+//    barycentric weights and el_minus_gr;
+//  * hash build: the table is a global open-addressing array of 64-bit packed keys, but a
+//    workgroup never sends duplicate keys to it: its 256 points x 4 simplex vertices are
+//    first inserted into a 2048-slot LDS table (ds_cmpst_rtn_b64 + ds_min), where
+//    neighbouring points collapse onto shared vertices, and only the distinct keys of the
+//    group CAS into global memory, each carrying the minimum entry index seen -- so the
+//    global atomics are per distinct (group, vertex) instead of per (point, remainder);
+//  * vertex ids must reproduce the reference's first-appearance numbering: a slot keeps
+//    the minimum entry index j = 4*point + remainder, the entries that own their slot
+//    (first[slot] == j) are flagged, and an exclusive scan of the flags is the id;
+//  * neighbour tables are pure lookups (15 + 15 + 225 per pc1 vertex), one lane per probe.
+//
+// All HBM-bound integer work.  Algorithmic bytes per level: keys 12N in, 80N out; hash
+// 64N key bytes + table; neighbours 16H in, 4*(15+15+225)*H1 + 60*H2 out.
+#include "common.h"
+
+#include <math.h>
+
+using namespace hpl;
+
+namespace hpl {
+// defined in index_ops.hip
+int exclusive_scan_i32(const int32_t *cnt, int64_t n, int32_t *ptr, hipStream_t s);
+}  // namespace hpl
+
+namespace {
+
+constexpr int64_t EMPTY = -1;   // packed keys of real vertices are >= 0
+
+struct Elev {
+    float e[12];   // (4,3) row-major elevation matrix, transforms.py:271-276
+    float stdf;    // float32((d+1) * sqrt(2/3)), transforms.py:275
+};
+
+Elev make_elev() {
+    Elev E;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float left = (j >= i) ? 1.0f : 0.0f;
+            if (i >= 1 && j == i - 1) left += -(float)i;
+            const float prod = (float)(j + 1) * (float)(j + 2);
+            const float right = 1.0f / sqrtf(prod);
+            E.e[i * 3 + j] = left * right;
+        }
+    E.stdf = (float)(4.0 * sqrt(2.0 / 3.0));
+    return E;
+}
+
+__device__ __forceinline__ int canonical(int i, int j) { return (j < 4 - i) ? j : j - 4; }
+
+// transforms/transforms.py:300-353, same statement order as oracle hpl_keys_and_barycentric
+__global__ void k_lattice_keys(const float *__restrict__ pc, int64_t N, float scale, const Elev E,
+                               int32_t *__restrict__ keys, float *__restrict__ bary,
+                               float *__restrict__ emg) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float p0 = pc[n] * scale, p1 = pc[N + n] * scale, p2 = pc[2 * N + n] * scale;
+    float el[4], gr[4], res[4];
+    int rank[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = E.e[j * 3 + 0] * p0;
+        acc = fmaf(E.e[j * 3 + 1], p1, acc);
+        acc = fmaf(E.e[j * 3 + 2], p2, acc);
+        el[j] = acc * E.stdf;
+        gr[j] = rintf(el[j] / 4.0f) * 4.0f;      // round half to even
+        res[j] = el[j] - gr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (res[k] > res[j] || (res[k] == res[j] && k < j)) r++;
+        rank[j] = r;
+    }
+    float sum = ((gr[0] + gr[1]) + (gr[2] + gr[3])) / 4.0f;
+    const int s = (int)sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (s > 0 && (float)rank[j] >= 4.0f - sum) { gr[j] -= 4.0f; rank[j] -= 4; }
+        else if (s < 0 && (float)rank[j] < -sum) { gr[j] += 4.0f; rank[j] += 4; }
+        rank[j] += s;
+    }
+    float b[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        res[j] = el[j] - gr[j];
+        emg[(int64_t)j * N + n] = res[j];
+    }
+    // rank is a permutation of 0..3: resolve the dynamic index with selects (no scratch)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+            if (t == 3 - rank[j]) b[t] += res[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+            if (t == 4 - rank[j]) b[t] -= res[j];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) b[t] /= 4.0f;
+    b[0] += 1.0f + b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bary[(int64_t)t * N + n] = b[t];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int4 k;
+        const int g = (int)gr[j];
+        k.x = g + canonical(rank[j], 0);
+        k.y = g + canonical(rank[j], 1);
+        k.z = g + canonical(rank[j], 2);
+        k.w = g + canonical(rank[j], 3);
+        *reinterpret_cast<int4 *>(keys + ((int64_t)j * N + n) * 4) = k;
+    }
+}
+
+// ---------------------------------------------------------------- workspace layout
+struct CloudWS {
+    int64_t *tkeys;    // [cap]
+    int32_t *tfirst;   // [cap]  min entry index
+    int32_t *tid;      // [cap]  vertex id
+    int32_t *slot;     // [E]    table slot of every entry
+    int32_t *flag;     // [E+1]  ownership flags, then their exclusive scan (in place copy)
+    int32_t *scan;     // [E+1]
+    uint64_t mask;     // cap - 1
+    int64_t n, E, cap;
+};
+struct WS {
+    int32_t *mm;       // [8] mins[4], maxs[4]
+    CloudWS c[2];
+    int64_t bytes;
+};
+
+int64_t pow2_at_least(int64_t x) { int64_t p = 64; while (p < x) p <<= 1; return p; }
+
+WS carve(void *base, int64_t n1, int64_t n2) {
+    WS w;
+    char *p = reinterpret_cast<char *>(base);
+    auto take = [&](int64_t bytes) { char *r = p; p += (bytes + 255) / 256 * 256; return r; };
+    w.mm = reinterpret_cast<int32_t *>(take(8 * sizeof(int32_t)));
+    const int64_t ns[2] = {n1, n2};
+    for (int c = 0; c < 2; ++c) {
+        CloudWS &q = w.c[c];
+        q.n = ns[c]; q.E = 4 * ns[c]; q.cap = pow2_at_least(2 * q.E); q.mask = (uint64_t)q.cap - 1;
+        q.tkeys = reinterpret_cast<int64_t *>(take(q.cap * 8));
+        q.tfirst = reinterpret_cast<int32_t *>(take(q.cap * 4));
+        q.tid = reinterpret_cast<int32_t *>(take(q.cap * 4));
+        q.slot = reinterpret_cast<int32_t *>(take(q.E * 4));
+        q.flag = reinterpret_cast<int32_t *>(take((q.E + 1) * 4));
+        q.scan = reinterpret_cast<int32_t *>(take((q.E + 1) * 4));
+    }
+    w.bytes = p - reinterpret_cast<char *>(base);
+    return w;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+// key2int, transforms.py:70-86 (no range check, on purpose)
+__device__ __forceinline__ int64_t pack_key(const int k[4], const int32_t *__restrict__ mm) {
+    int64_t res = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        res += (int64_t)k[i] - mm[i];
+        res *= (int64_t)mm[4 + i + 1] - mm[i + 1] + 1;
+    }
+    return res + ((int64_t)k[3] - mm[3]);
+}
+
+__global__ void k_init_ws(int32_t *mm, int64_t *tk1, int32_t *tf1, int64_t cap1, int64_t *tk2, int32_t *tf2,
+                          int64_t cap2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4) mm[i] = INT32_MAX;
+    else if (i < 8) mm[i] = INT32_MIN;
+    if (i < cap1) { tk1[i] = EMPTY; tf1[i] = INT32_MAX; }
+    if (i < cap2) { tk2[i] = EMPTY; tf2[i] = INT32_MAX; }
+}
+
+// per-coordinate min/max over keys [4][n][4] of one cloud (transforms.py:384-385)
+__global__ void k_minmax(const int32_t *__restrict__ keys, int64_t n, int32_t *mm) {
+    const int j = blockIdx.y;   // coordinate
+    const int4 *p = reinterpret_cast<const int4 *>(keys + (int64_t)j * n * 4);
+    int lo = INT32_MAX, hi = INT32_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int4 v = p[i];
+        lo = min(min(lo, v.x), min(v.y, min(v.z, v.w)));
+        hi = max(max(hi, v.x), max(v.y, max(v.z, v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[j], lo);
+        atomicMax(&mm[4 + j], hi);
+    }
+}
+
+// Hash build with LDS staging.  256 points per workgroup = 1024 entries.
+constexpr int LSLOTS = 2048;
+__global__ void __launch_bounds__(256) k_hash_insert(const int32_t *__restrict__ keys, int64_t n,
+                                                     const int32_t *__restrict__ mm,
+                                                     int64_t *__restrict__ tkeys, int32_t *__restrict__ tfirst,
+                                                     uint64_t mask, int32_t *__restrict__ slot_of) {
+    __shared__ unsigned long long lkeys[LSLOTS];
+    __shared__ int lmin[LSLOTS];
+    __shared__ int lglob[LSLOTS];
+    for (int i = threadIdx.x; i < LSLOTS; i += 256) { lkeys[i] = (unsigned long long)EMPTY; lmin[i] = INT32_MAX; }
+    __syncthreads();
+    const int64_t pnt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int ls[4] = {-1, -1, -1, -1};
+    if (pnt < n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int k[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) k[j] = keys[((int64_t)j * n + pnt) * 4 + r];
+            const unsigned long long packed = (unsigned long long)pack_key(k, mm);
+            int s = (int)(mix64(packed) & (LSLOTS - 1));
+            while (true) {
+                const unsigned long long prev = atomicCAS(&lkeys[s], (unsigned long long)EMPTY, packed);
+                if (prev == (unsigned long long)EMPTY || prev == packed) break;
+                s = (s + 1) & (LSLOTS - 1);
+            }
+            atomicMin(&lmin[s], (int)(pnt * 4 + r));
+            ls[r] = s;
+        }
+    }
+    __syncthreads();
+    // distinct keys of this workgroup -> global table
+    for (int i = threadIdx.x; i < LSLOTS; i += 256) {
+        const unsigned long long packed = lkeys[i];
+        if (packed == (unsigned long long)EMPTY) continue;
+        uint64_t s = mix64(packed) & mask;
+        while (true) {
+            const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&tkeys[s]),
+                                                      (unsigned long long)EMPTY, packed);
+            if (prev == (unsigned long long)EMPTY || prev == packed) break;
+            s = (s + 1) & mask;
+        }
+        atomicMin(&tfirst[s], lmin[i]);
+        lglob[i] = (int)s;
+    }
+    __syncthreads();
+    if (pnt < n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slot_of[pnt * 4 + r] = lglob[ls[r]];
+    }
+}
+
+__global__ void k_flags(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ tfirst, int64_t E,
+                        int32_t *__restrict__ flag) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < E) flag[j] = (tfirst[slot_of[j]] == (int32_t)j) ? 1 : 0;
+}
+
+// owners publish their id (= rank among owners, i.e. first-appearance order) and vertex key
+__global__ void k_assign_ids(const int32_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ slot_of,
+                             const int32_t *__restrict__ flag, const int32_t *__restrict__ scan,
+                             int32_t *__restrict__ tid, int32_t *__restrict__ vkeys, int64_t vstride,
+                             int32_t *__restrict__ count_out) {
+    const int64_t E = 4 * n;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) *count_out = scan[E];
+    if (j >= E || !flag[j]) return;
+    const int32_t id = scan[j];
+    tid[slot_of[j]] = id;
+    const int64_t p = j >> 2;
+    const int r = (int)(j & 3);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vkeys[(int64_t)c * vstride + id] = keys[((int64_t)c * n + p) * 4 + r];
+}
+
+__global__ void k_offsets(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ tid, int64_t n,
+                          int32_t *__restrict__ off) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 4 * n) return;
+    off[(j & 3) * n + (j >> 2)] = tid[slot_of[j]];
+}
+
+__device__ __forceinline__ int32_t lookup(const int64_t *__restrict__ tkeys, const int32_t *__restrict__ tid,
+                                          uint64_t mask, int64_t packed) {
+    if (packed < 0) return -1;   // never inserted (all stored keys are >= 0)
+    uint64_t s = mix64((uint64_t)packed) & mask;
+    while (true) {
+        const int64_t k = tkeys[s];
+        if (k == packed) return tid[s];
+        if (k == EMPTY) return -1;
+        s = (s + 1) & mask;
+    }
+}
+
+struct Offsets {
+    int n;
+    int v[65 * 4];   // radius <= 2
+};
+
+void walk(int radius, int axis, int has_zero, const int *start, Offsets &o) {   // transforms.py:112-130
+    if (axis > 3) {
+        for (int j = 0; j < 4; ++j) o.v[o.n * 4 + j] = start[j];
+        o.n++;
+        return;
+    }
+    int cur[4] = {start[0], start[1], start[2], start[3]};
+    const int steps = (has_zero || axis < 3) ? radius + 1 : 1;
+    for (int i = 0; i < steps; ++i) {
+        walk(radius, axis + 1, has_zero || (i == 0), cur, o);
+        for (int j = 0; j < 4; ++j) cur[j] -= 1;
+        cur[axis] += 4;
+    }
+}
+
+Offsets make_offsets(int radius) {
+    Offsets o;
+    o.n = 0;
+    const int zero[4] = {0, 0, 0, 0};
+    walk(radius, 0, 0, zero, o);
+    return o;
+}
+
+// out[f * ostride + h] = id of vertex (key_h + off_f) in `table`, -1 if absent
+__global__ void k_neighbors(const int32_t *__restrict__ vkeys, int64_t vstride, int64_t H, const Offsets offs,
+                            const int32_t *__restrict__ mm, const int64_t *__restrict__ tkeys,
+                            const int32_t *__restrict__ tid, uint64_t mask, int32_t *__restrict__ out,
+                            int64_t ostride) {
+    const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (h >= H) return;
+    int k[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) k[c] = vkeys[(int64_t)c * vstride + h] + offs.v[f * 4 + c];
+    out[(int64_t)f * ostride + h] = lookup(tkeys, tid, mask, pack_key(k, mm));
+}
+
+// corr2p[k][f*H1 + h] = id in table 2 of (key1_h + coff_k + foff_f)   (transforms.py:223-241)
+__global__ void k_neighbors_corr2(const int32_t *__restrict__ vkeys, int64_t vstride, int64_t H1,
+                                  const Offsets coff, const Offsets foff, const int32_t *__restrict__ mm,
+                                  const int64_t *__restrict__ tkeys2, const int32_t *__restrict__ tid2,
+                                  uint64_t mask2, int32_t *__restrict__ out) {
+    const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kf = blockIdx.y;
+    const int kc = kf / foff.n, f = kf - kc * foff.n;
+    if (h >= H1) return;
+    int k[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) k[c] = vkeys[(int64_t)c * vstride + h] + coff.v[kc * 4 + c] + foff.v[f * 4 + c];
+    out[((int64_t)kc * foff.n + f) * H1 + h] = lookup(tkeys2, tid2, mask2, pack_key(k, mm));
+}
+
+__global__ void k_next_points(const int32_t *__restrict__ vkeys, int64_t vstride, int64_t H, float divisor,
+                              const Elev E, float *__restrict__ out) {
+    const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (float)vkeys[(int64_t)j * vstride + h] / divisor;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = E.e[0 * 3 + i] * v[0];
+        acc = fmaf(E.e[1 * 3 + i], v[1], acc);
+        acc = fmaf(E.e[2 * 3 + i], v[2], acc);
+        acc = fmaf(E.e[3 * 3 + i], v[3], acc);
+        out[(int64_t)i * H + h] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int hpl_lattice_keys(const float *pc, int64_t N, float scale, int32_t *keys, float *bary,
+                                float *emg, hplStream stream) {
+    HPL_REQUIRE(pc && keys && bary && emg && N > 0, "hpl_lattice_keys: bad arguments");
+    HPL_REQUIRE(aligned16(keys), "hpl_lattice_keys: keys must be 16-byte aligned");
+    k_lattice_keys<<<(int)cdiv(N, 256), 256, 0, to_stream(stream)>>>(pc, N, scale, make_elev(), keys, bary, emg);
+    HPL_CHECK_LAUNCH("hpl_lattice_keys");
+    return HPL_OK;
+}
+
+extern "C" int64_t hpl_lattice_workspace_bytes(int64_t n1, int64_t n2) {
+    if (n1 <= 0 || n2 <= 0) return 0;
+    return carve(nullptr, n1, n2).bytes;
+}
+
+extern "C" int hpl_lattice_hash(const int32_t *keys1, int64_t n1, const int32_t *keys2, int64_t n2,
+                                int32_t *off1, int32_t *off2, int32_t *vkeys1, int32_t *vkeys2,
+                                int32_t *counts, void *workspace, int64_t workspace_bytes, hplStream stream) {
+    HPL_REQUIRE(keys1 && keys2 && off1 && off2 && vkeys1 && vkeys2 && counts && workspace,
+                "hpl_lattice_hash: null pointer");
+    HPL_REQUIRE(n1 > 0 && n2 > 0 && 4 * n1 < INT32_MAX && 4 * n2 < INT32_MAX, "hpl_lattice_hash: bad sizes");
+    HPL_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "hpl_lattice_hash: workspace must be 256-byte aligned");
+    WS w = carve(workspace, n1, n2);
+    HPL_REQUIRE(workspace_bytes >= w.bytes, "hpl_lattice_hash: workspace too small (%lld < %lld)",
+                (long long)workspace_bytes, (long long)w.bytes);
+    hipStream_t s = to_stream(stream);
+    const int64_t capmax = imax(w.c[0].cap, w.c[1].cap);
+    k_init_ws<<<(int)cdiv(capmax, 256), 256, 0, s>>>(w.mm, w.c[0].tkeys, w.c[0].tfirst, w.c[0].cap, w.c[1].tkeys,
+                                                      w.c[1].tfirst, w.c[1].cap);
+    const int32_t *keys[2] = {keys1, keys2};
+    int32_t *offs[2] = {off1, off2};
+    int32_t *vk[2] = {vkeys1, vkeys2};
+    for (int c = 0; c < 2; ++c) {
+        dim3 g((unsigned)imin(cdiv(w.c[c].n, 256), 256), 4);
+        k_minmax<<<g, 256, 0, s>>>(keys[c], w.c[c].n, w.mm);
+    }
+    for (int c = 0; c < 2; ++c) {
+        const CloudWS &q = w.c[c];
+        k_hash_insert<<<(int)cdiv(q.n, 256), 256, 0, s>>>(keys[c], q.n, w.mm, q.tkeys, q.tfirst, q.mask, q.slot);
+        k_flags<<<(int)cdiv(q.E, 256), 256, 0, s>>>(q.slot, q.tfirst, q.E, q.flag);
+        int rc = exclusive_scan_i32(q.flag, q.E, q.scan, s);
+        if (rc != HPL_OK) return rc;
+        k_assign_ids<<<(int)cdiv(q.E, 256), 256, 0, s>>>(keys[c], q.n, q.slot, q.flag, q.scan, q.tid, vk[c],
+                                                        q.E, counts + c);
+        k_offsets<<<(int)cdiv(q.E, 256), 256, 0, s>>>(q.slot, q.tid, q.n, offs[c]);
+    }
+    HPL_CHECK_LAUNCH("hpl_lattice_hash");
+    return HPL_OK;
+}
+
+extern "C" int hpl_lattice_neighbors(const void *workspace, int64_t n1, int64_t n2, const int32_t *vkeys1,
+                                     const int32_t *vkeys2, int64_t H1, int64_t H2, int bcn_radius,
+                                     int corr_filter_radius, int corr_corr_radius, int32_t *blur1,
+                                     int32_t *blur2, int32_t *corr1, int32_t *corr2, hplStream stream) {
+    HPL_REQUIRE(workspace && vkeys1 && vkeys2 && n1 > 0 && n2 > 0, "hpl_lattice_neighbors: bad arguments");
+    HPL_REQUIRE(H1 > 0 && H2 > 0 && H1 <= 4 * n1 && H2 <= 4 * n2, "hpl_lattice_neighbors: bad vertex counts");
+    HPL_REQUIRE(bcn_radius <= 2 && corr_filter_radius <= 2 && corr_corr_radius <= 2,
+                "hpl_lattice_neighbors: radius > 2 not supported");
+    HPL_REQUIRE((corr_filter_radius == -1) == (corr_corr_radius == -1), "hpl_lattice_neighbors: corr radii must both be set or both -1");
+    WS w = carve(const_cast<void *>(workspace), n1, n2);
+    hipStream_t s = to_stream(stream);
+    if (bcn_radius != -1) {
+        HPL_REQUIRE(blur1 && blur2, "hpl_lattice_neighbors: null blur table");
+        const Offsets o = make_offsets(bcn_radius);
+        k_neighbors<<<dim3((unsigned)cdiv(H1, 256), o.n), 256, 0, s>>>(vkeys1, 4 * n1, H1, o, w.mm, w.c[0].tkeys,
+                                                                       w.c[0].tid, w.c[0].mask, blur1, H1);
+        k_neighbors<<<dim3((unsigned)cdiv(H2, 256), o.n), 256, 0, s>>>(vkeys2, 4 * n2, H2, o, w.mm, w.c[1].tkeys,
+                                                                       w.c[1].tid, w.c[1].mask, blur2, H2);
+    }
+    if (corr_filter_radius != -1) {
+        HPL_REQUIRE(corr1 && corr2, "hpl_lattice_neighbors: null corr table");
+        const Offsets co = make_offsets(corr_corr_radius), fo = make_offsets(corr_filter_radius);
+        k_neighbors<<<dim3((unsigned)cdiv(H1, 256), co.n), 256, 0, s>>>(vkeys1, 4 * n1, H1, co, w.mm, w.c[0].tkeys,
+                                                                        w.c[0].tid, w.c[0].mask, corr1, H1);
+        k_neighbors_corr2<<<dim3((unsigned)cdiv(H1, 256), co.n * fo.n), 256, 0, s>>>(
+            vkeys1, 4 * n1, H1, co, fo, w.mm, w.c[1].tkeys, w.c[1].tid, w.c[1].mask, corr2);
+    }
+    HPL_CHECK_LAUNCH("hpl_lattice_neighbors");
+    return HPL_OK;
+}
+
+extern "C" int hpl_lattice_next_points(const int32_t *vkeys, int64_t vstride, int64_t H, float divisor,
+                                       float *out, hplStream stream) {
+    HPL_REQUIRE(vkeys && out && H > 0 && vstride >= H && divisor != 0.f, "hpl_lattice_next_points: bad arguments");
+    k_next_points<<<(int)cdiv(H, 256), 256, 0, to_stream(stream)>>>(vkeys, vstride, H, divisor, make_elev(), out);
+    HPL_CHECK_LAUNCH("hpl_lattice_next_points");
+    return HPL_OK;
+}

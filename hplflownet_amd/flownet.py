@@ -1,0 +1,231 @@
+"""Model assembly on top of the HIP bilateral layers: HPLFlowNet and HPLFlowNetShallow.
+
+Own counterpart of the reference's callers of the hot path:
+same module names, hence the same state_dict keys and shapes as
+/root/reference/models/HPLFlowNet.py:11-236 and models/HPLFlowNet_shallow.py:11-169
+(checked against tests/golden/state_dict.json), same forward signature
+`model(pc1, pc2, generated_data) -> (1, 3, N)`.  The wiring is table driven instead of
+spelled out layer by layer, runs channel-last end to end, and replaces every torch.cat of
+the reference forward by writes into column slices of one buffer per layer input.
+
+Level L (0-based) hosts bcn{L+1} (Down, shared by both clouds), bcn{L+1}_ (Up) and, for
+L >= 2, corr{L-1}.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .bcl import (BilateralConvFlex, BilateralCorrelationFlex, Conv1dReLU, NbrTable, pointwise_conv,
+                  to_channel_first, to_channel_last)
+
+__all__ = ['HPLFlowNet', 'HPLFlowNetShallow', 'DeviceLattice']
+
+
+# ----------------------------------------------------------------------------- lattice container
+class _Level(object):
+    __slots__ = ('clouds', 'blur', 'emg', 'corr1', 'corr2', 'H')
+
+
+class DeviceLattice(object):
+    """`generated_data` resident on the device in kernel-ready form:
+    int32 tables, CSR of each splat, channel-last el_minus_gr.  Built either from the
+    reference's list of dicts (host or device tensors, with or without the B=1 dimension
+    added by default_collate) or directly by hplflownet_amd.lattice on the GPU."""
+
+    def __init__(self, levels):
+        self.levels = levels
+
+    @staticmethod
+    def from_generated_data(gd, device):
+        levels = []
+        for d in gd:
+            lv = _Level()
+
+            def t(key):
+                v = d[key]
+                v = torch.as_tensor(v)
+                return v.to(device, non_blocking=True)
+
+            def cnt(key):
+                v = d[key]
+                return int(v.reshape(-1)[0].item()) if torch.is_tensor(v) else int(v)
+
+            lv.H = (cnt('pc1_hash_cnt'), cnt('pc2_hash_cnt'))
+            lv.clouds, lv.blur, lv.emg = [], [], []
+            for ci, nm in enumerate(('pc1', 'pc2')):
+                bary = t(nm + '_barycentric').reshape(4, -1).float()
+                off = t(nm + '_lattice_offset').reshape(4, -1)
+                lv.clouds.append(ops.CloudTables(bary, off, lv.H[ci]))
+                bl = t(nm + '_blur_neighbors')
+                lv.blur.append(NbrTable(ops.narrow(bl.reshape(-1, lv.H[ci]))) if bl.numel() > 1 else None)
+                lv.emg.append(t(nm + '_el_minus_gr').reshape(4, -1).float().t().contiguous())
+            c1 = t('pc1_corr_indices')
+            if c1.numel() > 1:
+                lv.corr1 = NbrTable(ops.narrow(c1.reshape(-1, lv.H[0])))
+                c2 = t('pc2_corr_indices')
+                c2 = c2.reshape(-1, lv.corr1.t.shape[0], lv.H[0])
+                lv.corr2 = NbrTable(ops.corr2_permute(c2))
+                lv.corr2._sym = False
+            else:
+                lv.corr1 = lv.corr2 = None
+            levels.append(lv)
+        return DeviceLattice(levels)
+
+
+def _assemble(rows, parts, device):
+    """Concatenate channel blocks into one [rows, sum C] matrix.  A part is (C, tensor) or
+    (C, callable(out_view) -> tensor).  Without autograd the blocks are written in place
+    (no cat copy for callables); with autograd this is a plain torch.cat."""
+    if torch.is_grad_enabled():
+        return torch.cat([src(None) if callable(src) else src for _, src in parts], dim=1)
+    total = sum(c for c, _ in parts)
+    buf = torch.empty((rows, total), dtype=torch.float32, device=device)
+    col = 0
+    for c, src in parts:
+        view = buf[:, col:col + c]
+        if callable(src):
+            src(view)
+        else:
+            view.copy_(src)
+        col += c
+    return buf
+
+
+# ----------------------------------------------------------------------------- the two models
+class _FlowNetBase(nn.Module):
+    """Shared wiring.  Subclasses define SPEC."""
+
+    NLEV = None          # number of lattice levels
+    DOWN = None          # num_output of every Down BCL
+    CORR = None          # (num_corr_output, num_output) of every CorrBCL
+    UP = None            # per level L: num_output of bcn{L+1}_
+    REFINE = False       # corr{j}_refine Conv1d stacks (shallow model)
+    HEAD_IN = None
+
+    def __init__(self, args):
+        super(_FlowNetBase, self).__init__()
+        self.scales_filter_map = args.scales_filter_map
+        assert len(self.scales_filter_map) == self.NLEV
+        sfm = self.scales_filter_map
+        dim, leaky = args.dim, args.use_leaky
+        self.use_leaky = leaky
+        chunk = -1 if getattr(args, 'evaluate', False) else 1024 * 1024 * 25
+        self.chunk_size = chunk
+
+        def bcl(n_in, n_out, radius, splat, slice_):
+            return BilateralConvFlex(dim, radius, n_in, n_out, args.DEVICE, use_bias=args.bcn_use_bias,
+                                     use_leaky=leaky, use_norm=args.bcn_use_norm, do_splat=splat,
+                                     do_slice=slice_, last_relu=args.last_relu, chunk_size=chunk)
+
+        self.conv1 = nn.Sequential(Conv1dReLU(dim, 32, use_leaky=leaky), Conv1dReLU(32, 32, use_leaky=leaky),
+                                   Conv1dReLU(32, 64, use_leaky=leaky))
+        feat = 64
+        corr_dim = {}                     # channels of the (refined) correlation living at level L
+        for L in range(self.NLEV):
+            setattr(self, 'bcn%d' % (L + 1), bcl(feat + dim + 1, self.DOWN, sfm[L][1], True, False))
+            if L >= 2:
+                j = L - 1
+                setattr(self, 'corr%d' % j, BilateralCorrelationFlex(
+                    dim, sfm[L][2], sfm[L][3], feat, self.CORR[0], self.CORR[1], args.DEVICE,
+                    use_bias=args.bcn_use_bias, use_leaky=leaky, use_norm=args.bcn_use_norm,
+                    prev_corr_dim=0 if L == 2 else corr_dim[L - 1], last_relu=args.last_relu,
+                    chunk_size=chunk))
+                corr_dim[L] = self.CORR[1][-1]
+                if self.REFINE:
+                    c_in = corr_dim[L] + (dim + 1 if L + 1 < self.NLEV else 0)
+                    setattr(self, 'corr%d_refine' % j, nn.Sequential(
+                        Conv1dReLU(c_in, 64, use_leaky=leaky), Conv1dReLU(64, 64, use_leaky=leaky),
+                        Conv1dReLU(64, 64, use_leaky=leaky)))
+                    corr_dim[L] = 64
+        up_out = None
+        for L in reversed(range(self.NLEV)):
+            if L == self.NLEV - 1:
+                n_in = corr_dim[L] + feat
+            else:
+                n_in = dim + 1 + up_out + (corr_dim[L] if L >= 2 else 0) + feat
+            setattr(self, 'bcn%d_' % (L + 1), bcl(n_in, self.UP[L], sfm[L][1], False, True))
+            up_out = self.UP[L][-1]
+        self.conv2 = Conv1dReLU(self.HEAD_IN, 1024, use_leaky=leaky)
+        self.conv3 = Conv1dReLU(1024, 512, use_leaky=leaky)
+        self.conv4 = nn.Conv1d(512, 3, kernel_size=1)
+
+    # -- helpers ------------------------------------------------------------------------
+    def _stack(self, x, seq, out=None):
+        mods = list(seq)
+        for i, m in enumerate(mods):
+            x = pointwise_conv(x, m.conv, True, self.use_leaky, out=out if i == len(mods) - 1 else None)
+        return x
+
+    def forward(self, pc1, pc2, generated_data):
+        dev = pc1.device
+        if not pc1.is_cuda:
+            raise _lib.HplError('the HIP path needs device tensors (no CPU fallback)')
+        lat = generated_data if isinstance(generated_data, DeviceLattice) else \
+            DeviceLattice.from_generated_data(generated_data[:self.NLEV], dev)
+        nlev = self.NLEV
+        feats = [self._stack(to_channel_last(pc1), self.conv1), self._stack(to_channel_last(pc2), self.conv1)]
+        down = [[], []]
+        corrs = {}
+        prev = None
+        for L in range(nlev):
+            lv = lat.levels[L]
+            layer = getattr(self, 'bcn%d' % (L + 1))
+            for ci in (0, 1):
+                cloud = lv.clouds[ci]
+                x = _assemble(cloud.N, [(4, lv.emg[ci]), (feats[ci].shape[1], feats[ci])], dev)
+                feats[ci] = layer.forward_cl(x, cloud, lv.blur[ci], None)
+                down[ci].append(feats[ci])
+            if L >= 2:
+                j = L - 1
+                c = getattr(self, 'corr%d' % j).forward_cl(feats[0], feats[1], prev,
+                                                          lv.clouds[0] if prev is not None else None,
+                                                          lv.corr1, lv.corr2)
+                if self.REFINE:
+                    if L + 1 < nlev:
+                        c = _assemble(c.shape[0], [(4, lat.levels[L + 1].emg[0]), (c.shape[1], c)], dev)
+                    c = self._stack(c, getattr(self, 'corr%d_refine' % j))
+                corrs[L] = c
+                prev = c
+        up = None        # callable(out_view) producing the previous Up output, or None
+        up_c = 0
+        for L in reversed(range(nlev)):
+            lv = lat.levels[L]
+            layer = getattr(self, 'bcn%d_' % (L + 1))
+            if L == nlev - 1:
+                parts = [(corrs[L].shape[1], corrs[L]), (down[0][L].shape[1], down[0][L])]
+            else:
+                parts = [(4, lat.levels[L + 1].emg[0]), (up_c, up)]
+                if L >= 2:
+                    parts.append((corrs[L].shape[1], corrs[L]))
+                parts.append((down[0][L].shape[1], down[0][L]))
+            x = _assemble(lv.H[0], parts, dev)
+
+            def produce(out, layer=layer, x=x, lv=lv):
+                return layer.forward_cl(x, None, lv.blur[0], lv.clouds[0], out=out)
+            up, up_c = produce, layer.num_output[-1]
+        y = up(None)                                           # [N, HEAD_IN]
+        y = pointwise_conv(y, self.conv2.conv, True, self.use_leaky)
+        y = pointwise_conv(y, self.conv3.conv, True, self.use_leaky)
+        y = pointwise_conv(y, self.conv4, False, self.use_leaky)
+        return to_channel_first(y)
+
+
+class HPLFlowNet(_FlowNetBase):
+    """7-level model: /root/reference/models/HPLFlowNet.py:11-430."""
+    NLEV = 7
+    DOWN = [64, 64]
+    CORR = ([32, 32], [64, 64])
+    UP = {6: [128, 128], 5: [128, 128], 4: [128, 128], 3: [256, 256], 2: [256, 256], 1: [512, 512],
+          0: [1024, 1024]}
+    REFINE = False
+    HEAD_IN = 1024
+
+
+class HPLFlowNetShallow(_FlowNetBase):
+    """5-level model: /root/reference/models/HPLFlowNet_shallow.py:11-311."""
+    NLEV = 5
+    DOWN = [64]
+    CORR = ([32], [32])
+    UP = {4: [64], 3: [64], 2: [64], 1: [64], 0: [128]}
+    REFINE = True
+    HEAD_IN = 128

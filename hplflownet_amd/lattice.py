@@ -1,0 +1,137 @@
+"""Permutohedral lattice construction on the GPU.
+
+Device counterpart of the reference's `GenerateDataUnsymmetric`
+(/root/reference/transforms/transforms.py:264-490): same constructor argument (`args.dim`,
+`args.scales_filter_map`), same call convention `gen([pc1, pc2, sf]) -> (pc1.T, pc2.T, sf.T,
+generated_data)`, but `generated_data` is a `DeviceLattice` (int32 tables, CSR and
+channel-last el_minus_gr already resident in HBM) which the models in
+hplflownet_amd.flownet consume directly; `to_reference_format()` gives the reference's
+list-of-dicts wire format (int64) for anything else.
+
+The float part is bit-identical to the reference's torch-CPU arithmetic as measured in the
+build container (see oracle/lattice_oracle.c); the integer part is exact.  One host
+synchronisation per level remains: the vertex counts size the next level's arrays.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check, ptr, stream
+from .bcl import NbrTable
+from .flownet import DeviceLattice, _Level
+
+
+def _filter_size(radius, d1=4):
+    return (radius + 1) ** d1 - radius ** d1
+
+
+class GenerateDataUnsymmetric(object):
+    def __init__(self, args, device='cuda'):
+        self.d = args.dim
+        if self.d != 3:
+            raise _lib.HplError('only d = 3 is implemented (reference configs use dim: 3)')
+        self.d1 = self.d + 1
+        self.scales_filter_map = args.scales_filter_map
+        self.expected_std = (self.d + 1) * math.sqrt(2 / 3)        # transforms.py:275
+        self.device = torch.device(device)
+
+    def build(self, pc1, pc2):
+        """pc1, pc2: (3, N) float32 device tensors -> DeviceLattice."""
+        L = _lib.load()
+        dev = pc1.device
+        last = [pc1.contiguous().float(), pc2.contiguous().float()]
+        levels = []
+        nlev = len(self.scales_filter_map)
+        for idx, (scale, bcn_r, cf_r, cc_r) in enumerate(self.scales_filter_map):
+            n = [int(last[0].shape[1]), int(last[1].shape[1])]
+            keys, bary, emg = [], [], []
+            for c in (0, 1):
+                k = torch.empty((4, n[c], 4), dtype=torch.int32, device=dev)
+                b = torch.empty((4, n[c]), dtype=torch.float32, device=dev)
+                e = torch.empty((4, n[c]), dtype=torch.float32, device=dev)
+                check(L.hpl_lattice_keys(ptr(last[c]), n[c], float(scale), ptr(k), ptr(b), ptr(e), stream()),
+                      'hpl_lattice_keys')
+                keys.append(k); bary.append(b); emg.append(e)
+            wsb = int(L.hpl_lattice_workspace_bytes(n[0], n[1]))
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            off = [torch.empty((4, n[c]), dtype=torch.int32, device=dev) for c in (0, 1)]
+            vk = [torch.empty((4, 4 * n[c]), dtype=torch.int32, device=dev) for c in (0, 1)]
+            counts = torch.empty(2, dtype=torch.int32, device=dev)
+            check(L.hpl_lattice_hash(ptr(keys[0]), n[0], ptr(keys[1]), n[1], ptr(off[0]), ptr(off[1]), ptr(vk[0]),
+                                     ptr(vk[1]), ptr(counts), ptr(ws), wsb, stream()), 'hpl_lattice_hash')
+            H = [int(v) for v in counts.tolist()]                  # host sync: sizes of the next arrays
+            blur = [None, None]
+            corr1 = corr2 = None
+            if bcn_r != -1:
+                F = _filter_size(bcn_r)
+                blur = [torch.empty((F, H[c]), dtype=torch.int32, device=dev) for c in (0, 1)]
+            if cf_r != -1:
+                corr1 = torch.empty((_filter_size(cc_r), H[0]), dtype=torch.int32, device=dev)
+                corr2 = torch.empty((_filter_size(cc_r), _filter_size(cf_r) * H[0]), dtype=torch.int32, device=dev)
+            check(L.hpl_lattice_neighbors(ptr(ws), n[0], n[1], ptr(vk[0]), ptr(vk[1]), H[0], H[1], int(bcn_r),
+                                          int(cf_r), int(cc_r), ptr(blur[0]), ptr(blur[1]), ptr(corr1),
+                                          ptr(corr2), stream()), 'hpl_lattice_neighbors')
+            lv = _Level()
+            lv.H = (H[0], H[1])
+            lv.clouds = [ops.CloudTables(bary[c], off[c], H[c]) for c in (0, 1)]
+            lv.blur = [NbrTable(b) if b is not None else None for b in blur]
+            lv.emg = [emg[c].t().contiguous() for c in (0, 1)]
+            lv.corr1 = NbrTable(corr1) if corr1 is not None else None
+            lv.corr2 = NbrTable(corr2) if corr2 is not None else None
+            if lv.corr2 is not None:
+                lv.corr2._sym = False
+            lv.corr_shape = (_filter_size(cf_r), _filter_size(cc_r)) if cf_r != -1 else None
+            levels.append(lv)
+            if idx != nlev - 1:
+                div = float(np.float32(self.expected_std * scale))         # transforms.py:462-463
+                nxt = []
+                for c in (0, 1):
+                    o = torch.empty((3, H[c]), dtype=torch.float32, device=dev)
+                    check(L.hpl_lattice_next_points(ptr(vk[c]), 4 * n[c], H[c], div, ptr(o), stream()),
+                          'hpl_lattice_next_points')
+                    nxt.append(o)
+                last = nxt
+        return DeviceLattice(levels)
+
+    def __call__(self, data):
+        pc1, pc2, sf = data
+        if pc1 is None:                                                    # transforms.py:360-361
+            return None, None, None, None
+        with torch.no_grad():
+            t1 = torch.as_tensor(pc1).to(self.device).t().contiguous()
+            t2 = torch.as_tensor(pc2).to(self.device).t().contiguous()
+            tsf = torch.as_tensor(sf).to(self.device).t().contiguous()
+            return t1, t2, tsf, self.build(t1, t2)
+
+    def __repr__(self):
+        return '%s\n(scales_filter_map: %s\n)' % (self.__class__.__name__, self.scales_filter_map)
+
+
+def to_reference_format(lat):
+    """DeviceLattice -> the reference's generated_data (transforms.py:471-483): list of dicts of
+    int64 / float32 tensors (on the device), absent tables as zeros(1)."""
+    out = []
+    for lv in lat.levels:
+        d = {}
+        for c, nm in enumerate(('pc1', 'pc2')):
+            cl = lv.clouds[c]
+            d[nm + '_barycentric'] = cl.bary
+            d[nm + '_el_minus_gr'] = lv.emg[c].t().contiguous()
+            d[nm + '_lattice_offset'] = cl.off.long()
+            d[nm + '_blur_neighbors'] = lv.blur[c].t.long() if lv.blur[c] is not None else \
+                torch.zeros(1, dtype=torch.long, device=cl.bary.device)
+            d[nm + '_hash_cnt'] = lv.H[c]
+        if lv.corr1 is not None:
+            K = lv.corr1.t.shape[0]
+            H1 = lv.H[0]
+            F = lv.corr2.t.shape[1] // H1
+            d['pc1_corr_indices'] = lv.corr1.t.long()
+            d['pc2_corr_indices'] = lv.corr2.t.view(K, F, H1).permute(1, 0, 2).contiguous().long()
+        else:
+            z = torch.zeros(1, dtype=torch.long, device=lv.clouds[0].bary.device)
+            d['pc1_corr_indices'] = z
+            d['pc2_corr_indices'] = z.clone()
+        out.append(d)
+    return out

@@ -1,0 +1,319 @@
+"""Tensor-level wrappers and autograd glue over the C ABI (include/hpl_bcl.h).
+
+Everything here is host-side plumbing: shapes are checked, outputs are allocated as
+torch tensors, and the HIP library does the work on the current stream.  Activations
+are channel-last 2-D float32 tensors `[rows, channels]` with unit channel stride (the
+row stride may exceed the channel count: column slices of wider buffers are fine).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GConvDesc, check, ptr, stream
+
+ACT_NONE, ACT_LEAKY = 0, 1
+LEAKY_RATE = 0.1   # reference: models/module_utils.py:6
+
+
+def _cl(x, what='activation'):
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or (x.shape[1] > 1 and x.stride(1) != 1):
+        raise _lib.HplError('%s must be a channel-last 2-D float32 device tensor with unit channel stride, '
+                            'got shape %s strides %s dtype %s device %s'
+                            % (what, tuple(x.shape), x.stride(), x.dtype, x.device))
+    return x
+
+
+def _ld(x):
+    return x.stride(0) if x.shape[0] > 1 else max(x.shape[1], x.stride(0))
+
+
+# --------------------------------------------------------------------------- tables
+def narrow(t):
+    """int64 device table (reference wire format) -> contiguous int32."""
+    if t.dtype == torch.int32:
+        return t.contiguous()
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=torch.int32, device=t.device)
+    check(_lib.load().hpl_index_narrow(ptr(t), ptr(out), t.numel(), stream()), 'hpl_index_narrow')
+    return out
+
+
+def corr2_permute(t):
+    """pc2_corr_indices [F, K, H] (int64 or int32) -> int32 [K, F*H]."""
+    t = t.contiguous()
+    F, K, H = t.shape
+    out = torch.empty((K, F * H), dtype=torch.int32, device=t.device)
+    fn = _lib.load().hpl_corr2_permute if t.dtype == torch.int64 else _lib.load().hpl_corr2_permute32
+    check(fn(ptr(t), ptr(out), F, K, H, stream()), 'hpl_corr2_permute')
+    return out
+
+
+class CloudTables(object):
+    """Device-resident tables of one cloud at one lattice level.
+
+    bary [4, N] f32, off [4, N] i32 (vertex of each (remainder, point)), H vertices,
+    CSR of the splat (csr_ptr/csr_pt/csr_w) and the density normaliser `norm` [H]."""
+
+    def __init__(self, bary, off, H, blur=None):
+        self.bary = bary.contiguous().float()
+        self.off = narrow(off)
+        self.N = int(self.bary.shape[1])
+        self.H = int(H)
+        self.blur = narrow(blur) if blur is not None else None
+        self._csr = None
+        self._sym = {}
+
+    def csr(self):
+        if self._csr is None:
+            dev = self.bary.device
+            csr_ptr = torch.empty(self.H + 1, dtype=torch.int32, device=dev)
+            csr_pt = torch.empty(4 * self.N, dtype=torch.int32, device=dev)
+            csr_w = torch.empty(4 * self.N, dtype=torch.float32, device=dev)
+            norm = torch.empty(self.H, dtype=torch.float32, device=dev)
+            scratch = torch.empty(self.H + 1, dtype=torch.int32, device=dev)
+            check(_lib.load().hpl_csr_build(ptr(self.off), ptr(self.bary), 4 * self.N, self.N, self.H, ptr(csr_ptr),
+                                            ptr(csr_pt), ptr(csr_w), ptr(norm), ptr(scratch), stream()),
+                  'hpl_csr_build')
+            self._csr = (csr_ptr, csr_pt, csr_w, norm)
+        return self._csr
+
+
+def table_is_symmetric(nbr):
+    """nbr[f, h] = g  =>  nbr[(F - f) % F, g] = h  (SURVEY.md fact 7).  One host sync."""
+    F, H = nbr.shape
+    if F != 15:
+        return False
+    f = torch.arange(1, F, device=nbr.device)
+    g = nbr[f].long()
+    valid = g >= 0
+    back = nbr[(F - f)].long().gather(1, g.clamp(min=0))
+    hh = torch.arange(H, device=nbr.device)[None, :].expand_as(g)
+    ok = ((back == hh) | ~valid).all() & (nbr[0].long() == torch.arange(H, device=nbr.device)).all()
+    return bool(ok.item())
+
+
+# --------------------------------------------------------------------------- raw ops
+def splat_raw(feat, csr, H, use_norm=True, out=None):
+    feat = _cl(feat)
+    csr_ptr, csr_pt, csr_w, norm = csr
+    C = feat.shape[1]
+    if out is None:
+        out = torch.empty((H, C), dtype=torch.float32, device=feat.device)
+    _cl(out, 'out')
+    check(_lib.load().hpl_splat(ptr(feat), _ld(feat), C, ptr(csr_ptr), ptr(csr_pt), ptr(csr_w),
+                                ptr(norm) if use_norm else None, H, ptr(out), _ld(out), stream()), 'hpl_splat')
+    return out
+
+
+def slice_raw(Y, bary, off, N, vscale=None, bias=None, out=None):
+    Y = _cl(Y)
+    C = Y.shape[1]
+    if out is None:
+        out = torch.empty((N, C), dtype=torch.float32, device=Y.device)
+    _cl(out, 'out')
+    check(_lib.load().hpl_slice(ptr(Y), _ld(Y), C, ptr(bary), ptr(off), N, ptr(vscale), ptr(bias), ptr(out),
+                                _ld(out), stream()), 'hpl_slice')
+    return out
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def weight_relayout(W, R, Q, F, sr, sq, sf, base=0, fmap=None):
+    """-> Wt [roundup(F*R, 32), roundup(Q, 4)] with Wt[(fmap[f]*R + r), q] = W.flat[base + r*sr + q*sq + f*sf]."""
+    k_rows = round_up(F * R, 32)
+    ldw = round_up(Q, 4)
+    Wt = torch.empty((k_rows, ldw), dtype=torch.float32, device=W.device)
+    check(_lib.load().hpl_weight_relayout(ptr(W), base, R, Q, F, sr, sq, sf, ptr(fmap), ptr(Wt), k_rows, ldw,
+                                          stream()), 'hpl_weight_relayout')
+    return Wt
+
+
+def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
+              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE):
+    """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n])."""
+    A = _cl(A)
+    d = GConvDesc()
+    d.A, d.lda, d.rows_a = ptr(A), _ld(A), A.shape[0]
+    if nbr is not None:
+        if nbr.dtype != torch.int32 or nbr.dim() != 2 or nbr.shape[0] != F or nbr.shape[1] != M or \
+                not nbr.is_contiguous():
+            raise _lib.HplError('neighbour table must be contiguous int32 [F=%d, M=%d], got %s %s'
+                                % (F, M, tuple(nbr.shape), nbr.dtype))
+        d.nbr, d.nbr_stride = ptr(nbr), nbr.stride(0)
+    else:
+        if F != 1:
+            raise _lib.HplError('F > 1 needs a neighbour table')
+        d.nbr, d.nbr_stride = None, 0
+    d.reg_stride = 0
+    d.M, d.C, d.F = M, C, F
+    if C > A.shape[1]:
+        raise _lib.HplError('C=%d exceeds the %d channels of A' % (C, A.shape[1]))
+    if Wt.shape[0] < round_up(F * C, 32) or Wt.shape[1] < N or not Wt.is_contiguous():
+        raise _lib.HplError('Wt %s too small for K=%d N=%d' % (tuple(Wt.shape), F * C, N))
+    d.Wt, d.ldw, d.N = ptr(Wt), Wt.shape[1], N
+    d.act, d.slope = act, slope
+    d.bias = ptr(bias)
+    if res is not None:
+        _cl(res, 'res')
+        d.res, d.ldres, d.res_mod = ptr(res), _ld(res), res_mod or res.shape[0]
+    if scat is not None:
+        if out is None:
+            raise _lib.HplError('scatter epilogue needs a zero-initialised `out`')
+        d.scat, d.scat_stride, d.scat_c = ptr(scat), scat.stride(0), scat_c
+    elif out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    _cl(out, 'out')
+    d.Y, d.ldy = ptr(out), _ld(out)
+    fn = _lib.load().hpl_gconv_forward_naive if naive else _lib.load().hpl_gconv_forward
+    check(fn(ctypes.byref(d), stream()), 'hpl_gconv_forward')
+    return out
+
+
+def wgrad_raw(A, nbr, M, C, F, dY, N):
+    """-> dWt [roundup(F*C,32), roundup(N,4)] = sum_m A[nbr[f,m], c] * dY[m, n]."""
+    A, dY = _cl(A), _cl(dY, 'dY')
+    dWt = torch.zeros((round_up(F * C, 32), round_up(N, 4)), dtype=torch.float32, device=A.device)
+    check(_lib.load().hpl_gconv_wgrad(ptr(A), _ld(A), A.shape[0], ptr(nbr), nbr.stride(0) if nbr is not None else 0,
+                                      0, M, C, F, ptr(dY), _ld(dY), N, ptr(dWt), dWt.shape[1], stream()),
+          'hpl_gconv_wgrad')
+    return dWt
+
+
+def colsum(X):
+    X = _cl(X)
+    out = torch.empty(X.shape[1], dtype=torch.float32, device=X.device)
+    check(_lib.load().hpl_colsum(ptr(X), _ld(X), X.shape[0], X.shape[1], ptr(out), stream()), 'hpl_colsum')
+    return out
+
+
+def leaky_bwd(dY, Y, slope=LEAKY_RATE):
+    dY, Y = _cl(dY, 'dY'), _cl(Y, 'Y')
+    dX = torch.empty(tuple(Y.shape), dtype=torch.float32, device=Y.device)
+    check(_lib.load().hpl_leaky_bwd(ptr(dY), _ld(dY), ptr(Y), _ld(Y), slope, ptr(dX), _ld(dX), Y.shape[0],
+                                    Y.shape[1], stream()), 'hpl_leaky_bwd')
+    return dX
+
+
+# --------------------------------------------------------------------------- autograd
+class SplatFn(torch.autograd.Function):
+    """splat + density normalisation (models/bilateralNN.py:151-186); backward is a slice
+    weighted by the normaliser (SparseSum.backward, bilateralNN.py:33-40)."""
+
+    @staticmethod
+    def forward(ctx, feat, cloud, use_norm):
+        ctx.cloud, ctx.use_norm = cloud, use_norm
+        return splat_raw(feat, cloud.csr(), cloud.H, use_norm)
+
+    @staticmethod
+    def backward(ctx, g):
+        c = ctx.cloud
+        g = g if g.stride(1) == 1 else g.contiguous()
+        norm = c.csr()[3] if ctx.use_norm else None
+        return slice_raw(g, c.bary, c.off, c.N, vscale=norm), None, None
+
+
+class SliceFn(torch.autograd.Function):
+    """slice + bias (models/bilateralNN.py:223-238); backward w.r.t. Y is an un-normalised splat."""
+
+    @staticmethod
+    def forward(ctx, Y, cloud, bias):
+        ctx.cloud = cloud
+        ctx.has_bias = bias is not None
+        return slice_raw(Y, cloud.bary, cloud.off, cloud.N, bias=bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        c = ctx.cloud
+        g = g if g.stride(1) == 1 else g.contiguous()
+        gY = splat_raw(g, c.csr(), c.H, use_norm=False)
+        gb = colsum(g) if ctx.has_bias else None
+        return gY, None, gb
+
+
+def _mirror_map(F, device):
+    # tap f of the forward table is tap (F - f) % F seen from the neighbour
+    return ((F - torch.arange(F, device=device)) % F).to(torch.int32)
+
+
+class GConvFn(torch.autograd.Function):
+    """Gathered convolution Y = act(b + sum_f W_f . A[nbr[f]]) with the conv weight in its torch
+    layout `weight.view(O, Ctot, F)`; channels [c0, c0+C) of the weight are used.
+
+    bwd_mode: 'mirror' (symmetric table over the same vertex set: gather with mirrored taps),
+              'scatter' (any table: fp32 atomics), 'dense' (no table)."""
+
+    @staticmethod
+    def forward(ctx, A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope):
+        O = weight.shape[0]
+        Ctot = weight.numel() // (O * F)
+        Wt = weight_relayout(weight, C, O, F, F, Ctot * F, 1, base=c0 * F)
+        Y = gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=act, res=res, res_mod=res_mod, slope=slope)
+        ctx.slope = slope
+        ctx.save_for_backward(A, weight, nbr, Y if act != ACT_NONE else None)
+        ctx.cfg = (M, c0, C, F, act, res is not None, res_mod, bwd_mode, bias is not None, Ctot)
+        return Y
+
+    @staticmethod
+    def backward(ctx, g):
+        A, weight, nbr, Y = ctx.saved_tensors
+        M, c0, C, F, act, has_res, res_mod, bwd_mode, has_bias, Ctot = ctx.cfg
+        O = weight.shape[0]
+        g = g if (g.dim() == 2 and g.stride(1) == 1) else g.contiguous()
+        if act == ACT_LEAKY:
+            g = leaky_bwd(g, Y, ctx.slope)
+        gA = gW = gb = gres = None
+        if ctx.needs_input_grad[0]:
+            rows = A.shape[0]
+            if bwd_mode == 'dense':
+                WtT = weight_relayout(weight, O, C, 1, Ctot * F, F, 1, base=c0 * F)
+                gA_c = gconv_raw(g, None, M, O, 1, WtT, C)
+            elif bwd_mode == 'mirror':
+                if rows != M:
+                    raise _lib.HplError('mirror backward needs a table over the same vertex set')
+                WtT = weight_relayout(weight, O, C, F, Ctot * F, F, 1, base=c0 * F,
+                                      fmap=_mirror_map(F, weight.device))
+                gA_c = gconv_raw(g, nbr, M, O, F, WtT, C)
+            else:   # scatter: G[m, (f, c)] = g[m] . W[:, c, f], added into row nbr[f, m]
+                # columns ordered (f, c): source element (o, f*C + c) = W[o, c0 + c, f]
+                Wcols = weight.view(O, Ctot, F)[:, c0:c0 + C, :].permute(0, 2, 1).reshape(O, F * C).contiguous()
+                WtS = weight_relayout(Wcols, O, F * C, 1, F * C, 1, 1)
+                gA_c = torch.zeros((rows, C), dtype=torch.float32, device=A.device)
+                gconv_raw(g, None, M, O, 1, WtS, F * C, out=gA_c, scat=nbr, scat_c=C)
+            if C == A.shape[1]:
+                gA = gA_c
+            else:
+                gA = torch.zeros_like(A)
+                gA[:, :C] = gA_c
+        if ctx.needs_input_grad[1]:
+            dWt = wgrad_raw(A, nbr, M, C, F, g, O)
+            gW = torch.zeros_like(weight)
+            check(_lib.load().hpl_weight_unlayout(ptr(dWt), dWt.shape[1], C, O, F, ptr(gW), c0 * F, F, Ctot * F, 1,
+                                                  0, stream()), 'hpl_weight_unlayout')
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = colsum(g)
+        if has_res and ctx.needs_input_grad[9]:
+            if res_mod and res_mod != M:
+                gres = g.view(M // res_mod, res_mod, O).sum(dim=0)
+            else:
+                gres = g
+        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None
+
+
+def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_mod=0, bwd_mode='scatter',
+          out=None, slope=LEAKY_RATE):
+    """Autograd-aware gathered convolution; with grad disabled it can write into `out`."""
+    O = weight.shape[0]
+    Ctot = weight.numel() // (O * F)
+    C = Ctot if C is None else C
+    if torch.is_grad_enabled() and (A.requires_grad or weight.requires_grad or
+                                    (res is not None and res.requires_grad)):
+        y = GConvFn.apply(A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    Wt = weight_relayout(weight.detach(), C, O, F, F, Ctot * F, 1, base=c0 * F)
+    return gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope)

@@ -1,0 +1,218 @@
+/*
+ * hpl_bcl.h -- C ABI of libhplbcl.so: the MI355X (gfx950) implementation of
+ * HPLFlowNet's bilateral-convolution hot path.
+ *
+ * This is the drop-in boundary (SURVEY.md §8 b).  The reference has no native ops
+ * for the layer half of the path (it composes ATen calls) and a 4-function khash
+ * FFI for the lattice half; each entry point below names the reference lines it
+ * replaces (paths relative to the reference repository root).  All pointers are
+ * DEVICE pointers unless marked HOST; all kernels are enqueued on `stream`
+ * (a hipStream_t passed as void*) and return without synchronising.  No torch
+ * types appear here: hplflownet_amd/_lib.py binds this header with ctypes and
+ * passes tensor.data_ptr() values.
+ *
+ * Conventions
+ *   - activations are CHANNEL-LAST float32: X[row * ld + channel]; `ld` (row stride
+ *     in floats) lets a kernel read or write a column slice of a wider buffer, which
+ *     is how the torch.cat calls of models/HPLFlowNet.py:242-423 disappear;
+ *   - index tables are int32 (converted once per sample from the reference's int64
+ *     wire format); -1 means "no such lattice vertex" and reads as
+ *     an all-zero row (the reference's "+1 / zero column" trick,
+ *     models/bilateralNN.py:158-162,215-217);
+ *   - float4 fast paths need ld % 4 == 0, channel counts % 4 == 0 and 16-byte
+ *     aligned bases; other shapes take a scalar path (same results).
+ *   - return value: 0 on success, negative HPL_E* on failure; hpl_last_error()
+ *     gives the message of the calling thread's last failure.
+ */
+#ifndef HPL_BCL_H
+#define HPL_BCL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPL_OK 0
+#define HPL_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define HPL_EHIP (-2)     /* a HIP runtime call or kernel launch failed */
+#define HPL_ENODEV (-3)   /* no gfx950 device visible */
+
+#define HPL_ACT_NONE 0
+#define HPL_ACT_LEAKY 1   /* y > 0 ? y : slope * y   (models/module_utils.py:6,14) */
+
+typedef void *hplStream;
+
+int hpl_version(void);
+const char *hpl_last_error(void);
+/* HOST outputs. arch receives e.g. "gfx950". */
+int hpl_device_info(int device, int *cu_count, int *wave_size, char *arch, int arch_len);
+
+/* ------------------------------------------------------------------------ *
+ * Index tables
+ * ------------------------------------------------------------------------ */
+/* int64 -> int32 narrowing of any reference table (lattice_offset, blur_neighbors,
+ * pc1_corr_indices; transforms/transforms.py:471-483). */
+int hpl_index_narrow(const int64_t *src, int32_t *dst, int64_t n, hplStream stream);
+
+/* pc2_corr_indices [F][K][H] int64 (models/bnn_flow.py:195-197, index order
+ * transforms/transforms.py:232-241) -> int32 [K][F*H]: row k of the result is the
+ * neighbour table of the F*H "virtual vertices" m = f*H + h used by the
+ * patch-correlation gather-GEMM. */
+int hpl_corr2_permute(const int64_t *src, int32_t *dst, int F, int K, int64_t H, hplStream stream);
+/* same from an int32 [F][K][H] source (device-built lattices) */
+int hpl_corr2_permute32(const int32_t *src, int32_t *dst, int F, int K, int64_t H, hplStream stream);
+
+/* CSR of the splat: for `off` (int32, n_entries values in [0,H); for a lattice_offset table
+ * entry e = r*N + n and n_entries = 4*N) and per-entry weights `bary` ([n_entries]) produce
+ *   csr_ptr [H+1]        segment bounds per vertex,
+ *   csr_pt  [n_entries]  source row (e % pt_mod; pt_mod = N gives the point index) of each
+ *                        contribution, ascending e within a vertex,
+ *   csr_w   [n_entries]  its weight,
+ *   norm    [H]          1 / (sum of weights + 1e-5)   (models/bilateralNN.py:168-183).
+ * `scratch` needs (H + 1) int32.  Replaces the COO coalesce inside
+ * torch.sparse.FloatTensor(...).to_dense() (models/bilateralNN.py:24-29): the sort is
+ * done once per lattice instead of once per layer call, and is deterministic. */
+int hpl_csr_build(const int32_t *off, const float *bary, int64_t n_entries, int64_t pt_mod, int64_t H,
+                  int32_t *csr_ptr, int32_t *csr_pt, float *csr_w, float *norm,
+                  int32_t *scratch, hplStream stream);
+
+/* ------------------------------------------------------------------------ *
+ * Splat / slice  (HBM-bound gathers)
+ * ------------------------------------------------------------------------ */
+/* out[v, c] = (norm ? norm[v] : 1) * sum_{j in csr(v)} csr_w[j] * feat[csr_pt[j], c]
+ * Forward splat + density normalisation: models/bilateralNN.py:151-186 and
+ * models/bnn_flow.py:119-151 (SparseSum.forward, bilateralNN.py:9-30).
+ * With norm == NULL it is also the backward of hpl_slice w.r.t. Y. */
+int hpl_splat(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr, const int32_t *csr_pt,
+              const float *csr_w, const float *norm, int64_t H, float *out, int64_t ldo,
+              hplStream stream);
+
+/* out[n, c] = (bias ? bias[c] : 0) + sum_{r<4} bary[r*N+n] * (vscale ? vscale[v] : 1) * Y[v, c],
+ * v = off[r*N+n].   Slice + bias: models/bilateralNN.py:223-238.  With vscale = norm it is
+ * also the backward of hpl_splat w.r.t. feat (SparseSum.backward, bilateralNN.py:33-40). */
+int hpl_slice(const float *Y, int64_t ldy, int C, const float *bary, const int32_t *off, int64_t N,
+              const float *vscale, const float *bias, float *out, int64_t ldo, hplStream stream);
+
+/* ------------------------------------------------------------------------ *
+ * Per-vertex dense contraction: gather-GEMM on fp32 MFMA
+ * ------------------------------------------------------------------------ */
+/* Weight re-layout.  Source element (r, q, f) lives at W[base + r*sr + q*sq + f*sf];
+ * destination Wt[(fdst*R + r) * ldw + q] with fdst = fmap ? fmap[f] : f.  Rows beyond
+ * F*R (up to k_rows) and columns beyond Q (up to ldw) are zero-filled.
+ *   forward  of Conv2d (O,C,F,1) / Conv3d (O,Ctot,1,K,1) / Conv1d (O,C,1):
+ *            r = input channel, q = output channel  -> Wt[(f*C + c)][o]
+ *   backward-data: r = output channel, q = input channel, fmap[f] = (15-f)%15 style
+ *            mirror. */
+int hpl_weight_relayout(const float *W, int64_t base, int R, int Q, int F, int64_t sr, int64_t sq,
+                        int64_t sf, const int32_t *fmap, float *Wt, int64_t k_rows, int64_t ldw,
+                        hplStream stream);
+/* inverse scatter for weight gradients: W[base + r*sr + q*sq + f*sf] (+)= Wt[(f*R + r)*ldw + q] */
+int hpl_weight_unlayout(const float *Wt, int64_t ldw, int R, int Q, int F, float *W, int64_t base,
+                        int64_t sr, int64_t sq, int64_t sf, int accumulate, hplStream stream);
+
+typedef struct hpl_gconv_desc {
+    /* A operand: rows of a channel-last matrix, gathered through a neighbour table */
+    const float *A;         /* [rows_a][lda] */
+    int64_t lda;
+    int64_t rows_a;         /* rows addressable in A (indices are checked against it in debug) */
+    const int32_t *nbr;     /* nbr[f * nbr_stride + m] in [-1, rows_a); NULL: see reg_stride */
+    int64_t nbr_stride;
+    int64_t reg_stride;     /* used when nbr == NULL: source row = f * reg_stride + m
+                               (F == 1, reg_stride == 0 is a plain GEMM) */
+    int64_t M;              /* output rows (lattice vertices, or F*H virtual vertices) */
+    int32_t C;              /* channels taken from each gathered row */
+    int32_t F;              /* filter taps; contraction length K = F * C */
+    /* B operand: re-laid-out weights (hpl_weight_relayout) */
+    const float *Wt;        /* [>= roundup(F*C, 32)][ldw], zero padded */
+    int64_t ldw;            /* multiple of 4, >= N */
+    int32_t N;              /* output channels */
+    int32_t act;            /* HPL_ACT_* applied after bias and residual */
+    float slope;
+    const float *bias;      /* [N] or NULL */
+    const float *res;       /* optional addend res[(m % res_mod) * ldres + n] (before act) */
+    int64_t ldres;
+    int64_t res_mod;
+    float *Y;               /* [M][ldy] */
+    int64_t ldy;
+    /* optional scatter epilogue (backward-data through a non-symmetric table): when
+     * scat != NULL the result is NOT stored to Y[m]; column n = k*scat_c + c is
+     * atomically added to Y[scat[k*scat_stride + m] * ldy + c] (skipped when < 0). */
+    const int32_t *scat;
+    int64_t scat_stride;
+    int32_t scat_c;
+    int32_t reserved;
+} hpl_gconv_desc;
+
+/* Y[m, n] = act(bias[n] + res[...] + sum_{f<F, c<C} A[nbr[f][m], c] * Wt[f*C + c, n]).
+ * One call covers: the blur Conv2d((15,1)) over gathered neighbours
+ * (models/bilateralNN.py:199-221), every 1x1 Conv2d/Conv3d/Conv1d that follows
+ * (bilateralNN.py:219, bnn_flow.py:202-205, HPLFlowNet.py:239-240,426-428), the patch
+ * correlation Conv3d((1,15,1)) split into its f-independent pc1 half and its pc2 half
+ * (bnn_flow.py:189-202) and the displacement filter Conv2d((15,1))
+ * (bnn_flow.py:205).  The gathered tensor is never materialised. */
+int hpl_gconv_forward(const hpl_gconv_desc *desc /* HOST */, hplStream stream);
+/* same contract, one thread per output element, no MFMA: test/debug reference only */
+int hpl_gconv_forward_naive(const hpl_gconv_desc *desc /* HOST */, hplStream stream);
+
+/* dWt[f*C + c, n] (+)= sum_m A[nbr[f][m], c] * dY[m, n]    (weight gradient; split over m
+ * with fp32 atomics, so dWt must be zero-initialised by the caller unless accumulating) */
+int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, const int32_t *nbr,
+                    int64_t nbr_stride, int64_t reg_stride, int64_t M, int C, int F,
+                    const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
+                    hplStream stream);
+
+/* out[n] = sum_m X[m*ld + n]   (bias gradients) */
+int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStream stream);
+/* dX = dY * (Y > 0 ? 1 : slope)   element-wise on [M][N] views (LeakyReLU backward) */
+int hpl_leaky_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, float slope,
+                  float *dX, int64_t lddx, int64_t M, int N, hplStream stream);
+/* dst[m*ldd + c] = src[c*lds + m]  (channel-first <-> channel-last at the API edge) */
+int hpl_transpose(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t rows_src,
+                  int64_t cols_src, hplStream stream);
+
+/* ------------------------------------------------------------------------ *
+ * Lattice construction on the device (replaces the Numba + CFFI khash path:
+ * transforms/transforms.py:133-261,300-353,358-485 and models/khash_int2int.h:8-33)
+ * ------------------------------------------------------------------------ */
+/* Float part, transforms/transforms.py:300-353.  pc (3, N) float32 (unscaled), the level
+ * scale is applied inside (:377-378).  keys: int32 [4 coord][N][4 remainder]; bary, emg
+ * (4, N).  Bit-identical to oracle/lattice_oracle.c (explicit fmaf chain, half-even
+ * rounding, stable descending rank). */
+int hpl_lattice_keys(const float *pc, int64_t N, float scale, int32_t *keys, float *bary,
+                     float *emg, hplStream stream);
+
+/* Integer part, stage 1 (transforms/transforms.py:171-207 and :384-391): per-coordinate
+ * key range over both clouds, mixed-radix packing (key2int, :70-86), one open-addressing
+ * 64-bit table per cloud -- each workgroup first deduplicates its 1024 keys in an LDS
+ * table, then only distinct keys CAS into the global table -- and vertex ids in
+ * first-appearance order (points outer, remainder inner).  Outputs:
+ *   off1/off2 int32 [4][n]   lattice_offset
+ *   vkeys1/2  int32 [4][4n]  key of every vertex (first H columns valid)
+ *   counts    int32 [2]      H1, H2  (DEVICE; the host reads them to size stage 2)
+ * `workspace` (hpl_lattice_workspace_bytes(n1, n2) bytes) keeps the tables for stage 2. */
+int64_t hpl_lattice_workspace_bytes(int64_t n1, int64_t n2);
+int hpl_lattice_hash(const int32_t *keys1, int64_t n1, const int32_t *keys2, int64_t n2,
+                     int32_t *off1, int32_t *off2, int32_t *vkeys1, int32_t *vkeys2,
+                     int32_t *counts, void *workspace, int64_t workspace_bytes, hplStream stream);
+
+/* Integer part, stage 2 (transforms/transforms.py:209-255): neighbour tables by hash lookup.
+ * Radius -1 skips a table (pointer may be NULL).  H1, H2 are the counts read back from
+ * stage 1.  blur1 [F][H1], blur2 [F][H2], corr1 [K][H1]; corr2 is written directly in the
+ * kernel-ready permuted layout [K][F*H1] (see hpl_corr2_permute).  Misses are -1; like the
+ * reference, neighbour keys are packed without a range check. */
+int hpl_lattice_neighbors(const void *workspace, int64_t n1, int64_t n2,
+                          const int32_t *vkeys1, const int32_t *vkeys2, int64_t H1, int64_t H2,
+                          int bcn_radius, int corr_filter_radius, int corr_corr_radius,
+                          int32_t *blur1, int32_t *blur2, int32_t *corr1, int32_t *corr2,
+                          hplStream stream);
+
+/* Next level's points (transforms.py:461-467): out (3, H) = E^T (vkeys / divisor), divisor =
+ * (float)(expected_std * scale) computed by the caller in double like the reference. */
+int hpl_lattice_next_points(const int32_t *vkeys, int64_t vstride, int64_t H, float divisor,
+                            float *out, hplStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPL_BCL_H */

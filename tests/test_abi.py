@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads and exports every symbol include/hpl_bcl.h declares; the ctypes
+mirror of hpl_gconv_desc matches the header; the product path refuses to run without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from common import ROOT
+from hplflownet_amd import _lib
+
+
+def header_text():
+    return open(os.path.join(ROOT, 'include', 'hpl_bcl.h')).read()
+
+
+def test_header_symbols_exported():
+    hdr = header_text()
+    body = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(hpl_[a-z0-9_]+)\s*\(', body))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.load()                      # resolves each symbol, sets argtypes
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.hpl_version() >= 100
+
+
+def test_gconv_desc_layout_matches_header():
+    hdr = header_text()
+    struct = hdr[hdr.index('typedef struct hpl_gconv_desc {'):hdr.index('} hpl_gconv_desc;')]
+    struct = re.sub(r'/\*.*?\*/', '', struct, flags=re.S)
+    fields = re.findall(r'(?:const\s+)?(?:float|int32_t|int64_t)\s*\*?\s*(\w+);', struct)
+    assert fields == [f[0] for f in _lib.GConvDesc._fields_]
+    assert ctypes.sizeof(_lib.GConvDesc) == 8 * 3 + 8 * 3 + 8 + 4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 4 + 4
+
+
+def test_no_cpu_fallback():
+    import hplflownet_amd as H
+    m = H.BilateralConvFlex(3, 1, 8, [8], 'cpu', True, True, True, False, False, False)
+    with pytest.raises(_lib.HplError):
+        m(torch.zeros(1, 8, 5), None, None, torch.zeros(1, 15, 5, dtype=torch.long), None, None)
+    with pytest.raises(_lib.HplError):
+        H.sparse_sum(torch.zeros(1, 4, dtype=torch.long), torch.zeros(4, 3), torch.Size([5, 3]), False)
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    d = _lib.GConvDesc()
+    assert lib.hpl_gconv_forward(ctypes.byref(d), None) == -1          # HPL_EINVAL: null pointers
+    assert b'null' in lib.hpl_last_error()
+    assert lib.hpl_splat(None, 0, 4, None, None, None, None, 1, None, 0, None) == -1
+    assert lib.hpl_lattice_workspace_bytes(8192, 8192) > 0
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'hplflownet_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert 'import oracle' not in src and 'from oracle' not in src, fn

@@ -1,0 +1,259 @@
+"""GPU: every HIP kernel through the C ABI against numpy/oracle on seeded inputs.
+Integer outputs bit-exact; fp32 outputs within 1e-5 (relative to the tensor's max-abs) of a
+float64 evaluation unless a looser bound is stated next to the assert."""
+import numpy as np
+import pytest
+import torch
+
+from common import oracle_lattice, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from hplflownet_amd import ops as o
+    return o
+
+
+def test_device_is_gfx950():
+    import ctypes
+    from hplflownet_amd import _lib
+    cu, ws = ctypes.c_int(0), ctypes.c_int(0)
+    arch = ctypes.create_string_buffer(64)
+    _lib.check(_lib.load().hpl_device_info(0, ctypes.byref(cu), ctypes.byref(ws), arch, 64), 'hpl_device_info')
+    assert arch.value.decode().startswith('gfx950'), arch.value
+    assert ws.value == 64 and cu.value == 256
+
+
+def test_narrow_and_permute(ops):
+    rng = np.random.RandomState(0)
+    a = rng.randint(-1, 5000, size=(15, 777)).astype(np.int64)
+    assert np.array_equal(ops.narrow(dev(a)).cpu().numpy(), a.astype(np.int32))
+    c2 = rng.randint(-1, 900, size=(15, 15, 333)).astype(np.int64)
+    want = c2.transpose(1, 0, 2).reshape(15, 15 * 333).astype(np.int32)
+    assert np.array_equal(ops.corr2_permute(dev(c2)).cpu().numpy(), want)
+    assert np.array_equal(ops.corr2_permute(dev(c2.astype(np.int32))).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('n,level', [(256, 0), (256, 2), (1024, 1)])
+def test_csr_build(ops, n, level):
+    _, _, _, gd = oracle_lattice(n)
+    g = gd[level]
+    H = g['pc1_hash_cnt']
+    off, bary = g['pc1_lattice_offset'], g['pc1_barycentric']
+    ct = ops.CloudTables(dev(bary), dev(off), H)
+    csr_ptr, csr_pt, csr_w, norm = [t.cpu().numpy() for t in ct.csr()]
+    N = off.shape[1]
+    flat = off.reshape(-1)
+    order = np.argsort(flat, kind='stable')                 # ascending vertex, then ascending entry
+    cnt = np.bincount(flat, minlength=H)
+    assert np.array_equal(csr_ptr, np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32))
+    assert np.array_equal(csr_pt, (order % N).astype(np.int32))
+    assert np.array_equal(csr_w, bary.reshape(-1)[order])
+    w = np.zeros(H, np.float64)
+    np.add.at(w, flat, bary.reshape(-1).astype(np.float64))
+    assert rel_err(norm, 1.0 / (w + 1e-5)) < 1e-6
+
+
+@pytest.mark.parametrize('C', [68, 64, 4, 12, 5, 33, 128, 1024])
+def test_splat_and_slice(ops, C):
+    from oracle import bcl_oracle as BO
+    _, _, _, gd = oracle_lattice(256)
+    g = gd[1]
+    H, off, bary = g['pc1_hash_cnt'], g['pc1_lattice_offset'], g['pc1_barycentric']
+    N = off.shape[1]
+    rng = np.random.RandomState(C)
+    feat = rng.randn(N, C).astype(np.float32)
+    ct = ops.CloudTables(dev(bary), dev(off), H)
+    for use_norm in (True, False):
+        S = ops.splat_raw(dev(feat), ct.csr(), H, use_norm).cpu().numpy()
+        want = BO.splat(feat.T.astype(np.float64), bary.astype(np.float64), off, H, use_norm)[:, 1:].T
+        assert rel_err(S, want) < 1e-5, (C, use_norm)
+    Y = rng.randn(H, C).astype(np.float32)
+    bias = rng.randn(C).astype(np.float32)
+    out = ops.slice_raw(dev(Y), ct.bary, ct.off, N, bias=dev(bias)).cpu().numpy()
+    want = (bary[:, :, None].astype(np.float64) * Y[off].astype(np.float64)).sum(0) + bias[None]
+    assert rel_err(out, want) < 1e-5
+    vs = rng.rand(H).astype(np.float32)
+    out = ops.slice_raw(dev(Y), ct.bary, ct.off, N, vscale=dev(vs)).cpu().numpy()
+    want = ((bary * vs[off])[:, :, None].astype(np.float64) * Y[off]).sum(0)
+    assert rel_err(out, want) < 1e-5
+    # strided views: read a column slice of a wider buffer, write into another
+    wide = torch.zeros(N, C + 8, device=DEV)
+    wide[:, 4:4 + C] = dev(feat)
+    dst = torch.full((H, C + 4), 7.0, device=DEV)
+    ops.splat_raw(wide[:, 4:4 + C], ct.csr(), H, True, out=dst[:, :C])
+    assert np.array_equal(dst[:, :C].cpu().numpy(), ops.splat_raw(dev(feat), ct.csr(), H, True).cpu().numpy())
+    assert float(dst[:, C:].min()) == 7.0
+
+
+def _gconv_ref(A, nbr, M, C, F, W, bias, res, res_mod, act, slope=0.1):
+    """float64 reference: W is (O, C, F)."""
+    Ap = np.concatenate([A[:, :C].astype(np.float64), np.zeros((1, C))], axis=0)    # row -1 -> zeros
+    if nbr is None:
+        X = Ap[:M][None]
+    else:
+        X = Ap[nbr]                                                                 # (F, M, C)
+    y = np.einsum('fmc,ocf->mo', X, W.astype(np.float64))
+    if bias is not None:
+        y = y + bias[None].astype(np.float64)
+    if res is not None:
+        y = y + res[np.arange(M) % res_mod].astype(np.float64)
+    if act:
+        y = np.where(y > 0, y, slope * y)
+    return y
+
+
+GCONV_CASES = [
+    # M, rowsA, C, F, O, table, bias, res, act
+    (300, 300, 68, 15, 64, True, True, False, True),       # Down blur conv, 64x64 tile
+    (1000, 1000, 64, 1, 64, False, True, False, False),    # 1x1 conv, dense
+    (700, 650, 36, 15, 128, True, True, False, True),      # 128x128 tile, table into a different row set
+    (513, 513, 580, 15, 200, True, False, False, False),   # wide C, K tail (8700 % 32 != 0), N tail
+    (2000, 2000, 3, 1, 32, False, True, False, True),      # conv1 first layer: C=3 scalar path
+    (900, 900, 32, 1, 3, False, True, False, False),       # conv4: N=3
+    (15 * 97, 120, 64, 15, 32, True, True, True, True),    # corr B-term: virtual vertices + broadcast residual
+    (97, 15 * 97, 32, 15, 64, True, True, False, True),    # displacement filter through a regular table
+    (70000, 70000, 68, 15, 64, True, True, False, True),   # enough tiles for the 128-row configs
+    (70000, 500, 64, 15, 32, True, False, False, False),   # 128x32 config
+    (33, 40, 8, 15, 16, True, True, False, True),          # tiny
+]
+
+
+@pytest.mark.parametrize('case', GCONV_CASES, ids=[str(i) for i in range(len(GCONV_CASES))])
+def test_gconv_forward(ops, case):
+    M, rows, C, F, O, table, has_bias, has_res, act = case
+    rng = np.random.RandomState(M + C + O)
+    A = rng.randn(rows, C).astype(np.float32)
+    W = (rng.randn(O, C, F) / np.sqrt(C * F)).astype(np.float32)
+    bias = rng.randn(O).astype(np.float32) if has_bias else None
+    nbr = None
+    if table:
+        nbr = rng.randint(-1, rows, size=(F, M)).astype(np.int32)
+        nbr[rng.rand(F, M) < 0.3] = -1
+    res_mod = 97 if has_res else 0
+    res = rng.randn(res_mod, O).astype(np.float32) if has_res else None
+    Wd = dev(W)
+    Wt = ops.weight_relayout(Wd, C, O, F, F, C * F, 1)
+    args = dict(bias=dev(bias) if has_bias else None, act=1 if act else 0,
+                res=dev(res) if has_res else None, res_mod=res_mod)
+    y = ops.gconv_raw(dev(A), dev(nbr) if table else None, M, C, F, Wt, O, **args).cpu().numpy()
+    yn = ops.gconv_raw(dev(A), dev(nbr) if table else None, M, C, F, Wt, O, naive=True, **args).cpu().numpy()
+    if M * C * F * O < 4e9:
+        want = _gconv_ref(A, nbr, M, C, F, W, bias, res, res_mod, act)
+        assert rel_err(yn, want) < 1e-5
+        assert rel_err(y, want) < 1e-5
+    # the MFMA is a k-ordered fmaf chain like the naive kernel: expect (near) bit equality
+    assert rel_err(y, yn) < 1e-6
+    # determinism: same launch twice, bit-identical
+    y2 = ops.gconv_raw(dev(A), dev(nbr) if table else None, M, C, F, Wt, O, **args).cpu().numpy()
+    assert np.array_equal(y, y2)
+
+
+def test_gconv_strided_io(ops):
+    rng = np.random.RandomState(3)
+    M, C, F, O = 500, 64, 15, 64
+    wide = torch.zeros(M, 4 + C + 12, device=DEV)
+    A = rng.randn(M, C).astype(np.float32)
+    wide[:, 4:4 + C] = dev(A)
+    nbr = rng.randint(-1, M, size=(F, M)).astype(np.int32)
+    W = (rng.randn(O, C, F) / 30).astype(np.float32)
+    Wt = ops.weight_relayout(dev(W), C, O, F, F, C * F, 1)
+    dst = torch.full((M, O + 8), -3.0, device=DEV)
+    ops.gconv_raw(wide[:, 4:4 + C], dev(nbr), M, C, F, Wt, O, out=dst[:, 4:4 + O])
+    want = ops.gconv_raw(dev(A), dev(nbr), M, C, F, Wt, O)
+    assert torch.equal(dst[:, 4:4 + O], want)
+    assert float(dst[:, :4].max()) == -3.0 and float(dst[:, 4 + O:].max()) == -3.0
+
+
+def test_weight_relayout_roundtrip(ops):
+    from hplflownet_amd import _lib
+    rng = np.random.RandomState(5)
+    O, Ctot, F, c0, C = 24, 40, 15, 8, 20
+    W = rng.randn(O, Ctot, F).astype(np.float32)
+    Wt = ops.weight_relayout(dev(W), C, O, F, F, Ctot * F, 1, base=c0 * F).cpu().numpy()
+    want = np.zeros_like(Wt)
+    want[:F * C, :O] = W[:, c0:c0 + C, :].transpose(2, 1, 0).reshape(F * C, O)
+    assert np.array_equal(Wt, want)
+    fmap = ((F - np.arange(F)) % F).astype(np.int32)
+    WtT = ops.weight_relayout(dev(W), O, C, F, Ctot * F, F, 1, base=c0 * F, fmap=dev(fmap)).cpu().numpy()
+    want = np.zeros_like(WtT)
+    for f in range(F):
+        want[fmap[f] * O:(fmap[f] + 1) * O, :C] = W[:, c0:c0 + C, f]
+    assert np.array_equal(WtT, want)
+    back = torch.zeros(O, Ctot, F, device=DEV)
+    Wt_d = ops.weight_relayout(dev(W), C, O, F, F, Ctot * F, 1, base=c0 * F)
+    _lib.check(_lib.load().hpl_weight_unlayout(Wt_d.data_ptr(), Wt_d.shape[1], C, O, F, back.data_ptr(), c0 * F, F,
+                                               Ctot * F, 1, 0, _lib.stream()), 'unlayout')
+    want = np.zeros_like(W)
+    want[:, c0:c0 + C] = W[:, c0:c0 + C]
+    assert np.array_equal(back.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('M,rows,C,F,O', [(3000, 3000, 68, 15, 64), (5000, 4000, 32, 1, 200), (900, 900, 3, 1, 32),
+                                          (40000, 40000, 36, 15, 32)])
+def test_wgrad_colsum_leaky(ops, M, rows, C, F, O):
+    rng = np.random.RandomState(M)
+    A = rng.randn(rows, C).astype(np.float32)
+    nbr = rng.randint(-1, rows, size=(F, M)).astype(np.int32) if F > 1 else None
+    dY = rng.randn(M, O).astype(np.float32)
+    dWt = ops.wgrad_raw(dev(A), dev(nbr) if nbr is not None else None, M, C, F, dev(dY), O).cpu().numpy()
+    Ap = np.concatenate([A.astype(np.float64), np.zeros((1, C))], 0)
+    X = Ap[nbr] if nbr is not None else Ap[:M][None]                 # (F, M, C)
+    want = np.einsum('fmc,mo->fco', X, dY.astype(np.float64)).reshape(F * C, O)
+    assert rel_err(dWt[:F * C, :O], want) < 2e-5                     # fp32 atomics over vertex slabs
+    assert not dWt[F * C:].any() and not dWt[:, O:].any()
+    assert rel_err(ops.colsum(dev(dY)).cpu().numpy(), dY.astype(np.float64).sum(0)) < 2e-5
+    Y = rng.randn(M, O).astype(np.float32)
+    got = ops.leaky_bwd(dev(dY), dev(Y)).cpu().numpy()
+    assert np.array_equal(got, dY * np.where(Y > 0, np.float32(1), np.float32(0.1)))
+
+
+def test_gconv_scatter_epilogue(ops):
+    rng = np.random.RandomState(11)
+    M, rows, O, F, C = 400, 300, 32, 15, 16
+    g = rng.randn(M, O).astype(np.float32)
+    W = rng.randn(O, F * C).astype(np.float32) / 6
+    nbr = rng.randint(-1, rows, size=(F, M)).astype(np.int32)
+    Wt = ops.weight_relayout(dev(W), O, F * C, 1, F * C, 1, 1)
+    out = torch.zeros(rows, C, device=DEV)
+    ops.gconv_raw(dev(g), None, M, O, 1, Wt, F * C, out=out, scat=dev(nbr), scat_c=C)
+    G = (g.astype(np.float64) @ W.astype(np.float64)).reshape(M, F, C)
+    want = np.zeros((rows, C))
+    for f in range(F):
+        ok = nbr[f] >= 0
+        np.add.at(want, nbr[f][ok], G[ok, f])
+    assert rel_err(out.cpu().numpy(), want) < 2e-5
+
+
+def test_full_size_properties(ops):
+    """BASELINE size (N=8192 level-0 tables from the oracle): size-independent properties."""
+    _, _, _, gd = oracle_lattice(8192, nscales=1)
+    g = gd[0]
+    H, off, bary = g['pc1_hash_cnt'], g['pc1_lattice_offset'], g['pc1_barycentric']
+    N = 8192
+    ct = ops.CloudTables(dev(bary), dev(off), H)
+    rng = np.random.RandomState(0)
+    x = dev(rng.randn(N, 68).astype(np.float32))
+    y = dev(rng.randn(N, 68).astype(np.float32))
+    Sx, Sy = ops.splat_raw(x, ct.csr(), H), ops.splat_raw(y, ct.csr(), H)
+    Sxy = ops.splat_raw(x + 2 * y, ct.csr(), H)
+    assert float((Sxy - (Sx + 2 * Sy)).abs().max()) < 1e-4                       # linearity
+    ones = torch.ones(N, 4, device=DEV)
+    s1 = ops.splat_raw(ones, ct.csr(), H, use_norm=False)                       # total mass = sum of weights
+    assert abs(float(s1[:, 0].sum()) - float(bary.astype(np.float64).sum())) < 1e-2
+    sl = ops.slice_raw(torch.ones(H, 4, device=DEV), ct.bary, ct.off, N)        # partition of unity
+    assert float((sl - 1).abs().max()) < 1e-5
+    # <splat x, z> == <x, slice_norm z>  (splat and its backward are adjoint)
+    z = dev(rng.randn(H, 68).astype(np.float32))
+    lhs = float((Sx.double() * z.double()).sum())
+    rhs = float((x.double() * ops.slice_raw(z, ct.bary, ct.off, N, vscale=ct.csr()[3]).double()).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+    assert torch.equal(Sx, ops.splat_raw(x, ct.csr(), H))                       # deterministic

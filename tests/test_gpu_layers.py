@@ -1,0 +1,246 @@
+"""GPU: the drop-in layers, the models and the device lattice against the reference-generated
+golden vectors (tests/golden) and the CPU oracle.  These tests read like the reference would
+test itself: same constructors, same forward calls, (1, C, N) tensors, int64 index tensors."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from common import GOLD, oracle_lattice, rel_err
+from hplflownet_amd.synthetic import (MODEL_GAIN, SCALES_FILTER_MAP, closed_form_fill, fill_module_, subsample,
+                                      synthetic_pair)
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = 2e-5        # forward, relative to max-abs (reference itself is fp32 with another summation order)
+GTOL = 5e-4       # gradients that reduce over all vertices (see tests/test_oracle_layers.py RTOL)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def model_args(n, evaluate=True):
+    return types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP[:n], evaluate=evaluate, use_leaky=True,
+                                 bcn_use_bias=True, bcn_use_norm=True, last_relu=False, DEVICE='cuda')
+
+
+def gd_batched_device(gd):
+    """generated_data as a DataLoader would deliver it: B=1 tensors, counts as 1-element tensors."""
+    out = []
+    for d in gd:
+        out.append({k: (T(v)[None] if isinstance(v, np.ndarray) else torch.tensor([v])) for k, v in d.items()})
+    return out
+
+
+BCL_CASES = [  # tag, n, level, cin, couts, do_splat, do_slice, last_relu, use_norm
+    ('cfg1', 1024, 0, 68, [64, 64], True, True, False, True),
+    ('down0', 256, 0, 68, [64, 64], True, False, False, True),
+    ('down2', 256, 2, 68, [64, 64], True, False, False, True),
+    ('up2', 256, 2, 36, [32, 32], False, True, False, True),
+    ('down1_single', 256, 1, 68, [64], True, False, False, True),
+    ('up1_single_relu', 256, 1, 20, [32], False, True, True, True),
+    ('cfg_nonorm', 256, 0, 12, [16, 16], True, True, False, False),
+]
+
+
+@pytest.mark.parametrize('case', BCL_CASES, ids=[c[0] for c in BCL_CASES])
+def test_bilateral_conv_golden_F4(case):
+    import hplflownet_amd as H
+    tag, n, lvl, cin, couts, do_splat, do_slice, last_relu, use_norm = case
+    z = np.load(os.path.join(GOLD, 'layers.npz'))
+    _, _, _, gd = oracle_lattice(n)
+    g = gd[lvl]
+    m = H.BilateralConvFlex(3, 1, cin, couts, 'cuda', True, True, use_norm, do_splat, do_slice, last_relu,
+                            chunk_size=-1)
+    fill_module_(m)
+    if do_slice:
+        with torch.no_grad():
+            m.bias.copy_(torch.from_numpy(closed_form_fill('slice_bias', (couts[-1],))))
+    m = m.to(DEV)
+    Hc = g['pc1_hash_cnt']
+    nfeat = g['pc1_barycentric'].shape[1] if do_splat else Hc
+    x = T(closed_form_fill(tag + '_x', (1, cin, nfeat)) * np.float32(np.sqrt(cin))).requires_grad_(True)
+    y = m(x,
+          T(g['pc1_barycentric'])[None] if do_splat else None,
+          T(g['pc1_lattice_offset'])[None] if do_splat else None,
+          T(g['pc1_blur_neighbors'])[None],
+          T(g['pc1_barycentric'])[None] if do_slice else None,
+          T(g['pc1_lattice_offset'])[None] if do_slice else None)
+    assert tuple(y.shape) == (1, couts[-1], g['pc1_barycentric'].shape[1] if do_slice else Hc)
+    assert rel_err(subsample(y.detach().cpu().numpy()[0]), z[tag + '_y']) < TOL
+    go = T(closed_form_fill(tag + '_g', tuple(y.shape)) * np.float32(np.sqrt(y.shape[1])))
+    (y * go).sum().backward()
+    assert rel_err(subsample(x.grad.cpu().numpy()[0]), z[tag + '_gx']) < 5 * TOL
+    for name, p in m.named_parameters():
+        assert rel_err(subsample(p.grad.cpu().numpy()), z[tag + '_g_' + name].reshape(-1)) < GTOL, name
+
+
+@pytest.mark.parametrize('tag,lvl,prev_dim,corr_outs,outs', [
+    ('corr_noprev', 2, 0, [32, 32], [64, 64]),
+    ('corr_prev', 3, 64, [32, 32], [64, 64]),
+    ('corr_shallow', 4, 64, [32], [32])])
+def test_bilateral_corr_golden_F4(tag, lvl, prev_dim, corr_outs, outs):
+    import hplflownet_amd as H
+    z = np.load(os.path.join(GOLD, 'layers.npz'))
+    _, _, _, gd = oracle_lattice(256)
+    g = gd[lvl]
+    H1, H2 = g['pc1_hash_cnt'], g['pc2_hash_cnt']
+    m = H.BilateralCorrelationFlex(3, 1, 1, 64, corr_outs, outs, 'cuda', True, True, True, prev_dim, False,
+                                   chunk_size=-1)
+    fill_module_(m)
+    m = m.to(DEV)
+    f1 = T(closed_form_fill(tag + '_f1', (1, 64, H1)) * 8).requires_grad_(True)
+    f2 = T(closed_form_fill(tag + '_f2', (1, 64, H2)) * 8).requires_grad_(True)
+    prev = None
+    if prev_dim:
+        prev = T(closed_form_fill(tag + '_prev', (1, prev_dim, g['pc1_barycentric'].shape[1])) * 8)
+        prev.requires_grad_(True)
+    y = m(f1, f2, prev,
+          T(g['pc1_barycentric'])[None] if prev_dim else None,
+          T(g['pc1_lattice_offset'])[None] if prev_dim else None,
+          T(g['pc1_corr_indices'])[None], T(g['pc2_corr_indices'])[None], H1, H2)
+    assert tuple(y.shape) == (1, outs[-1], H1)
+    assert rel_err(subsample(y.detach().cpu().numpy()[0]), z[tag + '_y']) < TOL
+    go = T(closed_form_fill(tag + '_g', tuple(y.shape)) * 8)
+    (y * go).sum().backward()
+    assert rel_err(subsample(f1.grad.cpu().numpy()[0]), z[tag + '_gf1']) < GTOL
+    assert rel_err(subsample(f2.grad.cpu().numpy()[0]), z[tag + '_gf2']) < GTOL
+    if prev is not None:
+        assert rel_err(subsample(prev.grad.cpu().numpy()[0]), z[tag + '_gprev']) < GTOL
+    for name, p in m.named_parameters():
+        assert rel_err(subsample(p.grad.cpu().numpy()), z[tag + '_g_' + name].reshape(-1)) < GTOL, name
+
+
+def test_sparse_sum_golden_F4():
+    import hplflownet_amd as H
+    z = np.load(os.path.join(GOLD, 'layers.npz'))
+    _, _, _, gd = oracle_lattice(256)
+    idx = T((gd[0]['pc1_lattice_offset'] + 1).reshape(1, -1))
+    vals = T(closed_form_fill('ss_vals', (idx.shape[1], 5))).requires_grad_(True)
+    ss = H.sparse_sum(idx, vals, torch.Size([gd[0]['pc1_hash_cnt'] + 1, 5]), True)
+    (ss * ss).sum().backward()
+    assert rel_err(ss.detach().cpu().numpy(), z['ss_y']) < TOL
+    assert rel_err(vals.grad.cpu().numpy(), z['ss_gvals']) < TOL
+
+
+@pytest.mark.parametrize('tag,cls,n,nsc', [('shallow_n256', 'HPLFlowNetShallow', 256, 5),
+                                           ('shallow_n1024', 'HPLFlowNetShallow', 1024, 5),
+                                           ('full_n256', 'HPLFlowNet', 256, 7)])
+def test_whole_model_golden_F5(tag, cls, n, nsc):
+    import hplflownet_amd as H
+    z = np.load(os.path.join(GOLD, 'models.npz'))
+    pc1, pc2, sf, gd = oracle_lattice(n)
+    m = getattr(H, cls)(model_args(nsc))
+    fill_module_(m, MODEL_GAIN)
+    m = m.to(DEV)
+    p1, p2 = T(pc1.T)[None], T(pc2.T)[None]
+    y = m(p1, p2, gd_batched_device(gd[:nsc]))
+    assert tuple(y.shape) == (1, 3, n)
+    loss = torch.norm(y - T(sf.T)[None], p=2, dim=1).mean()
+    ref = z[tag + '_flow']
+    # north-star bar: EPE3D delta < 1e-4 on fixed inputs
+    assert abs(float(loss.item()) - float(z[tag + '_loss'])) < 1e-4
+    assert np.abs(y.detach().cpu().numpy()[0] - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    loss.backward()
+    names = bytes(z[tag + '_gradnames']).decode().split('\n')
+    want = dict(zip(names, z[tag + '_gradnorm']))
+    got = {k: float(p.grad.norm()) for k, p in m.named_parameters()}
+    assert set(got) == set(want)
+    scale = max(want.values())
+    for k in want:
+        assert abs(got[k] - want[k]) < 2e-3 * max(want[k], 1e-3 * scale), (k, got[k], want[k])
+    # inference path (no autograd, in-place channel-block writes) gives the same flow
+    with torch.no_grad():
+        y2 = m(p1, p2, gd_batched_device(gd[:nsc]))
+    assert float((y2 - y.detach()).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('n,seed', [(256, 0), (1024, 0), (1024, 3), (8192, 0)])
+def test_device_lattice_bit_exact(n, seed):
+    """GPU lattice == C oracle (== reference, tests/test_oracle_lattice.py) on every table."""
+    import hplflownet_amd as H
+    pc1, pc2, sf, gd = oracle_lattice(n, seed)
+    gen = H.GenerateDataUnsymmetric(types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP), device=DEV)
+    t1, t2, tsf, lat = gen([pc1, pc2, sf])
+    assert tuple(t1.shape) == (3, n) and np.array_equal(tsf.cpu().numpy(), sf.T)
+    ref = H.to_reference_format(lat)
+    for l, (a, b) in enumerate(zip(ref, gd)):
+        for k in b:
+            va = a[k].cpu().numpy() if torch.is_tensor(a[k]) else a[k]
+            assert np.array_equal(np.asarray(va), np.asarray(b[k])), (l, k)
+
+
+def test_device_lattice_edge_cases():
+    import hplflownet_amd as H
+    from oracle import lattice_oracle as LO
+    gen = H.GenerateDataUnsymmetric(types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP), device=DEV)
+    one = np.array([[0.1, -0.2, 5.0]], np.float32)
+    p1, p2, _ = synthetic_pair(64, 5)
+    for a, b in ((one, one.copy()), (np.repeat(one, 7, 0), one.copy()), (p1, p2[:40])):
+        _, _, _, lat = gen([a, b, np.zeros_like(a)])
+        gd = LO.generate_data(a, b, SCALES_FILTER_MAP)
+        for l, (x, y) in enumerate(zip(H.to_reference_format(lat), gd)):
+            for k in y:
+                vx = x[k].cpu().numpy() if torch.is_tensor(x[k]) else x[k]
+                assert np.array_equal(np.asarray(vx), np.asarray(y[k])), (l, k)
+    assert gen([None, None, None]) == (None, None, None, None)       # transforms.py:360-361
+
+
+def test_config2_shallow_n4096_vs_oracle():
+    """BASELINE config 2: HPLFlowNetShallow forward, N=4096, device lattice + HIP layers vs oracle."""
+    import hplflownet_amd as H
+    from oracle import bcl_oracle as BO
+    n = 4096
+    pc1, pc2, sf, gd = oracle_lattice(n, 0, nscales=5)
+    args = model_args(5)
+    gen = H.GenerateDataUnsymmetric(args, device=DEV)
+    t1, t2, tsf, lat = gen([pc1, pc2, sf])
+    m = H.HPLFlowNetShallow(args)
+    fill_module_(m, MODEL_GAIN)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    with torch.no_grad():
+        y = m(t1[None], t2[None], lat)
+    ref = BO.hplflownet_forward(sd, pc1.T, pc2.T, gd, shallow=True)
+    got = y.cpu().numpy()[0]
+    assert abs(BO.epe3d(got, sf.T) - BO.epe3d(ref, sf.T)) < 1e-4
+    assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_config3_full_n8192_mfma_vs_naive_and_determinism():
+    """BASELINE config 3 size: full HPLFlowNet forward at N=8192.  The numpy oracle needs minutes
+    at this size, so the check is MFMA path vs the one-thread-per-output HIP kernel (same C ABI,
+    no matrix cores), bit-determinism across two runs, and finiteness."""
+    import hplflownet_amd as H
+    from hplflownet_amd import ops
+    n = 8192
+    pc1, pc2, sf = synthetic_pair(n, 0)
+    args = model_args(7)
+    gen = H.GenerateDataUnsymmetric(args, device=DEV)
+    t1, t2, tsf, lat = gen([pc1, pc2, sf])
+    assert [lv.H[0] for lv in lat.levels] == [25841, 34631, 9433, 1787, 426, 132, 53]
+    m = H.HPLFlowNet(args)
+    fill_module_(m, MODEL_GAIN)
+    m = m.to(DEV)
+    with torch.no_grad():
+        y1 = m(t1[None], t2[None], lat)
+        y2 = m(t1[None], t2[None], lat)
+        assert torch.equal(y1, y2)
+        orig = ops.gconv_raw
+
+        def naive(*a, **k):
+            k['naive'] = True
+            return orig(*a, **k)
+        ops.gconv_raw = naive
+        try:
+            y3 = m(t1[None], t2[None], lat)
+        finally:
+            ops.gconv_raw = orig
+    assert torch.isfinite(y1).all()
+    epe = lambda y: float(torch.norm(y - tsf[None], p=2, dim=1).mean())
+    assert abs(epe(y1) - epe(y3)) < 1e-4
+    assert float((y1 - y3).abs().max()) < 2e-4 * max(1.0, float(y3.abs().max()))
