@@ -82,7 +82,6 @@ class GenerateDataUnsymmetric(object):
             lv.corr2 = NbrTable(corr2) if corr2 is not None else None
             if lv.corr2 is not None:
                 lv.corr2._sym = False
-            lv.corr_shape = (_filter_size(cf_r), _filter_size(cc_r)) if cf_r != -1 else None
             levels.append(lv)
             if idx != nlev - 1:
                 div = float(np.float32(self.expected_std * scale))         # transforms.py:462-463

@@ -51,8 +51,29 @@ def closed_form_fill(name, shape):
     return (amp * np.sin(0.37 * i + len(name))).astype(np.float32).reshape(shape)
 
 
-#: weight gain used by the whole-model fixtures: with gain 1 the signal dies out after
-#: ~25 layers (output std across points ~1e-6); 5 keeps it O(0.1) in both models.
+def hash_fill(name, shape):
+    """Exactly reproducible pseudo-random parameter values (integer hash, no libm):
+    u = splitmix64(i + crc32(name) * 2^32) mapped to U(-a, a), a = sqrt(6 / fan_in) for weights
+    (He-uniform: keeps activations O(1) through the ~25 layers of the models) and 0.05 for
+    vectors.  Used by the whole-model fixtures: the sin fill above gives rank-2 weight
+    matrices, whose massive cancellations make whole-model gradients hypersensitive to
+    single LeakyReLU sign flips (measured)."""
+    import zlib
+    n = int(np.prod(shape))
+    x = np.arange(n, dtype=np.uint64) + (np.uint64(zlib.crc32(name.encode())) << np.uint64(32))
+    with np.errstate(over='ignore'):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(11)).astype(np.float64) / float(1 << 53)          # [0, 1)
+    a = math.sqrt(6.0 / float(np.prod(shape[1:]))) if len(shape) >= 2 else 0.05
+    return ((2.0 * u - 1.0) * a).astype(np.float32).reshape(shape)
+
+
+#: weight gain of the (legacy) sin fill for whole models; the model fixtures use hash_fill
 MODEL_GAIN = 5.0
 
 #: gradient tensors larger than this are stored strided in the fixtures
@@ -65,13 +86,14 @@ def subsample(a):
     return a[::GRAD_SUBSAMPLE_STRIDE] if a.size > GRAD_SUBSAMPLE_MIN else a
 
 
-def fill_module_(module, gain=1.0):
-    """In-place closed-form fill of every float parameter of a torch module
-    (weights, i.e. ndim >= 2, additionally scaled by `gain`)."""
+def fill_module_(module, gain=1.0, kind='sin'):
+    """In-place deterministic fill of every float parameter of a torch module
+    (weights, i.e. ndim >= 2, additionally scaled by `gain`); kind 'sin' or 'hash'."""
     import torch
+    fn = closed_form_fill if kind == 'sin' else hash_fill
     with torch.no_grad():
         for name, p in module.named_parameters():
-            v = closed_form_fill(name, tuple(p.shape))
+            v = fn(name, tuple(p.shape))
             if p.dim() >= 2:
                 v = v * np.float32(gain)
             p.copy_(torch.from_numpy(v))

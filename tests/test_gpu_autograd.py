@@ -1,0 +1,134 @@
+"""GPU: autograd of the HIP ops against a float64 torch restatement of the same op
+(torch.index_select / einsum / index_add on the device), random shapes and tables."""
+import numpy as np
+import pytest
+import torch
+
+from common import oracle_lattice, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def ref_gconv(A, W, bias, nbr, M, c0, C, F, act, res, res_mod, slope=0.1):
+    """float64 torch reference.  W (O, Ctot, F)."""
+    O = W.shape[0]
+    Ap = torch.cat([A[:, :C].double(), torch.zeros(1, C, dtype=torch.float64, device=A.device)], 0)
+    if nbr is None:
+        X = Ap[:M][None]
+    else:
+        idx = nbr.long()
+        idx = torch.where(idx < 0, torch.full_like(idx, A.shape[0]), idx)
+        X = Ap[idx]                                                    # (F, M, C)
+    Wd = W.double().view(O, -1, F)[:, c0:c0 + C, :]
+    y = torch.einsum('fmc,ocf->mo', X, Wd)
+    if bias is not None:
+        y = y + bias.double()[None]
+    if res is not None:
+        y = y + res.double()[torch.arange(M, device=A.device) % res_mod]
+    if act:
+        y = torch.where(y > 0, y, slope * y)
+    return y
+
+
+CASES = [
+    # M, rows, Ctot, c0, C, F, O, mode, bias, res, act
+    (256, 256, 1024, 0, 1024, 1, 512, 'dense', True, False, True),
+    (256, 256, 512, 0, 512, 1, 3, 'dense', True, False, False),
+    (300, 300, 3, 0, 3, 1, 32, 'dense', True, False, True),
+    (500, 500, 68, 0, 68, 15, 64, 'scatter', True, False, True),
+    (500, 420, 192, 64, 64, 15, 32, 'scatter', False, False, False),
+    (15 * 60, 77, 192, 128, 64, 15, 32, 'scatter', True, True, True),
+    (60, 15 * 60, 32, 0, 32, 15, 64, 'scatter', True, False, True),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[str(i) for i in range(len(CASES))])
+def test_gconv_autograd(case):
+    from hplflownet_amd import ops
+    M, rows, Ctot, c0, C, F, O, mode, has_bias, has_res, act = case
+    g = torch.Generator(device='cpu').manual_seed(M + O)
+    A = torch.randn(rows, C, generator=g).to(DEV).requires_grad_(True)
+    W = (torch.randn(O, Ctot, F, generator=g) / np.sqrt(C * F) * 3).to(DEV).requires_grad_(True)
+    bias = torch.randn(O, generator=g).to(DEV).requires_grad_(True) if has_bias else None
+    nbr = None
+    if F > 1:
+        nbr = torch.randint(-1, rows, (F, M), generator=g).to(torch.int32).to(DEV)
+    res_mod = 60 if has_res else 0
+    res = torch.randn(res_mod, O, generator=g).to(DEV).requires_grad_(True) if has_res else None
+    go = torch.randn(M, O, generator=g).to(DEV)
+    y = ops.gconv(A, W, bias, nbr, M, F, act=1 if act else 0, c0=c0, C=C, res=res, res_mod=res_mod, bwd_mode=mode)
+    (y * go).sum().backward()
+    got = [A.grad.clone(), W.grad.clone(), bias.grad.clone() if has_bias else None,
+           res.grad.clone() if has_res else None]
+    for t in (A, W, bias, res):
+        if t is not None:
+            t.grad = None
+    yr = ref_gconv(A, W, bias, nbr, M, c0, C, F, act, res, res_mod)
+    (yr * go.double()).sum().backward()
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 1e-5
+    want = [A.grad, W.grad, bias.grad if has_bias else None, res.grad if has_res else None]
+    for nm, a, b in zip(('dA', 'dW', 'db', 'dres'), got, want):
+        if b is not None:
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5, nm
+
+
+def test_gconv_autograd_mirror():
+    """symmetric table (a real blur table): mirror-gather backward == scatter backward == torch."""
+    from hplflownet_amd import ops
+    from hplflownet_amd.bcl import NbrTable
+    _, _, _, gd = oracle_lattice(256)
+    nbr = torch.from_numpy(gd[2]['pc1_blur_neighbors']).to(torch.int32).to(DEV)
+    H = nbr.shape[1]
+    tbl = NbrTable(nbr)
+    assert tbl.symmetric and tbl.bwd_mode(H) == 'mirror'
+    g = torch.Generator(device='cpu').manual_seed(1)
+    C, O, F = 36, 48, 15
+    W = (torch.randn(O, C, F, generator=g) / 10).to(DEV).requires_grad_(True)
+    go = torch.randn(H, O, generator=g).to(DEV)
+    grads = {}
+    for mode in ('mirror', 'scatter'):
+        A = torch.randn(H, C, generator=torch.Generator().manual_seed(2)).to(DEV).requires_grad_(True)
+        y = ops.gconv(A, W, None, nbr, H, F, act=1, bwd_mode=mode)
+        (y * go).sum().backward()
+        grads[mode] = A.grad.clone()
+        W.grad = None
+    A = torch.randn(H, C, generator=torch.Generator().manual_seed(2)).to(DEV).requires_grad_(True)
+    yr = ref_gconv(A, W, None, nbr, H, 0, C, F, True, None, 0)
+    (yr * go.double()).sum().backward()
+    assert rel_err(grads['mirror'].cpu().numpy(), A.grad.cpu().numpy()) < 2e-5
+    assert rel_err(grads['scatter'].cpu().numpy(), A.grad.cpu().numpy()) < 2e-5
+    bad = nbr.clone()
+    bad[3, 5] = (bad[3, 5] + 1) % H
+    assert not NbrTable(bad).symmetric
+
+
+def test_splat_slice_autograd():
+    from hplflownet_amd import ops
+    _, _, _, gd = oracle_lattice(256)
+    g = gd[1]
+    H, off, bary = g['pc1_hash_cnt'], g['pc1_lattice_offset'], g['pc1_barycentric']
+    N = off.shape[1]
+    ct = ops.CloudTables(torch.from_numpy(bary).to(DEV), torch.from_numpy(off).to(DEV), H)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(N, 20, generator=gen).to(DEV).requires_grad_(True)
+    bias = torch.randn(20, generator=gen).to(DEV).requires_grad_(True)
+    go = torch.randn(N, 20, generator=gen).to(DEV)
+    s = ops.SplatFn.apply(x, ct, True)
+    out = ops.SliceFn.apply(s, ct, bias)
+    (out * go).sum().backward()
+    gx, gb = x.grad.clone(), bias.grad.clone()
+    x.grad = bias.grad = None
+    offl = torch.from_numpy(off).to(DEV).long()
+    b = torch.from_numpy(bary).to(DEV).double()
+    S = torch.zeros(H, 20, dtype=torch.float64, device=DEV)
+    w = torch.zeros(H, dtype=torch.float64, device=DEV)
+    for r in range(4):
+        S = S.index_add(0, offl[r], b[r][:, None] * x.double())
+        w = w.index_add(0, offl[r], b[r])
+    S = S / (w + 1e-5)[:, None]
+    o = sum(b[r][:, None] * S[offl[r]] for r in range(4)) + bias.double()[None]
+    (o * go.double()).sum().backward()
+    assert rel_err(out.detach().cpu().numpy(), o.detach().cpu().numpy()) < 1e-5
+    assert rel_err(gx.cpu().numpy(), x.grad.cpu().numpy()) < 2e-5
+    assert rel_err(gb.cpu().numpy(), bias.grad.cpu().numpy()) < 2e-5

@@ -197,7 +197,7 @@ def test_weight_relayout_roundtrip(ops):
     assert np.array_equal(back.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize('M,rows,C,F,O', [(3000, 3000, 68, 15, 64), (5000, 4000, 32, 1, 200), (900, 900, 3, 1, 32),
+@pytest.mark.parametrize('M,rows,C,F,O', [(3000, 3000, 68, 15, 64), (5000, 5000, 32, 1, 200), (900, 900, 3, 1, 32),
                                           (40000, 40000, 36, 15, 32)])
 def test_wgrad_colsum_leaky(ops, M, rows, C, F, O):
     rng = np.random.RandomState(M)

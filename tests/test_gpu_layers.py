@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from common import GOLD, oracle_lattice, rel_err
-from hplflownet_amd.synthetic import (MODEL_GAIN, SCALES_FILTER_MAP, closed_form_fill, fill_module_, subsample,
+from hplflownet_amd.synthetic import (SCALES_FILTER_MAP, closed_form_fill, fill_module_, subsample,
                                       synthetic_pair)
 
 pytestmark = pytest.mark.gpu
@@ -135,7 +135,7 @@ def test_whole_model_golden_F5(tag, cls, n, nsc):
     z = np.load(os.path.join(GOLD, 'models.npz'))
     pc1, pc2, sf, gd = oracle_lattice(n)
     m = getattr(H, cls)(model_args(nsc))
-    fill_module_(m, MODEL_GAIN)
+    fill_module_(m, 1.0, 'hash')
     m = m.to(DEV)
     p1, p2 = T(pc1.T)[None], T(pc2.T)[None]
     y = m(p1, p2, gd_batched_device(gd[:nsc]))
@@ -200,7 +200,7 @@ def test_config2_shallow_n4096_vs_oracle():
     gen = H.GenerateDataUnsymmetric(args, device=DEV)
     t1, t2, tsf, lat = gen([pc1, pc2, sf])
     m = H.HPLFlowNetShallow(args)
-    fill_module_(m, MODEL_GAIN)
+    fill_module_(m, 1.0, 'hash')
     sd = {k: v.numpy() for k, v in m.state_dict().items()}
     m = m.to(DEV)
     with torch.no_grad():
@@ -224,7 +224,7 @@ def test_config3_full_n8192_mfma_vs_naive_and_determinism():
     t1, t2, tsf, lat = gen([pc1, pc2, sf])
     assert [lv.H[0] for lv in lat.levels] == [25841, 34631, 9433, 1787, 426, 132, 53]
     m = H.HPLFlowNet(args)
-    fill_module_(m, MODEL_GAIN)
+    fill_module_(m, 1.0, 'hash')
     m = m.to(DEV)
     with torch.no_grad():
         y1 = m(t1[None], t2[None], lat)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from common import GOLD, oracle_lattice, rel_err
-from hplflownet_amd.synthetic import MODEL_GAIN, closed_form_fill, subsample
+from hplflownet_amd.synthetic import closed_form_fill, hash_fill, subsample
 from oracle import bcl_oracle as BO
 
 TOL = 1e-5
@@ -124,14 +124,9 @@ def test_sparse_sum_F4():
     assert rel_err(BO.sparse_sum_backward(idx, 2 * y), z['ss_gvals']) < TOL
 
 
-def model_state(manifest, gain=MODEL_GAIN):
-    sd = {}
-    for k, (dt, *shape) in manifest.items():
-        if dt != 'float32':
-            continue
-        v = closed_form_fill(k, tuple(shape))
-        sd[k] = v * np.float32(gain) if len(shape) >= 2 else v
-    return sd
+def model_state(manifest):
+    """hash fill, exactly as tools/make_fixtures.py fills the reference models (F5)."""
+    return {k: hash_fill(k, tuple(shape)) for k, (dt, *shape) in manifest.items() if dt == 'float32'}
 
 
 @pytest.mark.parametrize('tag,cls,n,shallow', [('shallow_n256', 'HPLFlowNetShallow', 256, True),

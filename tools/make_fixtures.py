@@ -219,7 +219,7 @@ def main():
                                  ('full_n256', R.HPLFlowNet, 7, 256)):
             pc1, pc2, sf, gd = lat[n]
             m = cls(model_args(nsc))
-            fill_module_(m, MODEL_GAIN)
+            fill_module_(m, 1.0, 'hash')
             manifest[cls.__name__] = {k: [str(v.dtype).replace('torch.', '')] + list(v.shape)
                                       for k, v in m.state_dict().items()}
             p1 = torch.from_numpy(pc1.T.copy())[None]
