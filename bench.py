@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""Benchmark of the bilateral-convolution hot path on MI355X (contract: see the task brief).
+
+A step = one pass of the hot path over one synthetic point-cloud pair that is already resident
+in HBM: permutohedral lattice construction on the device (7 levels) + the full HPLFlowNet
+forward (21 BCL + 5 CorrBCL calls + Conv1d stacks), N=8192, bs=1 -- BASELINE.json's metric
+configuration ("point-pairs/sec + EPE3D, N=8192").  Pairs shard over GPUs as independent samples
+(one process per GPU, no data-path collective; inference needs none -- SURVEY.md §8 e), so
+`--gpus N` is weak scaling: every rank runs K steps on its own pairs, value = N*K / max-rank time.
+
+Printed JSON (rank 0, one line): the contract fields plus
+  roofline      dominant kernel (fp32-MFMA gather-GEMM, 128x128 tiles): algorithmic flops of its
+                launches / their HIP-event time, measured inside the timed region;
+  kernels       per-kernel-class breakdown (gather-GEMM classes by MFMA roofline, splat / slice by
+                HBM roofline with the algorithmic bytes of SURVEY.md §8 d2);
+  cpu_baseline  the CPU oracle ("port": C lattice + numpy/BLAS layers) timed on this host on ONE
+                pair of the same workload (rank 0, N=1 only); it doubles as the EPE3D parity check.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s measured copy)
+
+
+def gconv_class(M, N):
+    """Mirror of the tile selection in csrc/gconv.hip (hpl_gconv_forward)."""
+    big = (M + 127) // 128 >= 512
+    if N > 64:
+        return '128x128'
+    if N > 32:
+        return '128x64' if big else '64x64'
+    return '128x32' if big else '64x32'
+
+
+class KernelTimers(object):
+    """HIP events around every launch of the hot kernels (torch's current stream is the stream
+    the C ABI launches on), aggregated per kernel class."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.records = []
+        self.enabled = False
+        self._orig = (ops.gconv_raw, ops.splat_raw, ops.slice_raw)
+        timers = self
+
+        def wrap(fn, describe):
+            def inner(*a, **k):
+                if not timers.enabled:
+                    return fn(*a, **k)
+                s = torch.cuda.Event(enable_timing=True)
+                e = torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = fn(*a, **k)
+                e.record()
+                timers.records.append((describe(*a, **k), s, e))
+                return out
+            return inner
+
+        def d_gconv(A, nbr, M, C, F, Wt, N, **k):
+            return ('gconv_' + gconv_class(M, N), 2.0 * M * F * C * N, 0.0)
+
+        def d_splat(feat, csr, H, use_norm=True, out=None):
+            N, C = feat.shape
+            return ('splat', 0.0, 4.0 * C * N + 32.0 * N + 4.0 * (C + 1) * (H + 1))
+
+        def d_slice(Y, bary, off, N, vscale=None, bias=None, out=None):
+            H, C = Y.shape
+            return ('slice', 0.0, 4.0 * C * H + 32.0 * N + 4.0 * C * N)
+
+        ops.gconv_raw = wrap(ops.gconv_raw, d_gconv)
+        ops.splat_raw = wrap(ops.splat_raw, d_splat)
+        ops.slice_raw = wrap(ops.slice_raw, d_slice)
+
+    def summary(self, steps):
+        agg = {}
+        for (name, flops, nbytes), s, e in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e)         # ms
+            a[2] += flops
+            a[3] += nbytes
+        out = {}
+        for name, (cnt, ms, flops, nbytes) in sorted(agg.items()):
+            d = {'launches_per_step': cnt / float(steps), 'avg_launch_us': 1e3 * ms / cnt,
+                 'ms_per_step': ms / steps}
+            if flops:
+                d.update(bound='mfma', achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TFLOPS,
+                         unit='TFLOP/s', gflop_per_step=flops / steps / 1e9)
+            else:
+                d.update(bound='hbm', achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+                         mbytes_per_step=nbytes / steps / 1e6)
+            d['frac'] = d['achieved'] / d['peak']
+            out[name] = d
+        return out
+
+
+def cpu_baseline(pc1, pc2, sf, sfm, state_dict):
+    """The CPU oracle on one pair of the same workload; returns (dict, flow)."""
+    from oracle import bcl_oracle, lattice_oracle
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    t0 = time.time()
+    gd = lattice_oracle.generate_data(pc1, pc2, sfm)
+    t1 = time.time()
+    flow = bcl_oracle.hplflownet_forward(state_dict, pc1.T, pc2.T, gd)
+    t2 = time.time()
+    d = {'value': 1.0 / (t2 - t0), 'unit': 'point-pairs/s', 'cores': int(threads), 'kind': 'port',
+         'sample': '1 pair, N=%d, 7-level lattice build (C oracle, 1 thread) + full HPLFlowNet forward '
+                   '(numpy oracle, BLAS threads = cores)' % pc1.shape[0],
+         'lattice_s': t1 - t0, 'forward_s': t2 - t1, 'host_cpus': os.cpu_count()}
+    return d, flow, bcl_oracle.epe3d(flow, sf.T)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--points', type=int, default=8192)
+    ap.add_argument('--pool', type=int, default=4, help='distinct resident pairs cycled through the steps')
+    ap.add_argument('--no-lattice', action='store_true', help='exclude the device lattice build from the step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # RCCL; used for barrier/max only
+    if a.gpus != world and rank == 0 and world > 1:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
+
+    import hplflownet_amd as H
+    from hplflownet_amd import ops
+    from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_, synthetic_pair
+
+    margs = types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP, evaluate=True, use_leaky=True,
+                                  bcn_use_bias=True, bcn_use_norm=True, last_relu=False, DEVICE='cuda')
+    model = H.HPLFlowNet(margs)
+    fill_module_(model, 1.0, 'hash')                      # random-init weights of the named architecture
+    state = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    model = model.to(dev).eval()
+    gen = H.GenerateDataUnsymmetric(margs, device=dev)
+
+    pairs_np = [synthetic_pair(a.points, 1000 * rank + i) for i in range(a.pool)]
+    pairs = [(torch.from_numpy(p1.T.copy()).to(dev), torch.from_numpy(p2.T.copy()).to(dev)) for p1, p2, _ in pairs_np]
+    fixed_lat = [gen.build(p1, p2) for p1, p2 in pairs] if a.no_lattice else None
+    timers = KernelTimers(ops)
+
+    def step(i):
+        p1, p2 = pairs[i % a.pool]
+        lat = fixed_lat[i % a.pool] if a.no_lattice else gen.build(p1, p2)
+        return model(p1[None], p2[None], lat)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(a.warmup):
+            step(i)
+        sync_all()
+        timers.enabled = True
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            y = step(i)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        timers.enabled = False
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+    if rank == 0:
+        kernels = timers.summary(a.steps)
+        dom = kernels.get('gconv_128x128', {})
+        roofline = {'bound': 'mfma', 'achieved': dom.get('achieved'), 'peak': MFMA_F32_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': dom.get('frac'), 'traffic': None,
+                    'kernel': 'k_gconv<128,128,2,2,true> (fp32-MFMA gather-GEMM: Up-BCL blur convs, conv2, conv3)',
+                    'launches_per_step': dom.get('launches_per_step'), 'avg_launch_us': dom.get('avg_launch_us'),
+                    'gflop_per_step': dom.get('gflop_per_step')}
+        prof = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(prof):
+            try:
+                roofline['traffic'] = json.load(open(prof)).get('k_gconv_128x128_bytes_per_launch')
+            except Exception:
+                pass
+        line = {'metric': 'point-pairs/sec + EPE3D, N=8192 FlyingThings3D, 1/2/4/8 MI355X',
+                'value': world * a.steps / elapsed, 'unit': 'point-pairs/s', 'n_gpus': world, 'steps': a.steps,
+                'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': 'full HPLFlowNet inference (7 levels, 19.3M params, random init), '
+                                       'FT3D-like synthetic pair, N=%d, bs=1 per GPU' % a.points,
+                           'num_points': a.points, 'step_includes_lattice_build': not a.no_lattice,
+                           'sharding': 'independent pairs per GPU, no data-path collective',
+                           'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
+                'roofline': roofline, 'kernels': kernels}
+        if world == 1 and not a.no_cpu_baseline:
+            p1, p2, sf = pairs_np[0]
+            base, flow_cpu, epe_cpu = cpu_baseline(p1, p2, sf, SCALES_FILTER_MAP, state)
+            with torch.no_grad():
+                y0 = step(0)
+            flow_gpu = y0[0].cpu().numpy()
+            epe_gpu = float(np.sqrt(((flow_gpu - sf.T) ** 2).sum(0)).mean())
+            line['cpu_baseline'] = base
+            line['epe3d'] = {'gpu': epe_gpu, 'cpu_oracle': epe_cpu, 'abs_delta': abs(epe_gpu - epe_cpu),
+                             'max_abs_flow_diff': float(np.abs(flow_gpu - flow_cpu).max()),
+                             'note': 'random-init weights: parity number, not accuracy'}
+            line['speedup_vs_cpu_baseline'] = line['value'] / base['value']
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -5,6 +5,7 @@ torch tensors, and the HIP library does the work on the current stream.  Activat
 are channel-last 2-D float32 tensors `[rows, channels]` with unit channel stride (the
 row stride may exceed the channel count: column slices of wider buffers are fine).
 """
+import collections
 import ctypes
 
 import torch
@@ -315,5 +316,25 @@ def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_
             out.copy_(y)
             return out
         return y
-    Wt = weight_relayout(weight.detach(), C, O, F, F, Ctot * F, 1, base=c0 * F)
+    Wt = _cached_relayout(weight, C, O, F, Ctot, c0)
     return gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope)
+
+
+_WT_CACHE = collections.OrderedDict()
+_WT_CACHE_MAX = 512
+
+
+def _cached_relayout(weight, C, O, F, Ctot, c0):
+    """Inference path: the k-major weight image only changes when the parameter does
+    (tensor identity + version counter); the entry keeps the parameter alive, so its
+    address cannot be recycled while cached."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), c0, C)
+    hit = _WT_CACHE.get(key)
+    if hit is not None:
+        _WT_CACHE.move_to_end(key)
+        return hit[0]
+    Wt = weight_relayout(weight.detach(), C, O, F, F, Ctot * F, 1, base=c0 * F)
+    _WT_CACHE[key] = (Wt, weight)
+    if len(_WT_CACHE) > _WT_CACHE_MAX:
+        _WT_CACHE.popitem(last=False)
+    return Wt

@@ -165,10 +165,12 @@ def bilateral_corr_forward(feat1, feat2, prev_corr, bary1, off1, corr_idx1, corr
         X = np.concatenate([X1, X2], axis=0)                               # (Ctot, F, K, h) :199
         cur = X
         for i, (W, b) in enumerate(corr_convs):                            # :202
+            # Conv3d as one BLAS matmul per displacement tap f: (O, C*K) @ (C*K, h)
             if i == 0:
-                y = np.einsum('ock,cfkh->ofh', W, cur, optimize=True)
+                Xr = np.ascontiguousarray(cur.transpose(1, 0, 2, 3)).reshape(F, -1, cur.shape[-1])
             else:
-                y = np.einsum('oc,cfh->ofh', W.reshape(W.shape[0], -1), cur, optimize=True)
+                Xr = np.ascontiguousarray(cur.transpose(1, 0, 2))
+            y = np.matmul(W.reshape(W.shape[0], -1).astype(np.float32), Xr).transpose(1, 0, 2)   # (O, F, h)
             cur = leaky(y + b[:, None, None], use_leaky)
         y, _ = conv_stack(cur, blur_convs, acts_b, use_leaky)              # :205
         outs.append(y)
