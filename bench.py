@@ -36,12 +36,15 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s 
 
 def gconv_class(M, N):
     """Mirror of the tile selection in csrc/gconv.hip (hpl_gconv_forward)."""
-    big = (M + 127) // 128 >= 512
+    t128, t64 = (M + 127) // 128, (M + 63) // 64
     if N > 64:
-        return '128x128'
+        tn = (N + 127) // 128
+        if t128 * tn >= 448:
+            return '128x128'
+        return '64x128' if (t64 * tn >= 448 or N > 128) else '64x64'
     if N > 32:
-        return '128x64' if big else '64x64'
-    return '128x32' if big else '64x32'
+        return '128x64' if t128 >= 512 else '64x64'
+    return '128x32' if t128 >= 512 else '64x32'
 
 
 class KernelTimers(object):

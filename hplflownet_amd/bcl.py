@@ -193,7 +193,7 @@ class SparseSum(torch.autograd.Function):
         csr_pt = torch.empty(n, dtype=torch.int32, device=dev)
         csr_w = torch.empty(n, dtype=torch.float32, device=dev)
         norm = torch.empty(H, dtype=torch.float32, device=dev)
-        scratch = torch.empty(H + 1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(H + 1 + n + 1026, dtype=torch.int32, device=dev)
         ones = torch.ones(n, dtype=torch.float32, device=dev)
         _lib.check(_lib.load().hpl_csr_build(_lib.ptr(idx), _lib.ptr(ones), n, n, H, _lib.ptr(csr_ptr),
                                              _lib.ptr(csr_pt), _lib.ptr(csr_w), _lib.ptr(norm),
@@ -245,7 +245,8 @@ def _run_conv_stack(x, stack, table, M, F, use_leaky, out=None):
         o = out if i == n - 1 else None
         if i == 0:
             x = ops.gconv(x, conv.weight, conv.bias, table.t, M, F, act=act,
-                          bwd_mode=table.bwd_mode(x.shape[0]), out=o, slope=_slope(use_leaky))
+                          bwd_mode=table.bwd_mode(x.shape[0]) if torch.is_grad_enabled() else 'scatter',
+                          out=o, slope=_slope(use_leaky))
         else:
             x = ops.gconv(x, conv.weight, conv.bias, None, M, 1, act=act, bwd_mode='dense', out=o,
                           slope=_slope(use_leaky))
@@ -365,7 +366,7 @@ class BilateralCorrelationFlex(nn.Module):
                                 % (tuple(corr1.t.shape), tuple(corr2.t.shape), K, F, H1))
         conv0 = self.corr_conv[0].conv
         w0 = conv0.weight                                  # (O, P + 2C, 1, K, 1), channels [prev | f1 | f2]
-        mode1 = corr1.bwd_mode(H1)
+        mode1 = corr1.bwd_mode(H1) if torch.is_grad_enabled() else 'scatter'   # symmetry check syncs
         # A-term: pc1 half, independent of the displacement tap
         a = ops.gconv(f1, w0, None, corr1.t, H1, K, c0=P, C=C, bwd_mode=mode1)
         if prev is not None:

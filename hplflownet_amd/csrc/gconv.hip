@@ -17,11 +17,32 @@
 // Roofline: MFMA fp32 (157.3 TFLOP/s); flops = 2*M*F*C*N.
 #include "common.h"
 
+#include <type_traits>
+
 using namespace hpl;
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef int int32x4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// buffer_load_dwordx4 through the LLVM intrinsic (hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128
+// lowers to a single-dword load, so the intrinsic is bound by name instead)
+__device__ float4_t buffer_load_f32x4(int32x4_t srsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
 namespace {
+
+// raw buffer descriptor: base pointer, stride 0, extent in bytes, gfx9 dword-3 flags (32-bit data format)
+__device__ __forceinline__ int32x4_t make_rsrc(const void *base, int bytes) {
+    union {
+        int32x4_t v;
+        struct { const void *p; int range; int cfg; } s;
+    } u;
+    u.s.p = base;
+    u.s.range = bytes;
+    u.s.cfg = 0x00020000;
+    return u.v;
+}
 
 constexpr int BK = 32;   // contraction slice per step (floats) = one 128-byte line per gathered row
 
@@ -34,6 +55,7 @@ struct GParams {
     float *Y; int64_t ldy;
     const int32_t *scat; int64_t scat_stride; int scat_c;
     int tiles_m; int tiles_n;
+    int64_t a_bytes; int64_t w_bytes;   // extents of A and Wt for the buffer descriptors
 };
 
 __device__ __forceinline__ int64_t src_row(const GParams &p, int f, int64_t m) {
@@ -61,7 +83,7 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
     tn = in_band / rows_in_band;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool AVEC>
+template <int BM, int BN, int WGM, int WGN, bool AVEC, int F_LDS>
 __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -75,9 +97,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     constexpr int B_PASSES = BK / B_ROWS_PER_PASS;
     static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too small for the thread count");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA_S + 2 * BK * LDB_S];
+    // one LDS array (A ring | B ring | neighbour indices of this tile, [F][BM] ints)
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA_S + 2 * BK * LDB_S + F_LDS * BM];
     float *As = smem;
     float *Bs = smem + 2 * BK * LDA_S;
+    int *Is = reinterpret_cast<int *>(smem + 2 * BK * LDA_S + 2 * BK * LDB_S);
 
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
@@ -102,56 +126,80 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     float4 ra[A_PASSES];
     float4 rb[B_PASSES];
 
+    // Stage the tile's source-row indices once: every later step reads them from LDS, so the
+    // gather of step t+1 is a burst of independent loads (no global index -> address chain).
+    // Rows past M, missing neighbours (-1) and taps past F all become -1.
+    for (int i = t; i < F_LDS * BM; i += NT) {
+        const int f = i / BM, r = i - f * BM;
+        Is[i] = (int)src_row(p, f, m0 + r);
+    }
+    __syncthreads();
+    // Buffer descriptors (wave-uniform, built from kernel arguments): 32-bit byte offsets keep the
+    // per-load address arithmetic to a multiply-add, and an out-of-range offset returns zeros in
+    // hardware -- that is how absent neighbours (-1), taps past F and columns past ldw read as 0.
+    constexpr unsigned OOB = 0x80000000u;   // > any extent (< 2 GiB, checked on the host), no 32-bit wrap
+    const int32x4_t rsrc_a = make_rsrc(p.A, (int)p.a_bytes);
+    const int32x4_t rsrc_b = make_rsrc(p.Wt, (int)p.w_bytes);
+    const unsigned lda_b = (unsigned)p.lda * 4u, ldw_b = (unsigned)p.ldw * 4u;
+    const bool bvalid = (n0 + bn4 * 4) < p.ldw;
+    const unsigned boff0 = bvalid ? (unsigned)brow0 * ldw_b + (unsigned)(n0 + bn4 * 4) * 4u : OOB;
+
     auto load_regs = [&](int k0) {
+        if (AVEC) {
+            const int fi = min(f_t, F_LDS - 1);
+            int rows[A_PASSES];
 #pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) {
-            const int64_t m = m0 + arow0 + i * A_ROWS_PER_PASS;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (AVEC) {
-                const int64_t row = src_row(p, f_t, m);
-                if (row >= 0) v = *reinterpret_cast<const float4 *>(p.A + row * p.lda + c_t);
-            } else {   // generic path: any C / alignment, element by element
+            for (int i = 0; i < A_PASSES; ++i) rows[i] = Is[fi * BM + arow0 + i * A_ROWS_PER_PASS];
+#pragma unroll
+            for (int i = 0; i < A_PASSES; ++i) {
+                const bool ok = (f_t < p.F) && (rows[i] >= 0);
+                const unsigned off = ok ? (unsigned)rows[i] * lda_b + (unsigned)c_t * 4u : OOB;
+                const float4_t v = buffer_load_f32x4(rsrc_a, (int)off, 0, 0);
+                ra[i] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        } else {   // generic path: any C / alignment, element by element
+#pragma unroll
+            for (int i = 0; i < A_PASSES; ++i) {
                 float e[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = k0 + kq * 4 + j;
                     const int f = k / p.C, c = k - f * p.C;
-                    const int64_t row = src_row(p, f, m);
-                    e[j] = (row >= 0) ? p.A[row * p.lda + c] : 0.f;
+                    const int row = (f < p.F) ? Is[min(f, F_LDS - 1) * BM + arow0 + i * A_ROWS_PER_PASS] : -1;
+                    e[j] = (row >= 0) ? p.A[(int64_t)row * p.lda + c] : 0.f;
                 }
-                v = make_float4(e[0], e[1], e[2], e[3]);
+                ra[i] = make_float4(e[0], e[1], e[2], e[3]);
             }
-            ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
-            const int kr = brow0 + i * B_ROWS_PER_PASS;
-            const int col = n0 + bn4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col < p.ldw) v = *reinterpret_cast<const float4 *>(p.Wt + (int64_t)(k0 + kr) * p.ldw + col);
-            rb[i] = v;
+            const unsigned off = bvalid ? boff0 + (unsigned)(k0 + i * B_ROWS_PER_PASS) * ldw_b : OOB;
+            const float4_t v = buffer_load_f32x4(rsrc_b, (int)off, 0, 0);
+            rb[i] = make_float4(v.x, v.y, v.z, v.w);
         }
         // advance (f, c) to the next slice
         c_t += BK;
         while (c_t >= p.C) { c_t -= p.C; ++f_t; }
     };
 
-    auto store_lds = [&](int buf) {
+    auto store_a = [&](int buf, int i) {
         float *a = As + buf * BK * LDA_S;
-#pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) {
-            const int r = arow0 + i * A_ROWS_PER_PASS;
-            a[(kq * 4 + 0) * LDA_S + r] = ra[i].x;
-            a[(kq * 4 + 1) * LDA_S + r] = ra[i].y;
-            a[(kq * 4 + 2) * LDA_S + r] = ra[i].z;
-            a[(kq * 4 + 3) * LDA_S + r] = ra[i].w;
-        }
+        const int r = arow0 + i * A_ROWS_PER_PASS;
+        a[(kq * 4 + 0) * LDA_S + r] = ra[i].x;
+        a[(kq * 4 + 1) * LDA_S + r] = ra[i].y;
+        a[(kq * 4 + 2) * LDA_S + r] = ra[i].z;
+        a[(kq * 4 + 3) * LDA_S + r] = ra[i].w;
+    };
+    auto store_b = [&](int buf, int i) {
         float *b = Bs + buf * BK * LDB_S;
+        const int kr = brow0 + i * B_ROWS_PER_PASS;
+        *reinterpret_cast<float4 *>(b + kr * LDB_S + bn4 * 4) = rb[i];
+    };
+    auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) {
-            const int kr = brow0 + i * B_ROWS_PER_PASS;
-            *reinterpret_cast<float4 *>(b + kr * LDB_S + bn4 * 4) = rb[i];
-        }
+        for (int i = 0; i < A_PASSES; ++i) store_a(buf, i);
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) store_b(buf, i);
     };
 
     floatx16 acc[TM][TN];
@@ -167,28 +215,48 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     store_lds(0);
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) load_regs((kt + 1) * BK);
+    // one contraction step; MORE (compile time) = also prefetch and stage step kt+1
+    auto step = [&](int kt, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
         const float *a = As + cur * BK * LDA_S + wm * WTM + li;
         const float *b = Bs + cur * BK * LDB_S + wn * WTN + li;
+        // fragments of k-pair kk+1 are fetched from LDS while the MFMAs of kk run
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[0][i] = a[hi * LDA_S + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[0][j] = b[hi * LDB_S + j * 32];
+        // Everything that is not an MFMA is placed in the shadow of the 64-cycle MFMAs of this
+        // step: the address arithmetic + global loads of step t+1 right after the first k-pair,
+        // the LDS stores of those loads during the second half (the loads have had ~2000 cycles).
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float av[TM], bv[TN];
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = a[(kk * 2 + hi) * LDA_S + i * 32];
+                for (int i = 0; i < TM; ++i) av[(kk + 1) & 1][i] = a[((kk + 1) * 2 + hi) * LDA_S + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = b[(kk * 2 + hi) * LDB_S + j * 32];
+                for (int j = 0; j < TN; ++j) bv[(kk + 1) & 1][j] = b[((kk + 1) * 2 + hi) * LDB_S + j * 32];
+            }
+            // keep the ds_reads of kk+1 ahead of the MFMAs of kk (hipcc otherwise sinks them below
+            // the MFMAs and waits lgkmcnt(0) right after: ~50 idle matrix-pipe cycles per k-pair)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (more) {
+                if (kk == 0) load_regs((kt + 1) * BK);
+                if (kk >= 8 && kk - 8 < A_PASSES) store_a(cur ^ 1, kk - 8);
+                if (kk >= 12 && kk - 12 < B_PASSES) store_b(cur ^ 1, kk - 12);
+            }
         }
-        if (more) store_lds(cur ^ 1);
         __syncthreads();
         cur ^= 1;
-    }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) step(kt, std::true_type{});
+    step(nk - 1, std::false_type{});
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -250,6 +318,8 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     HPL_REQUIRE(d->A && d->Wt && d->Y, "%s: null A / Wt / Y", who);
     HPL_REQUIRE(d->M >= 0 && d->C > 0 && d->F > 0 && d->N > 0, "%s: bad sizes M=%lld C=%d F=%d N=%d", who,
                 (long long)d->M, d->C, d->F, d->N);
+    HPL_REQUIRE(d->F <= 15, "%s: F=%d taps (radius > 1) not supported by the LDS-staged index table", who, d->F);
+    HPL_REQUIRE(d->rows_a > 0 && d->rows_a < (int64_t)INT32_MAX, "%s: rows_a out of range", who);
     HPL_REQUIRE((int64_t)d->F * d->C < (int64_t)INT32_MAX, "%s: contraction too long", who);
     HPL_REQUIRE(d->lda >= d->C, "%s: lda %lld < C %d", who, (long long)d->lda, d->C);
     HPL_REQUIRE(d->ldw >= d->N && d->ldw % 4 == 0 && aligned16(d->Wt), "%s: ldw must be a multiple of 4 >= N and Wt 16-byte aligned", who);
@@ -266,6 +336,10 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.Y = d->Y; p.ldy = d->ldy;
     p.scat = d->scat; p.scat_stride = d->scat_stride; p.scat_c = d->scat_c;
     p.tiles_m = p.tiles_n = 0;
+    p.a_bytes = ((d->rows_a - 1) * d->lda + d->C) * 4;
+    p.w_bytes = cdiv(p.K, 32) * 32 * d->ldw * 4;
+    HPL_REQUIRE(p.a_bytes < (int64_t)INT32_MAX && p.w_bytes < (int64_t)INT32_MAX,
+                "%s: A or Wt spans >= 2 GiB (32-bit buffer offsets)", who);
     return HPL_OK;
 }
 
@@ -274,8 +348,14 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
     p.tiles_m = (int)cdiv(p.M, BM);
     p.tiles_n = (int)cdiv(p.N, BN);
     const int grid = p.tiles_m * p.tiles_n;
-    if (avec) k_gconv<BM, BN, WGM, WGN, true><<<grid, 64 * WGM * WGN, 0, s>>>(p);
-    else k_gconv<BM, BN, WGM, WGN, false><<<grid, 64 * WGM * WGN, 0, s>>>(p);
+    // F_LDS = taps whose indices are staged in LDS: 1 for dense GEMMs, 15 for the radius-1 stencil
+    if (p.F == 1) {
+        if (avec) k_gconv<BM, BN, WGM, WGN, true, 1><<<grid, 64 * WGM * WGN, 0, s>>>(p);
+        else k_gconv<BM, BN, WGM, WGN, false, 1><<<grid, 64 * WGM * WGN, 0, s>>>(p);
+    } else {
+        if (avec) k_gconv<BM, BN, WGM, WGN, true, 15><<<grid, 64 * WGM * WGN, 0, s>>>(p);
+        else k_gconv<BM, BN, WGM, WGN, false, 15><<<grid, 64 * WGM * WGN, 0, s>>>(p);
+    }
 }
 
 }  // namespace
@@ -287,16 +367,19 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     if (p.M == 0) return HPL_OK;
     hipStream_t s = to_stream(stream);
     const bool avec = (p.C % 4 == 0) && (p.lda % 4 == 0) && aligned16(p.A);
-    // tile selection: widest N tile that is not mostly padding; BM = 64 when 128-row tiles
-    // could not give every CU at least ~2 workgroups
-    const int64_t CU2 = 512;
+    // Tile selection.  The chip holds 512 workgroups of the 128x128 kernel (2 per CU): prefer the
+    // largest tile that still yields >= ~512 tiles, otherwise shrink BM first (keeps weight reuse).
+    const int64_t t128 = cdiv(p.M, 128), t64 = cdiv(p.M, 64);
     if (p.N > 64) {
-        launch_cfg<128, 128, 2, 2>(p, avec, s);
+        const int64_t tn = cdiv(p.N, 128);
+        if (t128 * tn >= 448) launch_cfg<128, 128, 2, 2>(p, avec, s);
+        else if (t64 * tn >= 448 || p.N > 128) launch_cfg<64, 128, 2, 2>(p, avec, s);
+        else launch_cfg<64, 64, 2, 2>(p, avec, s);
     } else if (p.N > 32) {
-        if (cdiv(p.M, 128) >= CU2) launch_cfg<128, 64, 2, 2>(p, avec, s);
+        if (t128 >= 512) launch_cfg<128, 64, 2, 2>(p, avec, s);
         else launch_cfg<64, 64, 2, 2>(p, avec, s);
     } else {
-        if (cdiv(p.M, 128) >= CU2) launch_cfg<128, 32, 4, 1>(p, avec, s);
+        if (t128 >= 512) launch_cfg<128, 32, 4, 1>(p, avec, s);
         else launch_cfg<64, 32, 2, 1>(p, avec, s);
     }
     HPL_CHECK_LAUNCH("hpl_gconv_forward");
@@ -570,5 +653,41 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
     if (bn == 128) LAUNCH(128); else if (bn == 64) LAUNCH(64); else LAUNCH(32);
 #undef LAUNCH
     HPL_CHECK_LAUNCH("hpl_gconv_wgrad");
+    return HPL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Diagnostic: sustained rate of v_mfma_f32_32x32x2_f32 with no memory traffic (what the chip
+// gives at its actual clock under this instruction mix).  Used by tools/ and bench.py to quote
+// the measured ceiling next to the 157.3 TFLOP/s datasheet peak.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) k_mfma_probe(float *out, int iters) {
+    floatx16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = (float)threadIdx.x * 1e-3f, b = 1.0f + (float)blockIdx.x * 1e-6f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int hpl_mfma_probe(float *out, int blocks, int iters, hplStream stream) {
+    HPL_REQUIRE(out && blocks > 0 && iters > 0, "hpl_mfma_probe: bad arguments");
+    k_mfma_probe<<<blocks, 256, 0, to_stream(stream)>>>(out, iters);
+    HPL_CHECK_LAUNCH("hpl_mfma_probe");
     return HPL_OK;
 }

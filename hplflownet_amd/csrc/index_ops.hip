@@ -88,6 +88,10 @@ extern "C" int hpl_corr2_permute32(const int32_t *src, int32_t *dst, int F, int 
     return HPL_OK;
 }
 
+namespace hpl {
+int exclusive_scan_i32(const int32_t *cnt, int64_t n, int32_t *ptr, int32_t *tmp, hipStream_t s);
+}
+
 // ---------------------------------------------------------------- CSR build
 __global__ void k_zero_i32(int32_t *p, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,30 +109,71 @@ __global__ void k_csr_count(const int32_t *__restrict__ off, int64_t n_entries, 
     }
 }
 
-// single-workgroup exclusive scan of cnt[0..n) into ptr[0..n], ptr[n] = total.
-// n <= ~150k here (vertices of one lattice level); one 1024-thread group is plenty.
-__global__ void __launch_bounds__(1024) k_exclusive_scan(const int32_t *__restrict__ cnt, int64_t n,
-                                                         int32_t *__restrict__ ptr) {
-    __shared__ int32_t part[1024];
-    const int t = threadIdx.x;
-    const int64_t per = (n + 1023) / 1024;
-    const int64_t b = (int64_t)t * per, e = imin(n, b + per);
-    int32_t s = 0;
-    for (int64_t i = b; i < e; ++i) s += cnt[i];
-    part[t] = s;
+// Exclusive scan of cnt[0..n) into ptr[0..n], ptr[n] = total, in three launches:
+// 1024-element block sums -> scan of the (<= 1024) block sums -> per-block scan + offset.
+constexpr int SCAN_BLOCK = 1024;   // elements per 256-thread workgroup
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int *total) {
+    // exclusive scan of one int per thread over a 256-thread workgroup
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan over the partials
-        int32_t v = (t >= d) ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) base += (i < w) ? wsum[i] : 0;
+    if (total) *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(256) k_scan_sums(const int32_t *__restrict__ in, int64_t n,
+                                                   int32_t *__restrict__ block_sums) {
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += (i0 + j < n) ? in[i0 + j] : 0;
+    int total;
+    block_exclusive_scan_256(s, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// in-place exclusive scan of nb <= 1024 block sums; block_sums[nb] = grand total
+__global__ void __launch_bounds__(256) k_scan_top(int32_t *__restrict__ block_sums, int nb) {
+    const int i0 = threadIdx.x * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = (i0 + j < nb) ? block_sums[i0 + j] : 0; s += v[j]; }
+    int total;
+    int run = block_exclusive_scan_256(s, &total);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (i0 + j < nb) block_sums[i0 + j] = run;
+        run += v[j];
     }
-    int32_t run = (t == 0) ? 0 : part[t - 1];
-    for (int64_t i = b; i < e; ++i) {
-        ptr[i] = run;
-        run += cnt[i];
+    if (threadIdx.x == 0) block_sums[nb] = total;
+}
+
+__global__ void __launch_bounds__(256) k_scan_final(const int32_t *__restrict__ in, int64_t n,
+                                                    const int32_t *__restrict__ block_sums, int nb,
+                                                    int32_t *__restrict__ out) {
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = (i0 + j < n) ? in[i0 + j] : 0; s += v[j]; }
+    int run = block_exclusive_scan_256(s, nullptr) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (i0 + j < n) out[i0 + j] = run;
+        run += v[j];
     }
-    if (t == 1023) ptr[n] = part[1023];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_sums[nb];
 }
 
 __global__ void k_csr_fill(const int32_t *__restrict__ off, int64_t n_entries, int64_t H,
@@ -145,32 +190,33 @@ __global__ void k_csr_fill(const int32_t *__restrict__ off, int64_t n_entries, i
     }
 }
 
-// one thread per vertex: insertion-sort its (short) segment by entry id so the summation
-// order is fixed, then emit (point, weight) pairs and the density normaliser.
-__global__ void k_csr_finish(const int32_t *__restrict__ ptr, int32_t *__restrict__ ent,
-                             const float *__restrict__ bary, int64_t N, int64_t H,
-                             float *__restrict__ w_out, float *__restrict__ norm) {
-    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Segments come out of k_csr_fill in atomic (arbitrary) order.  A 16-lane group per vertex ranks
+// every entry among its segment (entries are distinct, segments are short: mean 4..15), which
+// fixes the summation order of the splat, and emits (point, weight) pairs in that order.
+__global__ void __launch_bounds__(256) k_csr_rank(const int32_t *__restrict__ ptr, const int32_t *__restrict__ ent,
+                                                  const float *__restrict__ bary, int64_t pt_mod, int64_t H,
+                                                  int32_t *__restrict__ pt_out, float *__restrict__ w_out) {
+    const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int lg = threadIdx.x & 15;
     if (v >= H) return;
     const int32_t b = ptr[v], e = ptr[v + 1];
-    for (int32_t i = b + 1; i < e; ++i) {
-        int32_t x = ent[i];
-        int32_t j = i - 1;
-        while (j >= b && ent[j] > x) {
-            ent[j + 1] = ent[j];
-            --j;
-        }
-        ent[j + 1] = x;
+    for (int32_t i = b + lg; i < e; i += 16) {
+        const int32_t x = ent[i];
+        int32_t rank = 0;
+        for (int32_t j = b; j < e; ++j) rank += (ent[j] < x) ? 1 : 0;
+        pt_out[b + rank] = (int32_t)(x % pt_mod);
+        w_out[b + rank] = bary[x];
     }
+}
+
+// density normaliser 1 / (sum of weights + 1e-5), summed in segment order (models/bilateralNN.py:183)
+__global__ void k_csr_norm(const int32_t *__restrict__ ptr, const float *__restrict__ w, int64_t H,
+                           float *__restrict__ norm) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= H) return;
     float s = 0.f;
-    for (int32_t i = b; i < e; ++i) {
-        int32_t en = ent[i];
-        float w = bary[en];
-        w_out[i] = w;
-        ent[i] = (int32_t)(en % N);   // entry e = r*N + n  ->  point n
-        s += w;
-    }
-    norm[v] = 1.0f / (s + 1e-5f);   // models/bilateralNN.py:183
+    for (int32_t i = ptr[v]; i < ptr[v + 1]; ++i) s += w[i];
+    norm[v] = 1.0f / (s + 1e-5f);
 }
 
 extern "C" int hpl_csr_build(const int32_t *off, const float *bary, int64_t n_entries, int64_t pt_mod,
@@ -185,12 +231,15 @@ extern "C" int hpl_csr_build(const int32_t *off, const float *bary, int64_t n_en
     const int64_t N = pt_mod;
     int gh = (int)imin(cdiv(H + 1, 256), 2048);
     int ge = (int)imin(cdiv(ne, 256), 2048);
-    k_zero_i32<<<gh, 256, 0, s>>>(scratch, H + 1);
-    k_csr_count<<<ge, 256, 0, s>>>(off, ne, H, scratch);
-    k_exclusive_scan<<<1, 1024, 0, s>>>(scratch, H, csr_ptr);
-    k_zero_i32<<<gh, 256, 0, s>>>(scratch, H + 1);
-    k_csr_fill<<<ge, 256, 0, s>>>(off, ne, H, csr_ptr, scratch, csr_pt);
-    k_csr_finish<<<(int)cdiv(H, 256), 256, 0, s>>>(csr_ptr, csr_pt, bary, N, H, csr_w, norm);
+    int32_t *cursor = scratch, *ent = scratch + (H + 1), *scan_tmp = ent + ne;
+    k_zero_i32<<<gh, 256, 0, s>>>(cursor, H + 1);
+    k_csr_count<<<ge, 256, 0, s>>>(off, ne, H, cursor);
+    int rc = exclusive_scan_i32(cursor, H, csr_ptr, scan_tmp, s);
+    if (rc != HPL_OK) return rc;
+    k_zero_i32<<<gh, 256, 0, s>>>(cursor, H + 1);
+    k_csr_fill<<<ge, 256, 0, s>>>(off, ne, H, csr_ptr, cursor, ent);
+    k_csr_rank<<<(int)cdiv(H * 16, 256), 256, 0, s>>>(csr_ptr, ent, bary, N, H, csr_pt, csr_w);
+    k_csr_norm<<<(int)cdiv(H, 256), 256, 0, s>>>(csr_ptr, csr_w, H, norm);
     HPL_CHECK_LAUNCH("hpl_csr_build");
     return HPL_OK;
 }
@@ -279,10 +328,14 @@ extern "C" int hpl_leaky_bwd(const float *dY, int64_t lddy, const float *Y, int6
     return HPL_OK;
 }
 
-// shared with lattice.hip
+// shared with lattice.hip.  tmp: cdiv(n, 1024) + 1 ints.
 namespace hpl {
-int exclusive_scan_i32(const int32_t *cnt, int64_t n, int32_t *ptr, hipStream_t s) {
-    k_exclusive_scan<<<1, 1024, 0, s>>>(cnt, n, ptr);
+int exclusive_scan_i32(const int32_t *cnt, int64_t n, int32_t *ptr, int32_t *tmp, hipStream_t s) {
+    const int64_t nb = cdiv(n, SCAN_BLOCK);
+    HPL_REQUIRE(nb >= 1 && nb <= 1024, "exclusive_scan_i32: n=%lld out of range", (long long)n);
+    k_scan_sums<<<(int)nb, 256, 0, s>>>(cnt, n, tmp);
+    k_scan_top<<<1, 256, 0, s>>>(tmp, (int)nb);
+    k_scan_final<<<(int)nb, 256, 0, s>>>(cnt, n, tmp, (int)nb, ptr);
     HPL_CHECK_LAUNCH("exclusive_scan_i32");
     return HPL_OK;
 }

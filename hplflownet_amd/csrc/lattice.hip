@@ -28,7 +28,7 @@ using namespace hpl;
 
 namespace hpl {
 // defined in index_ops.hip
-int exclusive_scan_i32(const int32_t *cnt, int64_t n, int32_t *ptr, hipStream_t s);
+int exclusive_scan_i32(const int32_t *cnt, int64_t n, int32_t *ptr, int32_t *tmp, hipStream_t s);
 }  // namespace hpl
 
 namespace {
@@ -132,6 +132,7 @@ struct CloudWS {
     int32_t *slot;     // [E]    table slot of every entry
     int32_t *flag;     // [E+1]  ownership flags, then their exclusive scan (in place copy)
     int32_t *scan;     // [E+1]
+    int32_t *scan_tmp; // [1026] block sums of the scan
     uint64_t mask;     // cap - 1
     int64_t n, E, cap;
 };
@@ -158,6 +159,7 @@ WS carve(void *base, int64_t n1, int64_t n2) {
         q.slot = reinterpret_cast<int32_t *>(take(q.E * 4));
         q.flag = reinterpret_cast<int32_t *>(take((q.E + 1) * 4));
         q.scan = reinterpret_cast<int32_t *>(take((q.E + 1) * 4));
+        q.scan_tmp = reinterpret_cast<int32_t *>(take(1026 * 4));
     }
     w.bytes = p - reinterpret_cast<char *>(base);
     return w;
@@ -420,7 +422,7 @@ extern "C" int hpl_lattice_hash(const int32_t *keys1, int64_t n1, const int32_t 
         const CloudWS &q = w.c[c];
         k_hash_insert<<<(int)cdiv(q.n, 256), 256, 0, s>>>(keys[c], q.n, w.mm, q.tkeys, q.tfirst, q.mask, q.slot);
         k_flags<<<(int)cdiv(q.E, 256), 256, 0, s>>>(q.slot, q.tfirst, q.E, q.flag);
-        int rc = exclusive_scan_i32(q.flag, q.E, q.scan, s);
+        int rc = exclusive_scan_i32(q.flag, q.E, q.scan, q.scan_tmp, s);
         if (rc != HPL_OK) return rc;
         k_assign_ids<<<(int)cdiv(q.E, 256), 256, 0, s>>>(keys[c], q.n, q.slot, q.flag, q.scan, q.tid, vk[c],
                                                         q.E, counts + c);

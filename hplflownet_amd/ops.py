@@ -72,7 +72,7 @@ class CloudTables(object):
             csr_pt = torch.empty(4 * self.N, dtype=torch.int32, device=dev)
             csr_w = torch.empty(4 * self.N, dtype=torch.float32, device=dev)
             norm = torch.empty(self.H, dtype=torch.float32, device=dev)
-            scratch = torch.empty(self.H + 1, dtype=torch.int32, device=dev)
+            scratch = torch.empty(self.H + 1 + 4 * self.N + 1026, dtype=torch.int32, device=dev)
             check(_lib.load().hpl_csr_build(ptr(self.off), ptr(self.bary), 4 * self.N, self.N, self.H, ptr(csr_ptr),
                                             ptr(csr_pt), ptr(csr_w), ptr(norm), ptr(scratch), stream()),
                   'hpl_csr_build')

@@ -70,7 +70,7 @@ int hpl_corr2_permute32(const int32_t *src, int32_t *dst, int F, int K, int64_t 
  *                        contribution, ascending e within a vertex,
  *   csr_w   [n_entries]  its weight,
  *   norm    [H]          1 / (sum of weights + 1e-5)   (models/bilateralNN.py:168-183).
- * `scratch` needs (H + 1) int32.  Replaces the COO coalesce inside
+ * `scratch` needs (H + 1) + n_entries + 1026 int32.  Replaces the COO coalesce inside
  * torch.sparse.FloatTensor(...).to_dense() (models/bilateralNN.py:24-29): the sort is
  * done once per lattice instead of once per layer call, and is deterministic. */
 int hpl_csr_build(const int32_t *off, const float *bary, int64_t n_entries, int64_t pt_mod, int64_t H,
@@ -161,6 +161,10 @@ int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, const int32_t *
                     int64_t nbr_stride, int64_t reg_stride, int64_t M, int C, int F,
                     const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
                     hplStream stream);
+
+/* Diagnostic: `blocks` workgroups of 4 waves each issue iters*64 v_mfma_f32_32x32x2_f32 per wave
+ * with no memory traffic; out needs blocks*256 floats.  flops = blocks*4*iters*64*4096. */
+int hpl_mfma_probe(float *out, int blocks, int iters, hplStream stream);
 
 /* out[n] = sum_m X[m*ld + n]   (bias gradients) */
 int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStream stream);
