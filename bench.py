@@ -72,7 +72,8 @@ class KernelTimers(object):
             return inner
 
         def d_gconv(A, nbr, M, C, F, Wt, N, **k):
-            return ('gconv_' + gconv_class(M, N), 2.0 * M * F * C * N, 0.0)
+            # suffix: g = gathered (15-tap stencil, template F_LDS=15), d = dense (F_LDS=1)
+            return ('gconv_%s_%s' % (gconv_class(M, N), 'g' if F > 1 else 'd'), 2.0 * M * F * C * N, 0.0)
 
         def d_splat(feat, csr, H, use_norm=True, out=None):
             N, C = feat.shape
@@ -107,6 +108,21 @@ class KernelTimers(object):
             d['frac'] = d['achieved'] / d['peak']
             out[name] = d
         return out
+
+
+def mfma_ceiling(dev):
+    """Sustained v_mfma_f32_32x32x2_f32 rate with no memory traffic on this device (TFLOP/s)."""
+    from hplflownet_amd import _lib
+    L = _lib.load()
+    out = torch.empty(1024 * 256, device=dev)
+    L.hpl_mfma_probe(out.data_ptr(), 1024, 100, _lib.stream())
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    L.hpl_mfma_probe(out.data_ptr(), 1024, 2000, _lib.stream())
+    e.record()
+    torch.cuda.synchronize()
+    return 1024 * 4.0 * 2000 * 64 * 4096 / (s.elapsed_time(e) * 1e-3) / 1e12
 
 
 def cpu_baseline(pc1, pc2, sf, sfm, state_dict):
@@ -201,10 +217,11 @@ def main():
 
     if rank == 0:
         kernels = timers.summary(a.steps)
-        dom = kernels.get('gconv_128x128', {})
+        dom = kernels.get('gconv_128x128_g', {})
         roofline = {'bound': 'mfma', 'achieved': dom.get('achieved'), 'peak': MFMA_F32_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': dom.get('frac'), 'traffic': None,
-                    'kernel': 'k_gconv<128,128,2,2,true> (fp32-MFMA gather-GEMM: Up-BCL blur convs, conv2, conv3)',
+                    'kernel': 'k_gconv<128,128,2,2,true,15> (fp32-MFMA gather-GEMM, 15-tap stencil: blur convs of bcn1_/bcn2_)',
+                    'measured_mfma_ceiling': mfma_ceiling(dev),
                     'launches_per_step': dom.get('launches_per_step'), 'avg_launch_us': dom.get('avg_launch_us'),
                     'gflop_per_step': dom.get('gflop_per_step')}
         prof = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')

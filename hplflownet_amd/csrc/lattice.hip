@@ -415,7 +415,7 @@ extern "C" int hpl_lattice_hash(const int32_t *keys1, int64_t n1, const int32_t 
     int32_t *offs[2] = {off1, off2};
     int32_t *vk[2] = {vkeys1, vkeys2};
     for (int c = 0; c < 2; ++c) {
-        dim3 g((unsigned)imin(cdiv(w.c[c].n, 256), 256), 4);
+        dim3 g((unsigned)imin(cdiv(w.c[c].n, 1024), 16), 4);   // few groups: 8 contended atomics per wave
         k_minmax<<<g, 256, 0, s>>>(keys[c], w.c[c].n, w.mm);
     }
     for (int c = 0; c < 2; ++c) {

@@ -156,7 +156,8 @@ def test_whole_model_golden_F5(tag, cls, n, nsc):
     # inference path (no autograd, in-place channel-block writes) gives the same flow
     with torch.no_grad():
         y2 = m(p1, p2, gd_batched_device(gd[:nsc]))
-    assert float((y2 - y.detach()).abs().max()) < 1e-5
+    # (it also runs the last 1x1 conv of the Up layers after the slice, see bcl.py: rounding differs)
+    assert float((y2 - y.detach()).abs().max()) < 2e-5 * max(1.0, float(y.detach().abs().max()))
 
 
 @pytest.mark.parametrize('n,seed', [(256, 0), (1024, 0), (1024, 3), (8192, 0)])
