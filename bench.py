@@ -154,6 +154,8 @@ def main():
     ap.add_argument('--pool', type=int, default=4, help='distinct resident pairs cycled through the steps')
     ap.add_argument('--no-lattice', action='store_true', help='exclude the device lattice build from the step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--train', action='store_true',
+                    help='time a training step (fwd + bwd + gradient all-reduce + Adam) instead of inference')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -163,11 +165,8 @@ def main():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # RCCL; used for barrier/max only
+    from hplflownet_amd import parallel
+    parallel.init_distributed(backend='nccl', device=dev)      # RCCL; inference uses it for barrier/max only
     if a.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
 
@@ -183,7 +182,7 @@ def main():
     model = model.to(dev).eval()
     gen = H.GenerateDataUnsymmetric(margs, device=dev)
 
-    pairs_np = [synthetic_pair(a.points, 1000 * rank + i) for i in range(a.pool)]
+    pairs_np = [synthetic_pair(a.points, s) for s in parallel.sample_seeds(rank, world, a.pool)]
     pairs = [(torch.from_numpy(p1.T.copy()).to(dev), torch.from_numpy(p2.T.copy()).to(dev)) for p1, p2, _ in pairs_np]
     fixed_lat = [gen.build(p1, p2) for p1, p2 in pairs] if a.no_lattice else None
     timers = KernelTimers(ops)
@@ -194,11 +193,31 @@ def main():
         return model(p1[None], p2[None], lat)
 
     def sync_all():
-        if dist is not None:
-            dist.barrier()
+        parallel.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
+    if a.train:
+        # BASELINE config 4: one pair per GPU, identical weights, mean loss over ranks ==
+        # all-reduce(mean) of the gradients (77.2 MB fp32 over xGMI), Adam lr 1e-4 (main.py:138-140)
+        model.train()
+        parallel.broadcast_parameters(model)
+        reducer = parallel.GradAllReducer(model.parameters())
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        sfs = [torch.from_numpy(sf.T.copy()).to(dev) for _, _, sf in pairs_np]
+
+        def step(i):                                           # noqa: F811
+            p1, p2 = pairs[i % a.pool]
+            with torch.no_grad():
+                lat = fixed_lat[i % a.pool] if a.no_lattice else gen.build(p1, p2)
+            flow = model(p1[None], p2[None], lat)
+            loss = torch.norm(flow - sfs[i % a.pool][None], p=2, dim=1).mean()      # EPE3DLoss, main.py:213
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            reducer()
+            opt.step()
+            return flow
+
+    with torch.set_grad_enabled(a.train):
         for i in range(a.warmup):
             step(i)
         sync_all()
@@ -209,11 +228,8 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         timers.enabled = False
-        if dist is not None:
-            dist.barrier()
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        parallel.barrier()
+        elapsed = parallel.max_over_ranks(elapsed, device=dev)
 
     if rank == 0:
         kernels = timers.summary(a.steps)
@@ -234,13 +250,13 @@ def main():
                 'value': world * a.steps / elapsed, 'unit': 'point-pairs/s', 'n_gpus': world, 'steps': a.steps,
                 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': 'full HPLFlowNet inference (7 levels, 19.3M params, random init), '
+                'config': {'workload': 'full HPLFlowNet %s (7 levels, 19.3M params, random init), ' % ('training step (fwd+bwd+grad all-reduce+Adam)' if a.train else 'inference') +
                                        'FT3D-like synthetic pair, N=%d, bs=1 per GPU' % a.points,
                            'num_points': a.points, 'step_includes_lattice_build': not a.no_lattice,
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.train:
             p1, p2, sf = pairs_np[0]
             base, flow_cpu, epe_cpu = cpu_baseline(p1, p2, sf, SCALES_FILTER_MAP, state)
             with torch.no_grad():
@@ -253,8 +269,8 @@ def main():
                              'note': 'random-init weights: parity number, not accuracy'}
             line['speedup_vs_cpu_baseline'] = line['value'] / base['value']
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

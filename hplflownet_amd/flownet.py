@@ -229,3 +229,13 @@ class HPLFlowNetShallow(_FlowNetBase):
     UP = {4: [64], 3: [64], 2: [64], 1: [64], 0: [128]}
     REFINE = True
     HEAD_IN = 128
+
+
+def load_reference_checkpoint(model, checkpoint, strict=True):
+    """Load a checkpoint written by the reference (`main_utils.save_checkpoint`, main_utils.py:54-64:
+    dict with 'state_dict' of the DataParallel-wrapped model, keys prefixed 'module.', main.py:104,122)
+    or a bare state_dict into one of the models above.  `checkpoint` is a path or the loaded object."""
+    obj = torch.load(checkpoint, map_location='cpu') if isinstance(checkpoint, str) else checkpoint
+    sd = obj.get('state_dict', obj) if isinstance(obj, dict) else obj
+    sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
+    return model.load_state_dict(sd, strict=strict)

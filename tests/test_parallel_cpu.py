@@ -1,0 +1,74 @@
+"""CPU, world_size 2, gloo: the multi-process plumbing of hplflownet_amd.parallel -- sample
+sharding, max-over-ranks timing, bucketed gradient all-reduce == single-process gradient of the
+mean loss, parameter broadcast.  (The HIP kernels need a GPU; the collectives do not.)"""
+import os
+import socket
+import sys
+import tempfile
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Conv1d(3, 16, 1), torch.nn.LeakyReLU(0.1), torch.nn.Conv1d(16, 16, 1),
+                               torch.nn.LeakyReLU(0.1), torch.nn.Conv1d(16, 3, 1))
+
+
+def _sample(i):
+    g = torch.Generator().manual_seed(100 + i)
+    return torch.randn(1, 3, 64, generator=g), torch.randn(1, 3, 64, generator=g)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from hplflownet_amd import parallel as P
+    r, w, lr = P.init_distributed(backend='gloo')
+    assert (r, w, lr) == (rank, world, rank)
+    seeds = P.sample_seeds(rank, world, 3)
+    model = _make_model(seed=rank)                 # deliberately different per rank ...
+    P.broadcast_parameters(model, src=0)           # ... until broadcast
+    red = P.GradAllReducer(model.parameters(), bucket_bytes=1024)   # small buckets -> several collectives
+    assert len(red.buckets) > 1
+    x, t = _sample(seeds[0])
+    loss = torch.norm(model(x) - t, p=2, dim=1).mean()
+    loss.backward()
+    red()
+    P.barrier()
+    tmax = P.max_over_ranks(1.0 + rank)
+    torch.save({'seeds': seeds, 'grads': [p.grad.clone() for p in model.parameters()],
+                'params': [p.detach().clone() for p in model.parameters()], 'tmax': tmax},
+               os.path.join(out_dir, 'r%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        res = [torch.load(os.path.join(d, 'r%d.pt' % r)) for r in range(world)]
+    assert res[0]['seeds'] == [0, 2, 4] and res[1]['seeds'] == [1, 3, 5]            # disjoint shards
+    assert res[0]['tmax'] == res[1]['tmax'] == 2.0                                   # slowest rank
+    for a, b in zip(res[0]['params'], res[1]['params']):
+        assert torch.equal(a, b)                                                     # broadcast
+    for a, b in zip(res[0]['grads'], res[1]['grads']):
+        assert torch.equal(a, b)                                                     # identical after all-reduce
+    # reference: one process, mean of the two per-sample losses
+    model = _make_model(seed=0)
+    loss = sum(torch.norm(model(_sample(s)[0]) - _sample(s)[1], p=2, dim=1).mean() for s in (0, 1)) / 2
+    loss.backward()
+    for p, g in zip(model.parameters(), res[0]['grads']):
+        assert torch.allclose(p.grad, g, atol=1e-6, rtol=1e-5)
