@@ -154,6 +154,8 @@ def main():
     ap.add_argument('--pool', type=int, default=4, help='distinct resident pairs cycled through the steps')
     ap.add_argument('--no-lattice', action='store_true', help='exclude the device lattice build from the step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='build each lattice on the main stream instead of a second stream overlapping the previous forward')
     ap.add_argument('--train', action='store_true',
                     help='time a training step (fwd + bwd + gradient all-reduce + Adam) instead of inference')
     a = ap.parse_args()
@@ -217,14 +219,54 @@ def main():
             opt.step()
             return flow
 
+    overlap = not (a.train or a.no_lattice or a.no_overlap)
+    side = torch.cuda.Stream(device=dev) if overlap else None
+
+    def run_pipelined(first, count):
+        """count steps; the lattice of pair i+1 is built on a second HIP stream while the forward of
+        pair i runs on the main stream (the reference overlaps the same two stages with DataLoader
+        worker processes, main.py:85-92).  Exactly `count` lattice builds and `count` forwards."""
+        import collections
+        main = torch.cuda.current_stream()
+
+        def build(i):
+            with torch.cuda.stream(side):
+                lat = gen.build(*pairs[i % a.pool]).prepare()
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return lat, ev
+        keep = collections.deque()
+        nxt = build(first)
+        out = None
+        for i in range(first, first + count):
+            lat, ev = nxt
+            main.wait_event(ev)
+            p1, p2 = pairs[i % a.pool]
+            out = model(p1[None], p2[None], lat)
+            fin = torch.cuda.Event()
+            fin.record(main)
+            keep.append((lat, out, fin))          # side-stream allocations stay alive until their forward is done
+            if i + 1 < first + count:
+                nxt = build(i + 1)
+            while len(keep) > 2:
+                keep[0][2].synchronize()
+                keep.popleft()
+        return out
+
     with torch.set_grad_enabled(a.train):
-        for i in range(a.warmup):
-            step(i)
+        if overlap:
+            run_pipelined(0, a.warmup)
+        else:
+            for i in range(a.warmup):
+                step(i)
         sync_all()
         timers.enabled = True
         t0 = time.perf_counter()
-        for i in range(a.steps):
-            y = step(i)
+        if overlap:
+            y = run_pipelined(a.warmup, a.steps)
+        else:
+            for i in range(a.steps):
+                y = step(i)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         timers.enabled = False
@@ -253,6 +295,7 @@ def main():
                 'config': {'workload': 'full HPLFlowNet %s (7 levels, 19.3M params, random init), ' % ('training step (fwd+bwd+grad all-reduce+Adam)' if a.train else 'inference') +
                                        'FT3D-like synthetic pair, N=%d, bs=1 per GPU' % a.points,
                            'num_points': a.points, 'step_includes_lattice_build': not a.no_lattice,
+                           'lattice_overlapped_on_second_stream': bool(overlap),
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels}

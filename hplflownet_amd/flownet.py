@@ -35,6 +35,14 @@ class DeviceLattice(object):
     def __init__(self, levels):
         self.levels = levels
 
+    def prepare(self):
+        """Build every lazily constructed table (the CSR of each splat) now, on the current stream,
+        so that a lattice built on a side stream is complete before it is handed to the forward."""
+        for lv in self.levels:
+            for c in lv.clouds:
+                c.csr()
+        return self
+
     @staticmethod
     def from_generated_data(gd, device):
         levels = []
