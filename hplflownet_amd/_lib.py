@@ -27,7 +27,8 @@ class GConvDesc(ctypes.Structure):
                 ('Wt', c_vp), ('ldw', c_i64), ('N', c_i32), ('act', c_i32), ('slope', c_f32),
                 ('bias', c_vp), ('res', c_vp), ('ldres', c_i64), ('res_mod', c_i64),
                 ('Y', c_vp), ('ldy', c_i64),
-                ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('reserved', c_i32)]
+                ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('reserved', c_i32),
+                ('row_perm', c_vp)]
 
 
 _SIGNATURES = {
@@ -45,6 +46,7 @@ _SIGNATURES = {
                                            c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
     'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,
                                            c_i64, c_i64, c_i64, ctypes.c_int, c_vp]),
+    'hpl_tap_order': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
     'hpl_gconv_forward': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
     'hpl_gconv_forward_naive': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
     'hpl_gconv_wgrad': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,

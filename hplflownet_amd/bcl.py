@@ -98,9 +98,21 @@ def pointwise_conv(x, conv, act, use_leaky, out=None):
 class NbrTable(object):
     """int32 neighbour table [F, M] on the device + lazily checked symmetry."""
 
+    #: tables with fewer rows are not worth reordering (one tile or two)
+    PERM_MIN_ROWS = 1024
+
     def __init__(self, t):
         self.t = t
         self._sym = None
+        self._perm = False      # False = not computed yet, None = not applicable
+
+    @property
+    def perm(self):
+        """Row order grouping vertices by tap-presence mask (inference only; see gconv row_perm)."""
+        if self._perm is False:
+            F, M = self.t.shape
+            self._perm = ops.tap_order(self.t) if (1 < F <= 15 and M >= self.PERM_MIN_ROWS) else None
+        return self._perm
 
     @property
     def symmetric(self):
@@ -246,7 +258,8 @@ def _run_conv_stack(x, stack, table, M, F, use_leaky, out=None):
         if i == 0:
             x = ops.gconv(x, conv.weight, conv.bias, table.t, M, F, act=act,
                           bwd_mode=table.bwd_mode(x.shape[0]) if torch.is_grad_enabled() else 'scatter',
-                          out=o, slope=_slope(use_leaky))
+                          out=o, slope=_slope(use_leaky),
+                          row_perm=None if torch.is_grad_enabled() else table.perm)
         else:
             x = ops.gconv(x, conv.weight, conv.bias, None, M, 1, act=act, bwd_mode='dense', out=o,
                           slope=_slope(use_leaky))
@@ -380,7 +393,8 @@ class BilateralCorrelationFlex(nn.Module):
         w0 = conv0.weight                                  # (O, P + 2C, 1, K, 1), channels [prev | f1 | f2]
         mode1 = corr1.bwd_mode(H1) if torch.is_grad_enabled() else 'scatter'   # symmetry check syncs
         # A-term: pc1 half, independent of the displacement tap
-        a = ops.gconv(f1, w0, None, corr1.t, H1, K, c0=P, C=C, bwd_mode=mode1)
+        perm1 = None if torch.is_grad_enabled() else corr1.perm
+        a = ops.gconv(f1, w0, None, corr1.t, H1, K, c0=P, C=C, bwd_mode=mode1, row_perm=perm1)
         if prev is not None:
             if P == 0:
                 raise _lib.HplError('prev_corr_feat given but prev_corr_dim == 0')
@@ -388,7 +402,7 @@ class BilateralCorrelationFlex(nn.Module):
                 ps = ops.SplatFn.apply(prev, cloud1, self.use_norm)
             else:
                 ps = ops.splat_raw(prev, cloud1.csr(), H1, self.use_norm)
-            a = ops.gconv(ps, w0, None, corr1.t, H1, K, c0=0, C=P, res=a, res_mod=H1, bwd_mode=mode1)
+            a = ops.gconv(ps, w0, None, corr1.t, H1, K, c0=0, C=P, res=a, res_mod=H1, bwd_mode=mode1, row_perm=perm1)
         # B-term over the F*H1 virtual vertices, + broadcast A-term + bias, LeakyReLU
         p = ops.gconv(f2, w0, conv0.bias, corr2.t, F * H1, K, act=ACT_LEAKY, c0=P + C, C=C, res=a,
                       res_mod=H1, bwd_mode='scatter', slope=sl)

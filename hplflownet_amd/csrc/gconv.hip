@@ -56,6 +56,7 @@ struct GParams {
     const int32_t *scat; int64_t scat_stride; int scat_c;
     int tiles_m; int tiles_n;
     int64_t a_bytes; int64_t w_bytes;   // extents of A and Wt for the buffer descriptors
+    const int32_t *row_perm;            // optional permutation of the output rows (tile row -> vertex)
 };
 
 __device__ __forceinline__ int64_t src_row(const GParams &p, int f, int64_t m) {
@@ -74,6 +75,22 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
     const int q = nwg / 8, r = nwg % 8;
     const int xcd = bid % 8, pos = bid / 8;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // bijective
+    if (p.row_perm) {
+        // Rows are sorted by tap mask: tile-rows differ in work (few taps ... all taps) and have no
+        // spatial coherence.  Deal the tile-rows round-robin over the XCDs, heaviest (last in the
+        // sort) first, and keep the column tiles of one tile-row adjacent so that they share its
+        // gathered rows in that XCD's L2.
+        int s = id / p.tiles_n;             // position in the XCD-major sequence of tile-rows
+        tn = id - s * p.tiles_n;
+        int x = 0;
+        for (; x < 8; ++x) {
+            const int rows_x = (p.tiles_m - x + 7) / 8;
+            if (s < rows_x) break;
+            s -= rows_x;
+        }
+        tm = p.tiles_m - 1 - (s * 8 + x);
+        return;
+    }
     constexpr int BAND = 8;
     const int band_sz = BAND * p.tiles_n;
     const int band = id / band_sz;
@@ -98,10 +115,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too small for the thread count");
 
     // one LDS array (A ring | B ring | neighbour indices of this tile, [F][BM] ints)
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA_S + 2 * BK * LDB_S + F_LDS * BM];
+    // + output row of every tile row [BM] + the tile's tap mask [1])
+    // + list of the contraction slices this tile needs [KLIST ushort])
+    constexpr int KLIST = 1024;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA_S + 2 * BK * LDB_S + F_LDS * BM + BM + 4 + KLIST / 2];
     float *As = smem;
     float *Bs = smem + 2 * BK * LDA_S;
     int *Is = reinterpret_cast<int *>(smem + 2 * BK * LDA_S + 2 * BK * LDB_S);
+    int *Vs = Is + F_LDS * BM;          // vertex (output row) of tile row r, -1 past M
+    int *tapmask_s = Vs + BM;          // [0] tap mask, [1] number of needed slices
+    unsigned short *Ks = reinterpret_cast<unsigned short *>(tapmask_s + 4);
 
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
@@ -117,8 +140,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     // ---- A staging state: this thread always loads float4 column kq of the slice
     const int kq = t & 7;
     const int arow0 = t >> 3;
-    int f_t = (kq * 4) / p.C;          // (f, c) of flat index k0 + kq*4 ; advanced by BK per step
-    int c_t = (kq * 4) - f_t * p.C;
+    int f_t = 0, c_t = 0;              // (f, c) of flat index k0 + kq*4, set per step
     // ---- B staging state
     const int bn4 = t % B_F4_PER_ROW;
     const int brow0 = t / B_F4_PER_ROW;
@@ -129,11 +151,28 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     // Stage the tile's source-row indices once: every later step reads them from LDS, so the
     // gather of step t+1 is a burst of independent loads (no global index -> address chain).
     // Rows past M, missing neighbours (-1) and taps past F all become -1.
-    for (int i = t; i < F_LDS * BM; i += NT) {
-        const int f = i / BM, r = i - f * BM;
-        Is[i] = (int)src_row(p, f, m0 + r);
+    // With a row permutation (vertices sorted by tap mask, hpl_tap_order) tile row r is vertex
+    // row_perm[m0 + r]: rows of one tile then miss the same taps, and a whole 32-wide slice whose
+    // taps are absent for all BM rows is skipped (no loads, no MFMAs, no barrier).
+    if (t == 0) *tapmask_s = 0;
+    for (int r = t; r < BM; r += NT) {
+        const int64_t m = m0 + r;
+        Vs[r] = (m < p.M) ? (p.row_perm ? p.row_perm[m] : (int)m) : -1;
     }
     __syncthreads();
+    {
+        int mybits = 0;
+        for (int i = t; i < F_LDS * BM; i += NT) {
+            const int f = i / BM, r = i - f * BM;
+            const int v = Vs[r];
+            const int row = (v >= 0) ? (int)src_row(p, f, v) : -1;
+            Is[i] = row;
+            mybits |= (row >= 0) ? (1 << f) : 0;
+        }
+        if (mybits) atomicOr(tapmask_s, mybits);
+    }
+    __syncthreads();
+    const int tapmask = __builtin_amdgcn_readfirstlane(*tapmask_s);
     // Buffer descriptors (wave-uniform, built from kernel arguments): 32-bit byte offsets keep the
     // per-load address arithmetic to a multiply-add, and an out-of-range offset returns zeros in
     // hardware -- that is how absent neighbours (-1), taps past F and columns past ldw read as 0.
@@ -144,7 +183,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     const bool bvalid = (n0 + bn4 * 4) < p.ldw;
     const unsigned boff0 = bvalid ? (unsigned)brow0 * ldw_b + (unsigned)(n0 + bn4 * 4) * 4u : OOB;
 
+    // (f0, c0) of the first element of the slice being loaded; advanced incrementally (wave-uniform)
+    int f0_u = 0, c0_u = 0, k_u = 0;
     auto load_regs = [&](int k0) {
+        {   // (f, c) of this thread's float4 column in the slice starting at flat index k0 >= k_u
+            c0_u += k0 - k_u;
+            k_u = k0;
+            while (c0_u >= p.C) { c0_u -= p.C; ++f0_u; }
+            c_t = c0_u + kq * 4;
+            f_t = f0_u;
+            while (c_t >= p.C) { c_t -= p.C; ++f_t; }
+        }
         if (AVEC) {
             const int fi = min(f_t, F_LDS - 1);
             int rows[A_PASSES];
@@ -177,9 +226,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
             const float4_t v = buffer_load_f32x4(rsrc_b, (int)off, 0, 0);
             rb[i] = make_float4(v.x, v.y, v.z, v.w);
         }
-        // advance (f, c) to the next slice
-        c_t += BK;
-        while (c_t >= p.C) { c_t -= p.C; ++f_t; }
     };
 
     auto store_a = [&](int buf, int i) {
@@ -211,12 +257,36 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    load_regs(0);
-    store_lds(0);
+    // Slice kt covers taps f_lo..f_hi (at most two when C >= 32); it is needed iff one of them is
+    // present for some row of the tile.  Wave 0 compacts the needed slices into Ks (ballot prefix).
+    if (wave == 0) {
+        int count = 0;
+        for (int base = 0; base < nk; base += 64) {
+            const int kt = base + lane;
+            bool need = false;
+            if (kt < nk) {
+                const int f_lo = (kt * BK) / p.C;
+                const int f_hi = min((kt * BK + BK - 1) / p.C, p.F - 1);
+                int bits = 0;
+                for (int f = f_lo; f <= f_hi; ++f) bits |= 1 << f;
+                need = (tapmask & bits) != 0;
+            }
+            const unsigned long long bal = __ballot(need);
+            if (need) Ks[count + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)kt;
+            count += __popcll(bal);
+        }
+        if (lane == 0) tapmask_s[1] = count;
+    }
+    __syncthreads();
+    const int nlist = __builtin_amdgcn_readfirstlane(tapmask_s[1]);
+    if (nlist > 0) {
+        load_regs((int)Ks[0] * BK);
+        store_lds(0);
+    }
     __syncthreads();
     int cur = 0;
     // one contraction step; MORE (compile time) = also prefetch and stage step kt+1
-    auto step = [&](int kt, auto more_tag) {
+    auto step = [&](int kt_next, auto more_tag) {
         constexpr bool more = decltype(more_tag)::value;
         const float *a = As + cur * BK * LDA_S + wm * WTM + li;
         const float *b = Bs + cur * BK * LDB_S + wn * WTN + li;
@@ -247,7 +317,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (more) {
-                if (kk == 0) load_regs((kt + 1) * BK);
+                if (kk == 0) load_regs(kt_next * BK);
                 if (kk >= 8 && kk - 8 < A_PASSES) store_a(cur ^ 1, kk - 8);
                 if (kk >= 12 && kk - 12 < B_PASSES) store_b(cur ^ 1, kk - 12);
             }
@@ -255,8 +325,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
         __syncthreads();
         cur ^= 1;
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) step(kt, std::true_type{});
-    step(nk - 1, std::false_type{});
+    for (int i = 0; i + 1 < nlist; ++i) step((int)Ks[i + 1], std::true_type{});
+    if (nlist > 0) step(-1, std::false_type{});
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -268,8 +338,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
             const float bsv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m >= p.M) continue;
+                const int64_t m = Vs[wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];   // output row
+                if (m < 0) continue;
                 float v = acc[i][j][r] + bsv;
                 if (p.res) v += p.res[(m % p.res_mod) * p.ldres + n];
                 if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
@@ -320,7 +390,8 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
                 (long long)d->M, d->C, d->F, d->N);
     HPL_REQUIRE(d->F <= 15, "%s: F=%d taps (radius > 1) not supported by the LDS-staged index table", who, d->F);
     HPL_REQUIRE(d->rows_a > 0 && d->rows_a < (int64_t)INT32_MAX, "%s: rows_a out of range", who);
-    HPL_REQUIRE((int64_t)d->F * d->C < (int64_t)INT32_MAX, "%s: contraction too long", who);
+    HPL_REQUIRE((int64_t)d->F * d->C <= 32768, "%s: contraction length F*C = %lld > 32768 (slice list in LDS)", who,
+                (long long)d->F * d->C);
     HPL_REQUIRE(d->lda >= d->C, "%s: lda %lld < C %d", who, (long long)d->lda, d->C);
     HPL_REQUIRE(d->ldw >= d->N && d->ldw % 4 == 0 && aligned16(d->Wt), "%s: ldw must be a multiple of 4 >= N and Wt 16-byte aligned", who);
     HPL_REQUIRE(d->nbr || d->F == 1 || d->reg_stride > 0, "%s: F > 1 needs a neighbour table or reg_stride", who);
@@ -335,6 +406,7 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.bias = d->bias; p.res = d->res; p.ldres = d->ldres; p.res_mod = d->res_mod;
     p.Y = d->Y; p.ldy = d->ldy;
     p.scat = d->scat; p.scat_stride = d->scat_stride; p.scat_c = d->scat_c;
+    p.row_perm = d->row_perm;
     p.tiles_m = p.tiles_n = 0;
     p.a_bytes = ((d->rows_a - 1) * d->lda + d->C) * 4;
     p.w_bytes = cdiv(p.K, 32) * 32 * d->ldw * 4;

@@ -41,6 +41,9 @@ class DeviceLattice(object):
         for lv in self.levels:
             for c in lv.clouds:
                 c.csr()
+            for tbl in list(lv.blur) + [lv.corr1]:
+                if tbl is not None:
+                    tbl.perm
         return self
 
     @staticmethod

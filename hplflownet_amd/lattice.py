@@ -79,6 +79,8 @@ class GenerateDataUnsymmetric(object):
             lv.blur = [NbrTable(b) if b is not None else None for b in blur]
             lv.emg = [emg[c].t().contiguous() for c in (0, 1)]
             lv.corr1 = NbrTable(corr1) if corr1 is not None else None
+            if lv.corr1 is not None and cc_r == bcn_r:
+                lv.corr1 = lv.blur[0]          # same offsets, same table: share it
             lv.corr2 = NbrTable(corr2) if corr2 is not None else None
             if lv.corr2 is not None:
                 lv.corr2._sym = False

@@ -80,6 +80,15 @@ class CloudTables(object):
         return self._csr
 
 
+def tap_order(nbr):
+    """int32 [F<=15, M] neighbour table -> int32 [M] permutation grouping the rows by tap-presence mask."""
+    F, M = nbr.shape
+    perm = torch.empty(M, dtype=torch.int32, device=nbr.device)
+    scratch = torch.empty(M + 2 * 32768 + 1026 + 64, dtype=torch.int32, device=nbr.device)
+    check(_lib.load().hpl_tap_order(ptr(nbr), nbr.stride(0), F, M, ptr(perm), ptr(scratch), stream()), 'hpl_tap_order')
+    return perm
+
+
 def table_is_symmetric(nbr):
     """nbr[f, h] = g  =>  nbr[(F - f) % F, g] = h  (SURVEY.md fact 7).  One host sync."""
     F, H = nbr.shape
@@ -133,8 +142,9 @@ def weight_relayout(W, R, Q, F, sr, sq, sf, base=0, fmap=None):
 
 
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
-              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE):
-    """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n])."""
+              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None):
+    """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
+    row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged."""
     A = _cl(A)
     d = GConvDesc()
     d.A, d.lda, d.rows_a = ptr(A), _ld(A), A.shape[0]
@@ -168,6 +178,10 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     _cl(out, 'out')
     d.Y, d.ldy = ptr(out), _ld(out)
+    if row_perm is not None:
+        if row_perm.dtype != torch.int32 or row_perm.numel() != M or not row_perm.is_contiguous():
+            raise _lib.HplError('row_perm must be a contiguous int32 tensor of M=%d entries' % M)
+        d.row_perm = ptr(row_perm)
     fn = _lib.load().hpl_gconv_forward_naive if naive else _lib.load().hpl_gconv_forward
     check(fn(ctypes.byref(d), stream()), 'hpl_gconv_forward')
     return out
@@ -304,7 +318,7 @@ class GConvFn(torch.autograd.Function):
 
 
 def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_mod=0, bwd_mode='scatter',
-          out=None, slope=LEAKY_RATE):
+          out=None, slope=LEAKY_RATE, row_perm=None):
     """Autograd-aware gathered convolution; with grad disabled it can write into `out`."""
     O = weight.shape[0]
     Ctot = weight.numel() // (O * F)
@@ -317,7 +331,8 @@ def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_
             return out
         return y
     Wt = _cached_relayout(weight, C, O, F, Ctot, c0)
-    return gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope)
+    return gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope,
+                     row_perm=row_perm)
 
 
 _WT_CACHE = collections.OrderedDict()

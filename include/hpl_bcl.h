@@ -142,7 +142,17 @@ typedef struct hpl_gconv_desc {
     int64_t scat_stride;
     int32_t scat_c;
     int32_t reserved;
+    /* optional permutation of the M output rows (hpl_tap_order): tile row j computes and writes
+     * output row row_perm[j]; the result is unchanged, rows of one tile share absent taps so that
+     * whole contraction slices can be skipped.  NULL = identity. */
+    const int32_t *row_perm;
 } hpl_gconv_desc;
+
+/* Row order for tap skipping: perm = the M vertices grouped by their F-bit tap-presence mask
+ * (bit f set iff nbr[f*nbr_stride + m] >= 0; F <= 15).  Order inside a group is unspecified (it
+ * does not affect results).  scratch: M + 2 * 32768 + 1026 + 64 int32. */
+int hpl_tap_order(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *perm,
+                  int32_t *scratch, hplStream stream);
 
 /* Y[m, n] = act(bias[n] + res[...] + sum_{f<F, c<C} A[nbr[f][m], c] * Wt[f*C + c, n]).
  * One call covers: the blur Conv2d((15,1)) over gathered neighbours

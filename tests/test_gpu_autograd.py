@@ -132,3 +132,40 @@ def test_splat_slice_autograd():
     assert rel_err(out.detach().cpu().numpy(), o.detach().cpu().numpy()) < 1e-5
     assert rel_err(gx.cpu().numpy(), x.grad.cpu().numpy()) < 2e-5
     assert rel_err(gb.cpu().numpy(), bias.grad.cpu().numpy()) < 2e-5
+
+
+def test_tap_order_and_row_perm_leave_results_unchanged():
+    """hpl_tap_order groups rows by tap mask; gconv with row_perm is bit-identical to without."""
+    from hplflownet_amd import ops
+    _, _, _, gd = oracle_lattice(1024)
+    nbr_np = gd[0]['pc1_blur_neighbors'].astype(np.int32)
+    nbr = torch.from_numpy(nbr_np).to(DEV)
+    F, H = nbr.shape
+    perm = ops.tap_order(nbr)
+    p = perm.cpu().numpy()
+    assert np.array_equal(np.sort(p), np.arange(H))                       # a permutation
+    mask = ((nbr_np >= 0) * (1 << np.arange(F))[:, None]).sum(0)
+    assert np.all(np.diff(mask[p]) >= 0)                                  # grouped by ascending mask
+    g = torch.Generator().manual_seed(4)
+    for C, O in ((68, 64), (132, 128)):
+        A = torch.randn(H, C, generator=g).to(DEV)
+        W = (torch.randn(O, C, F, generator=g) / 30).to(DEV)
+        bias = torch.randn(O, generator=g).to(DEV)
+        Wt = ops.weight_relayout(W, C, O, F, F, C * F, 1)
+        y0 = ops.gconv_raw(A, nbr, H, C, F, Wt, O, bias=bias, act=1)
+        y1 = ops.gconv_raw(A, nbr, H, C, F, Wt, O, bias=bias, act=1, row_perm=perm)
+        yn = ops.gconv_raw(A, nbr, H, C, F, Wt, O, bias=bias, act=1, naive=True)
+        assert torch.equal(y0, y1)
+        assert rel_err(y1.cpu().numpy(), yn.cpu().numpy()) < 1e-6
+    # a table with whole taps missing: skipped slices must not change anything
+    sparse = nbr.clone()
+    sparse[[2, 5, 9, 14]] = -1
+    A = torch.randn(H, 68, generator=g).to(DEV)
+    W = (torch.randn(64, 68, F, generator=g) / 30).to(DEV)
+    Wt = ops.weight_relayout(W, 68, 64, F, F, 68 * F, 1)
+    ys = ops.gconv_raw(A, sparse, H, 68, F, Wt, 64, row_perm=ops.tap_order(sparse))
+    yn = ops.gconv_raw(A, sparse, H, 68, F, Wt, 64, naive=True)
+    assert rel_err(ys.cpu().numpy(), yn.cpu().numpy()) < 1e-6
+    empty = torch.full_like(nbr, -1)
+    ye = ops.gconv_raw(A, empty, H, 68, F, Wt, 64, bias=torch.ones(64, device=DEV))
+    assert float((ye - 1).abs().max()) == 0.0

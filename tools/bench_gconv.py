@@ -41,3 +41,14 @@ for name, lvl, C, O, F in shapes:
     fl = 2.0 * M * F * C * O
     valid = float((tbl >= 0).float().mean()) if nbr is not None else 1.0
     print('%-12s M=%6d K=%5d N=%5d  %8.3f ms  %6.1f TFLOP/s  (valid taps %.2f)' % (name, M, F * C, O, ms, fl / ms / 1e9, valid))
+    if nbr is not None:
+        perm = ops.tap_order(nbr)
+        for nm, pm in (('  +row_perm(mask)', perm), ('  +row_perm(random)', torch.randperm(M, device=dev).to(torch.int32))):
+            ops.gconv_raw(A, nbr, M, C, F, Wt, O, out=y, row_perm=pm)
+            torch.cuda.synchronize()
+            s.record()
+            for _ in range(reps):
+                ops.gconv_raw(A, nbr, M, C, F, Wt, O, out=y, row_perm=pm)
+            e.record(); torch.cuda.synchronize()
+            ms2 = s.elapsed_time(e) / reps
+            print('%-20s %8.3f ms  %6.1f TFLOP/s (nominal)' % (nm, ms2, fl / ms2 / 1e9))
