@@ -220,14 +220,15 @@ def main():
             return flow
 
     overlap = not (a.train or a.no_lattice or a.no_overlap)
-    side = torch.cuda.Stream(device=dev) if overlap else None
+    side = torch.cuda.Stream(device=dev) if overlap else None                  # lattice builds
+    fwd_stream = torch.cuda.Stream(device=dev, priority=-1) if overlap else None   # forwards: high priority
 
     def run_pipelined(first, count):
         """count steps; the lattice of pair i+1 is built on a second HIP stream while the forward of
         pair i runs on the main stream (the reference overlaps the same two stages with DataLoader
         worker processes, main.py:85-92).  Exactly `count` lattice builds and `count` forwards."""
         import collections
-        main = torch.cuda.current_stream()
+        main = fwd_stream
 
         def build(i):
             with torch.cuda.stream(side):
@@ -242,7 +243,8 @@ def main():
             lat, ev = nxt
             main.wait_event(ev)
             p1, p2 = pairs[i % a.pool]
-            out = model(p1[None], p2[None], lat)
+            with torch.cuda.stream(main):
+                out = model(p1[None], p2[None], lat)
             fin = torch.cuda.Event()
             fin.record(main)
             keep.append((lat, out, fin))          # side-stream allocations stay alive until their forward is done

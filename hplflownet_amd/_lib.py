@@ -28,7 +28,7 @@ class GConvDesc(ctypes.Structure):
                 ('bias', c_vp), ('res', c_vp), ('ldres', c_i64), ('res_mod', c_i64),
                 ('Y', c_vp), ('ldy', c_i64),
                 ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('reserved', c_i32),
-                ('row_perm', c_vp)]
+                ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64)]
 
 
 _SIGNATURES = {

@@ -57,6 +57,8 @@ struct GParams {
     int tiles_m; int tiles_n;
     int64_t a_bytes; int64_t w_bytes;   // extents of A and Wt for the buffer descriptors
     const int32_t *row_perm;            // optional permutation of the output rows (tile row -> vertex)
+    int splits; float *partial;         // split-K over the slice list: partial[split][M][N]
+    float *ws; int64_t ws_bytes;
 };
 
 __device__ __forceinline__ int64_t src_row(const GParams &p, int f, int64_t m) {
@@ -70,8 +72,8 @@ __device__ __forceinline__ int64_t src_row(const GParams &p, int f, int64_t m) {
 // and walk tiles_n fastest inside a band of 8 tile-rows so that concurrently resident
 // workgroups of one XCD share both gathered A rows and weight panels in that L2.
 __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) {
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x % nwg;       // (split-K: grid = splits x tiles)
     const int q = nwg / 8, r = nwg % 8;
     const int xcd = bid % 8, pos = bid / 8;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // bijective
@@ -279,8 +281,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     }
     __syncthreads();
     const int nlist = __builtin_amdgcn_readfirstlane(tapmask_s[1]);
-    if (nlist > 0) {
-        load_regs((int)Ks[0] * BK);
+    // split-K (small M): this workgroup handles slices [lo, hi) of the list and writes a partial tile
+    const int split = blockIdx.x / (p.tiles_m * p.tiles_n);
+    const int lo = (int)((int64_t)nlist * split / p.splits), hi_i = (int)((int64_t)nlist * (split + 1) / p.splits);
+    if (hi_i > lo) {
+        load_regs((int)Ks[lo] * BK);
         store_lds(0);
     }
     __syncthreads();
@@ -325,8 +330,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
         __syncthreads();
         cur ^= 1;
     };
-    for (int i = 0; i + 1 < nlist; ++i) step((int)Ks[i + 1], std::true_type{});
-    if (nlist > 0) step(-1, std::false_type{});
+    for (int i = lo; i + 1 < hi_i; ++i) step((int)Ks[i + 1], std::true_type{});
+    if (hi_i > lo) step(-1, std::false_type{});
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -340,6 +345,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = Vs[wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];   // output row
                 if (m < 0) continue;
+                if (p.splits > 1) {   // raw partial sum; k_gconv_finish adds them in split order
+                    p.partial[((int64_t)split * p.M + m) * p.N + n] = acc[i][j][r];
+                    continue;
+                }
                 float v = acc[i][j][r] + bsv;
                 if (p.res) v += p.res[(m % p.res_mod) * p.ldres + n];
                 if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
@@ -352,6 +361,23 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
                 }
             }
         }
+}
+
+// split-K epilogue: Y = act(bias + res + sum_s partial[s]) in fixed split order
+__global__ void k_gconv_finish(const GParams p) {
+    const int64_t total = p.M * p.N;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int64_t m = i / p.N;
+        const int n = (int)(i - m * p.N);
+        float acc = 0.f;
+        for (int sidx = 0; sidx < p.splits; ++sidx) acc += p.partial[(int64_t)sidx * total + i];
+        float v = acc + (p.bias ? p.bias[n] : 0.f);
+        if (p.res) v += p.res[(m % p.res_mod) * p.ldres + n];
+        if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
+        p.Y[m * p.ldy + n] = v;
+    }
 }
 
 // one thread per output element; sequential fmaf chain in k order (what one MFMA lane does)
@@ -407,6 +433,7 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.Y = d->Y; p.ldy = d->ldy;
     p.scat = d->scat; p.scat_stride = d->scat_stride; p.scat_c = d->scat_c;
     p.row_perm = d->row_perm;
+    p.ws = d->ws; p.ws_bytes = d->ws ? d->ws_bytes : 0; p.splits = 1; p.partial = nullptr;
     p.tiles_m = p.tiles_n = 0;
     p.a_bytes = ((d->rows_a - 1) * d->lda + d->C) * 4;
     p.w_bytes = cdiv(p.K, 32) * 32 * d->ldw * 4;
@@ -419,7 +446,19 @@ template <int BM, int BN, int WGM, int WGN>
 void launch_cfg(GParams &p, bool avec, hipStream_t s) {
     p.tiles_m = (int)cdiv(p.M, BM);
     p.tiles_n = (int)cdiv(p.N, BN);
-    const int grid = p.tiles_m * p.tiles_n;
+    // Small M: too few tiles to fill 256 CUs and a long serial slice loop (one exposed memory
+    // latency per slice).  Split the slice list over up to 16 workgroups per tile, partial tiles
+    // go to the caller's workspace and are summed in fixed order by k_gconv_finish.
+    p.splits = 1;
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int nk = (p.K + BK - 1) / BK;
+    if (p.ws && !p.scat && tiles <= 128 && nk >= 8) {
+        int sp = (int)imin(imin(16, nk / 4), imax(1, 512 / tiles));
+        while (sp > 1 && (int64_t)sp * p.M * p.N * 4 > p.ws_bytes) --sp;
+        p.splits = sp;
+        p.partial = p.ws;
+    }
+    const int grid = tiles * p.splits;
     // F_LDS = taps whose indices are staged in LDS: 1 for dense GEMMs, 15 for the radius-1 stencil
     if (p.F == 1) {
         if (avec) k_gconv<BM, BN, WGM, WGN, true, 1><<<grid, 64 * WGM * WGN, 0, s>>>(p);
@@ -453,6 +492,10 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     } else {
         if (t128 >= 512) launch_cfg<128, 32, 4, 1>(p, avec, s);
         else launch_cfg<64, 32, 2, 1>(p, avec, s);
+    }
+    if (p.splits > 1) {
+        const int g = (int)imin(cdiv(p.M * p.N, 256), 2048);
+        k_gconv_finish<<<g, 256, 0, s>>>(p);
     }
     HPL_CHECK_LAUNCH("hpl_gconv_forward");
     return HPL_OK;

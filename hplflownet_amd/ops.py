@@ -142,7 +142,7 @@ def weight_relayout(W, R, Q, F, sr, sq, sf, base=0, fmap=None):
 
 
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
-              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None):
+              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True):
     """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
     row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged."""
     A = _cl(A)
@@ -182,9 +182,25 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
         if row_perm.dtype != torch.int32 or row_perm.numel() != M or not row_perm.is_contiguous():
             raise _lib.HplError('row_perm must be a contiguous int32 tensor of M=%d entries' % M)
         d.row_perm = ptr(row_perm)
+    if split_k and scat is None and M * N <= _SPLITK_MAX_ELEMS:
+        ws = _splitk_workspace(A.device)
+        d.ws, d.ws_bytes = ptr(ws), ws.numel() * 4
     fn = _lib.load().hpl_gconv_forward_naive if naive else _lib.load().hpl_gconv_forward
     check(fn(ctypes.byref(d), stream()), 'hpl_gconv_forward')
     return out
+
+
+_SPLITK_MAX_ELEMS = 1 << 20          # split-K only pays for small outputs (M*N <= 1M elements)
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(device):
+    """Per-(device, stream) scratch for split-K partial tiles: 16 splits x 1M floats = 64 MB."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = _SPLITK_WS[key] = torch.empty(16 * _SPLITK_MAX_ELEMS, dtype=torch.float32, device=device)
+    return ws
 
 
 def wgrad_raw(A, nbr, M, C, F, dY, N):

@@ -146,6 +146,10 @@ typedef struct hpl_gconv_desc {
      * output row row_perm[j]; the result is unchanged, rows of one tile share absent taps so that
      * whole contraction slices can be skipped.  NULL = identity. */
     const int32_t *row_perm;
+    /* optional workspace for split-K on small problems (M*N*4 bytes per split, up to 16 splits);
+     * NULL = never split.  Partial tiles are summed in a fixed order: results stay deterministic. */
+    float *ws;
+    int64_t ws_bytes;
 } hpl_gconv_desc;
 
 /* Row order for tap skipping: perm = the M vertices grouped by their F-bit tap-presence mask

@@ -152,8 +152,8 @@ def test_tap_order_and_row_perm_leave_results_unchanged():
         W = (torch.randn(O, C, F, generator=g) / 30).to(DEV)
         bias = torch.randn(O, generator=g).to(DEV)
         Wt = ops.weight_relayout(W, C, O, F, F, C * F, 1)
-        y0 = ops.gconv_raw(A, nbr, H, C, F, Wt, O, bias=bias, act=1)
-        y1 = ops.gconv_raw(A, nbr, H, C, F, Wt, O, bias=bias, act=1, row_perm=perm)
+        y0 = ops.gconv_raw(A, nbr, H, C, F, Wt, O, bias=bias, act=1, split_k=False)
+        y1 = ops.gconv_raw(A, nbr, H, C, F, Wt, O, bias=bias, act=1, row_perm=perm, split_k=False)
         yn = ops.gconv_raw(A, nbr, H, C, F, Wt, O, bias=bias, act=1, naive=True)
         assert torch.equal(y0, y1)
         assert rel_err(y1.cpu().numpy(), yn.cpu().numpy()) < 1e-6

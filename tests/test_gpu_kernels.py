@@ -150,8 +150,11 @@ def test_gconv_forward(ops, case):
         want = _gconv_ref(A, nbr, M, C, F, W, bias, res, res_mod, act)
         assert rel_err(yn, want) < 1e-5
         assert rel_err(y, want) < 1e-5
-    # the MFMA is a k-ordered fmaf chain like the naive kernel: expect (near) bit equality
-    assert rel_err(y, yn) < 1e-6
+    # the MFMA is a k-ordered fmaf chain like the naive kernel: expect (near) bit equality -- unless the
+    # slice list was split over workgroups (small problems), which re-associates the sum
+    y1 = ops.gconv_raw(dev(A), dev(nbr) if table else None, M, C, F, Wt, O, split_k=False, **args).cpu().numpy()
+    assert rel_err(y1, yn) < 1e-6
+    assert rel_err(y, yn) < 1e-5
     # determinism: same launch twice, bit-identical
     y2 = ops.gconv_raw(dev(A), dev(nbr) if table else None, M, C, F, Wt, O, **args).cpu().numpy()
     assert np.array_equal(y, y2)
