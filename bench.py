@@ -34,7 +34,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s measured copy)
 
 
-def gconv_class(M, N):
+def gconv_class(M, N, K=1 << 20):
     """Mirror of the tile selection in csrc/gconv.hip (hpl_gconv_forward)."""
     t128, t64 = (M + 127) // 128, (M + 63) // 64
     if N > 64:
@@ -73,7 +73,7 @@ class KernelTimers(object):
 
         def d_gconv(A, nbr, M, C, F, Wt, N, **k):
             # suffix: g = gathered (15-tap stencil, template F_LDS=15), d = dense (F_LDS=1)
-            return ('gconv_%s_%s' % (gconv_class(M, N), 'g' if F > 1 else 'd'), 2.0 * M * F * C * N, 0.0)
+            return ('gconv_%s_%s' % (gconv_class(M, N, F * C), 'g' if F > 1 else 'd'), 2.0 * M * F * C * N, 0.0)
 
         def d_splat(feat, csr, H, use_norm=True, out=None):
             N, C = feat.shape

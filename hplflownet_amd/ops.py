@@ -7,6 +7,7 @@ row stride may exceed the channel count: column slices of wider buffers are fine
 """
 import collections
 import ctypes
+import os
 
 import torch
 
@@ -182,7 +183,7 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
         if row_perm.dtype != torch.int32 or row_perm.numel() != M or not row_perm.is_contiguous():
             raise _lib.HplError('row_perm must be a contiguous int32 tensor of M=%d entries' % M)
         d.row_perm = ptr(row_perm)
-    if split_k and scat is None and M * N <= _SPLITK_MAX_ELEMS:
+    if split_k and not _NO_SPLITK and scat is None and M * N <= _SPLITK_MAX_ELEMS:
         ws = _splitk_workspace(A.device)
         d.ws, d.ws_bytes = ptr(ws), ws.numel() * 4
     fn = _lib.load().hpl_gconv_forward_naive if naive else _lib.load().hpl_gconv_forward
@@ -190,8 +191,9 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
     return out
 
 
-_SPLITK_MAX_ELEMS = 1 << 20          # split-K only pays for small outputs (M*N <= 1M elements)
+_SPLITK_MAX_ELEMS = 1 << 20          # split-K only pays for small outputs (M*N <= 1M elements; measured)
 _SPLITK_WS = {}
+_NO_SPLITK = bool(os.environ.get('HPL_NO_SPLITK'))      # A/B switch for benchmarking
 
 
 def _splitk_workspace(device):
@@ -199,7 +201,7 @@ def _splitk_workspace(device):
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _SPLITK_WS.get(key)
     if ws is None:
-        ws = _SPLITK_WS[key] = torch.empty(16 * _SPLITK_MAX_ELEMS, dtype=torch.float32, device=device)
+        ws = _SPLITK_WS[key] = torch.empty(16 << 20, dtype=torch.float32, device=device)
     return ws
 
 
