@@ -187,47 +187,55 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
 
     // (f0, c0) of the first element of the slice being loaded; advanced incrementally (wave-uniform)
     int f0_u = 0, c0_u = 0, k_u = 0;
-    auto load_regs = [&](int k0) {
-        {   // (f, c) of this thread's float4 column in the slice starting at flat index k0 >= k_u
-            c0_u += k0 - k_u;
-            k_u = k0;
-            while (c0_u >= p.C) { c0_u -= p.C; ++f0_u; }
-            c_t = c0_u + kq * 4;
-            f_t = f0_u;
-            while (c_t >= p.C) { c_t -= p.C; ++f_t; }
-        }
+    // The prefetch of the next slice is cut into small pieces that are dropped between the MFMA
+    // groups of the current slice (each 4-MFMA group shadows ~256 cycles of other issue):
+    //   load_begin: (f, c) bookkeeping + LDS reads of the 4 row indices
+    //   load_a(i):  one gathered row slice (buffer_load_dwordx4)    load_b(i): one weight row slice
+    int rows_n[A_PASSES];
+    int k0_n = 0;
+    auto load_begin = [&](int k0) {
+        k0_n = k0;
+        c0_u += k0 - k_u;       // (f, c) of this thread's float4 column in the slice starting at k0 >= k_u
+        k_u = k0;
+        while (c0_u >= p.C) { c0_u -= p.C; ++f0_u; }
+        c_t = c0_u + kq * 4;
+        f_t = f0_u;
+        while (c_t >= p.C) { c_t -= p.C; ++f_t; }
         if (AVEC) {
             const int fi = min(f_t, F_LDS - 1);
-            int rows[A_PASSES];
 #pragma unroll
-            for (int i = 0; i < A_PASSES; ++i) rows[i] = Is[fi * BM + arow0 + i * A_ROWS_PER_PASS];
-#pragma unroll
-            for (int i = 0; i < A_PASSES; ++i) {
-                const bool ok = (f_t < p.F) && (rows[i] >= 0);
-                const unsigned off = ok ? (unsigned)rows[i] * lda_b + (unsigned)c_t * 4u : OOB;
-                const float4_t v = buffer_load_f32x4(rsrc_a, (int)off, 0, 0);
-                ra[i] = make_float4(v.x, v.y, v.z, v.w);
-            }
+            for (int i = 0; i < A_PASSES; ++i) rows_n[i] = Is[fi * BM + arow0 + i * A_ROWS_PER_PASS];
+        }
+    };
+    auto load_a = [&](int i) {
+        if (AVEC) {
+            const bool ok = (f_t < p.F) && (rows_n[i] >= 0);
+            const unsigned off = ok ? (unsigned)rows_n[i] * lda_b + (unsigned)c_t * 4u : OOB;
+            const float4_t v = buffer_load_f32x4(rsrc_a, (int)off, 0, 0);
+            ra[i] = make_float4(v.x, v.y, v.z, v.w);
         } else {   // generic path: any C / alignment, element by element
+            float e[4];
 #pragma unroll
-            for (int i = 0; i < A_PASSES; ++i) {
-                float e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = k0 + kq * 4 + j;
-                    const int f = k / p.C, c = k - f * p.C;
-                    const int row = (f < p.F) ? Is[min(f, F_LDS - 1) * BM + arow0 + i * A_ROWS_PER_PASS] : -1;
-                    e[j] = (row >= 0) ? p.A[(int64_t)row * p.lda + c] : 0.f;
-                }
-                ra[i] = make_float4(e[0], e[1], e[2], e[3]);
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0_n + kq * 4 + j;
+                const int f = k / p.C, c = k - f * p.C;
+                const int row = (f < p.F) ? Is[min(f, F_LDS - 1) * BM + arow0 + i * A_ROWS_PER_PASS] : -1;
+                e[j] = (row >= 0) ? p.A[(int64_t)row * p.lda + c] : 0.f;
             }
+            ra[i] = make_float4(e[0], e[1], e[2], e[3]);
         }
+    };
+    auto load_b = [&](int i) {
+        const unsigned off = bvalid ? boff0 + (unsigned)(k0_n + i * B_ROWS_PER_PASS) * ldw_b : OOB;
+        const float4_t v = buffer_load_f32x4(rsrc_b, (int)off, 0, 0);
+        rb[i] = make_float4(v.x, v.y, v.z, v.w);
+    };
+    auto load_regs = [&](int k0) {
+        load_begin(k0);
 #pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) {
-            const unsigned off = bvalid ? boff0 + (unsigned)(k0 + i * B_ROWS_PER_PASS) * ldw_b : OOB;
-            const float4_t v = buffer_load_f32x4(rsrc_b, (int)off, 0, 0);
-            rb[i] = make_float4(v.x, v.y, v.z, v.w);
-        }
+        for (int i = 0; i < A_PASSES; ++i) load_a(i);
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) load_b(i);
     };
 
     auto store_a = [&](int buf, int i) {
@@ -322,9 +330,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (more) {
-                if (kk == 0) load_regs(kt_next * BK);
-                if (kk >= 8 && kk - 8 < A_PASSES) store_a(cur ^ 1, kk - 8);
-                if (kk >= 12 && kk - 12 < B_PASSES) store_b(cur ^ 1, kk - 12);
+                if (kk == 0) load_begin(kt_next * BK);
+                if (kk >= 1 && kk - 1 < A_PASSES) load_a(kk - 1);
+                if (kk >= 5 && kk - 5 < B_PASSES) load_b(kk - 5);
+                if (kk >= 10 && kk - 10 < A_PASSES) store_a(cur ^ 1, kk - 10);
+                if (kk == 14) {
+#pragma unroll
+                    for (int i = 0; i < B_PASSES; i += 2) store_b(cur ^ 1, i);
+                }
+                if (kk == 15) {
+#pragma unroll
+                    for (int i = 1; i < B_PASSES; i += 2) store_b(cur ^ 1, i);
+                }
             }
         }
         __syncthreads();
