@@ -167,13 +167,24 @@ __global__ void __launch_bounds__(256) k_scan_final(const int32_t *__restrict__ 
     int v[4], s = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { v[j] = (i0 + j < n) ? in[i0 + j] : 0; s += v[j]; }
-    int run = block_exclusive_scan_256(s, nullptr) + block_sums[blockIdx.x];
+    // offset of this block = sum of the block sums before it (<= 1024 of them: summed here, in
+    // every block, instead of a separate single-block scan launch)
+    __shared__ int boff_s;
+    {
+        int part = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_sums[b];
+        int tot;
+        block_exclusive_scan_256(part, &tot);
+        if (threadIdx.x == 0) boff_s = tot;
+        __syncthreads();
+    }
+    int run = block_exclusive_scan_256(s, nullptr) + boff_s;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (i0 + j < n) out[i0 + j] = run;
         run += v[j];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_sums[nb];
+    if (blockIdx.x == (unsigned)(nb - 1) && threadIdx.x == 0) out[n] = boff_s + block_sums[nb - 1];
 }
 
 __global__ void k_csr_fill(const int32_t *__restrict__ off, int64_t n_entries, int64_t H,
@@ -272,17 +283,22 @@ extern "C" int hpl_transpose(const float *src, int64_t lds, float *dst, int64_t 
 }
 
 // ---------------------------------------------------------------- column sums
-// out[n] = sum_m X[m*ld + n].  Two-stage: each block sums a slab of rows into LDS partials,
-// then one atomicAdd per (block, column).  `out` must be zeroed by the launcher.
-__global__ void k_colsum(const float *__restrict__ X, int64_t ld, int64_t M, int N, int64_t rows_per_block,
-                         float *__restrict__ out) {
+// out[n] = sum_m X[m*ld + n].  A 256-thread group covers 64 columns (one 256-byte row segment per
+// wave) x a slab of rows: 4 row lanes per column, LDS combine, one atomicAdd per (group, column).
+// `out` is zeroed by the launcher.
+__global__ void __launch_bounds__(256) k_colsum(const float *__restrict__ X, int64_t ld, int64_t M, int N,
+                                                int64_t rows_per_block, float *__restrict__ out) {
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int n = blockIdx.y * 64 + cx;
     const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t m1 = imin(M, m0 + rows_per_block);
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        float s = 0.f;
-        for (int64_t m = m0; m < m1; ++m) s += X[m * ld + n];
-        atomicAdd(&out[n], s);
-    }
+    float s = 0.f;
+    if (n < N)
+        for (int64_t m = m0 + ry; m < m1; m += 4) s += X[m * ld + n];
+    part[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && n < N) atomicAdd(&out[n], (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]));
 }
 
 __global__ void k_zero_f32(float *p, int64_t n) {
@@ -295,9 +311,8 @@ extern "C" int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *o
     hipStream_t s = to_stream(stream);
     k_zero_f32<<<(int)cdiv(N, 256), 256, 0, s>>>(out, N);
     if (M > 0) {
-        int64_t rpb = 64;
-        int threads = N >= 256 ? 256 : (int)(cdiv(N, 64) * 64);
-        k_colsum<<<(int)cdiv(M, rpb), threads, 0, s>>>(X, ld, M, N, rpb, out);
+        const int64_t rpb = 256;
+        k_colsum<<<dim3((unsigned)cdiv(M, rpb), (unsigned)cdiv(N, 64)), 256, 0, s>>>(X, ld, M, N, rpb, out);
     }
     HPL_CHECK_LAUNCH("hpl_colsum");
     return HPL_OK;
@@ -334,7 +349,6 @@ int exclusive_scan_i32(const int32_t *cnt, int64_t n, int32_t *ptr, int32_t *tmp
     const int64_t nb = cdiv(n, SCAN_BLOCK);
     HPL_REQUIRE(nb >= 1 && nb <= 1024, "exclusive_scan_i32: n=%lld out of range", (long long)n);
     k_scan_sums<<<(int)nb, 256, 0, s>>>(cnt, n, tmp);
-    k_scan_top<<<1, 256, 0, s>>>(tmp, (int)nb);
     k_scan_final<<<(int)nb, 256, 0, s>>>(cnt, n, tmp, (int)nb, ptr);
     HPL_CHECK_LAUNCH("exclusive_scan_i32");
     return HPL_OK;

@@ -279,12 +279,14 @@ class GConvFn(torch.autograd.Function):
               'scatter' (any table: fp32 atomics), 'dense' (no table)."""
 
     @staticmethod
-    def forward(ctx, A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope):
+    def forward(ctx, A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm=None):
         O = weight.shape[0]
         Ctot = weight.numel() // (O * F)
         Wt = weight_relayout(weight, C, O, F, F, Ctot * F, 1, base=c0 * F)
-        Y = gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=act, res=res, res_mod=res_mod, slope=slope)
+        Y = gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=act, res=res, res_mod=res_mod, slope=slope,
+                      row_perm=row_perm)
         ctx.slope = slope
+        ctx.row_perm = row_perm      # same table in the mirror backward -> same tap masks -> same order
         ctx.save_for_backward(A, weight, nbr, Y if act != ACT_NONE else None)
         ctx.cfg = (M, c0, C, F, act, res is not None, res_mod, bwd_mode, bias is not None, Ctot)
         return Y
@@ -308,7 +310,7 @@ class GConvFn(torch.autograd.Function):
                     raise _lib.HplError('mirror backward needs a table over the same vertex set')
                 WtT = weight_relayout(weight, O, C, F, Ctot * F, F, 1, base=c0 * F,
                                       fmap=_mirror_map(F, weight.device))
-                gA_c = gconv_raw(g, nbr, M, O, F, WtT, C)
+                gA_c = gconv_raw(g, nbr, M, O, F, WtT, C, row_perm=ctx.row_perm)
             else:   # scatter: G[m, (f, c)] = g[m] . W[:, c, f], added into row nbr[f, m]
                 # columns ordered (f, c): source element (o, f*C + c) = W[o, c0 + c, f]
                 Wcols = weight.view(O, Ctot, F)[:, c0:c0 + C, :].permute(0, 2, 1).reshape(O, F * C).contiguous()
@@ -332,7 +334,7 @@ class GConvFn(torch.autograd.Function):
                 gres = g.view(M // res_mod, res_mod, O).sum(dim=0)
             else:
                 gres = g
-        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None
+        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None, None
 
 
 def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_mod=0, bwd_mode='scatter',
@@ -343,7 +345,7 @@ def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_
     C = Ctot if C is None else C
     if torch.is_grad_enabled() and (A.requires_grad or weight.requires_grad or
                                     (res is not None and res.requires_grad)):
-        y = GConvFn.apply(A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope)
+        y = GConvFn.apply(A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm)
         if out is not None:
             out.copy_(y)
             return out
