@@ -17,6 +17,7 @@
 // Roofline: MFMA fp32 (157.3 TFLOP/s); flops = 2*M*F*C*N.
 #include "common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 using namespace hpl;
@@ -57,6 +58,7 @@ struct GParams {
     int tiles_m; int tiles_n;
     int64_t a_bytes; int64_t w_bytes;   // extents of A and Wt for the buffer descriptors
     const int32_t *row_perm;            // optional permutation of the output rows (tile row -> vertex)
+    int perm_chunk;                     // tile-rows per XCD chunk in permuted launches
     int splits; float *partial;         // split-K over the slice list: partial[split][M][N]
     float *ws; int64_t ws_bytes;
 };
@@ -79,18 +81,37 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // bijective
     if (p.row_perm) {
         // Rows are sorted by tap mask: tile-rows differ in work (few taps ... all taps) and have no
-        // spatial coherence.  Deal the tile-rows round-robin over the XCDs, heaviest (last in the
-        // sort) first, and keep the column tiles of one tile-row adjacent so that they share its
-        // gathered rows in that XCD's L2.
-        int s = id / p.tiles_n;             // position in the XCD-major sequence of tile-rows
-        tn = id - s * p.tiles_n;
+        // spatial coherence.  Tile-rows are dealt to the 8 XCDs in chunks of PERM_CHUNK consecutive
+        // (= similar mask, similar slice list) tile-rows, heaviest chunk first, in snake order
+        // (0..7, 7..0, ...) so that XCDs finish together; the co-resident workgroups of an XCD then
+        // walk nearly the same slices and share weight panels in its L2, and the column tiles of
+        // one tile-row stay adjacent and share its gathered rows.
+        const int G = p.perm_chunk;
+        const int T = p.tiles_m;
+        const int nchunks = (T + G - 1) / G;
+        auto chunk_rows = [&](int c) { return min(G, T - c * G); };
+        auto chunk_of = [&](int x, int r) { return r * 8 + ((r & 1) ? 7 - x : x); };   // round r of XCD x
+        int sq = id / p.tiles_n;            // position in the XCD-major sequence of tile-rows
+        tn = id - sq * p.tiles_n;
         int x = 0;
         for (; x < 8; ++x) {
-            const int rows_x = (p.tiles_m - x + 7) / 8;
-            if (s < rows_x) break;
-            s -= rows_x;
+            int rows_x = 0;
+            for (int r = 0; r * 8 < nchunks; ++r) {      // rounds that contain at least one chunk
+                const int c = chunk_of(x, r);
+                if (c < nchunks) rows_x += chunk_rows(c);
+            }
+            if (sq < rows_x) break;
+            sq -= rows_x;
         }
-        tm = p.tiles_m - 1 - (s * 8 + x);
+        int row = 0;
+        for (int r = 0;; ++r) {
+            const int c = chunk_of(x, r);
+            if (c >= nchunks) continue;
+            const int n = chunk_rows(c);
+            if (sq < n) { row = c * G + sq; break; }
+            sq -= n;
+        }
+        tm = T - 1 - row;
         return;
     }
     constexpr int BAND = 8;
@@ -450,6 +471,11 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.Y = d->Y; p.ldy = d->ldy;
     p.scat = d->scat; p.scat_stride = d->scat_stride; p.scat_c = d->scat_c;
     p.row_perm = d->row_perm;
+    {
+        const char *e = getenv("HPL_PERM_CHUNK");
+        p.perm_chunk = e ? atoi(e) : 2;      // measured on bcn1_/bcn2_: 1: 3.06/1.56 ms, 2: 2.90/1.41, 4: 2.94/1.49, 8: 3.40/1.48
+        if (p.perm_chunk < 1) p.perm_chunk = 1;
+    }
     p.ws = d->ws; p.ws_bytes = d->ws ? d->ws_bytes : 0; p.splits = 1; p.partial = nullptr;
     p.tiles_m = p.tiles_n = 0;
     p.a_bytes = ((d->rows_a - 1) * d->lda + d->C) * 4;
