@@ -241,8 +241,10 @@ def main():
             return flow
 
     overlap = not (a.train or a.no_lattice or a.no_overlap)
-    side = torch.cuda.Stream(device=dev) if overlap else None                  # lattice builds
-    fwd_stream = torch.cuda.Stream(device=dev, priority=-1) if overlap else None   # forwards: high priority
+    # HPL_PRIO: which stream gets the high hardware-queue priority ('lattice' | 'forward' | 'none')
+    prio = os.environ.get('HPL_PRIO', 'lattice')
+    side = torch.cuda.Stream(device=dev, priority=-1 if prio == 'lattice' else 0) if overlap else None
+    fwd_stream = torch.cuda.Stream(device=dev, priority=-1 if prio == 'forward' else 0) if overlap else None
 
     def run_pipelined(first, count):
         """count steps; the lattice of pair i+1 is built on a second HIP stream while the forward of
