@@ -47,6 +47,9 @@ def gconv_class(M, N, K=1 << 20):
     return '128x32' if t128 >= 512 else '64x32'
 
 
+DOMINANT = 'gconv_128x128_g'
+
+
 class KernelTimers(object):
     """HIP events around every launch of the hot kernels (torch's current stream is the stream
     the C ABI launches on), aggregated per kernel class."""
@@ -55,12 +58,15 @@ class KernelTimers(object):
         self.ops = ops
         self.records = []
         self.enabled = False
+        self.only = None           # set of class names to time (None = all); events cost host time
         self._orig = (ops.gconv_raw, ops.splat_raw, ops.slice_raw)
         timers = self
 
         def wrap(fn, describe):
             def inner(*a, **k):
                 if not timers.enabled:
+                    return fn(*a, **k)
+                if timers.only is not None and describe(*a, **k)[0] not in timers.only:
                     return fn(*a, **k)
                 s = torch.cuda.Event(enable_timing=True)
                 e = torch.cuda.Event(enable_timing=True)
@@ -88,6 +94,8 @@ class KernelTimers(object):
         ops.slice_raw = wrap(ops.slice_raw, d_slice)
 
     def summary(self, steps):
+        if not self.records:
+            return {}
         agg = {}
         for (name, flops, nbytes), s, e in self.records:
             a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
@@ -254,10 +262,12 @@ def main():
         main = fwd_stream
 
         def build(i):
+            t = time.perf_counter()
             with torch.cuda.stream(side):
                 lat = gen.build(*pairs[i % a.pool]).prepare()
                 ev = torch.cuda.Event()
                 ev.record(side)
+            host['lattice_build_ms'] += (time.perf_counter() - t) * 1e3
             return lat, ev
         keep = collections.deque()
         nxt = build(first)
@@ -266,8 +276,10 @@ def main():
             lat, ev = nxt
             main.wait_event(ev)
             p1, p2 = pairs[i % a.pool]
+            t = time.perf_counter()
             with torch.cuda.stream(main):
                 out = model(p1[None], p2[None], lat)
+            host['forward_enqueue_ms'] += (time.perf_counter() - t) * 1e3
             fin = torch.cuda.Event()
             fin.record(main)
             keep.append((lat, out, fin))          # side-stream allocations stay alive until their forward is done
@@ -278,6 +290,7 @@ def main():
                 keep.popleft()
         return out
 
+    host = {'lattice_build_ms': 0.0, 'forward_enqueue_ms': 0.0}     # host wall time inside the timed loop
     with torch.set_grad_enabled(a.train):
         if overlap:
             run_pipelined(0, a.warmup)
@@ -286,6 +299,8 @@ def main():
                 step(i)
         sync_all()
         timers.enabled = True
+        timers.only = {DOMINANT}
+        host = dict.fromkeys(host, 0.0)
         t0 = time.perf_counter()
         if overlap:
             y = run_pipelined(a.warmup, a.steps)
@@ -298,9 +313,20 @@ def main():
         parallel.barrier()
         elapsed = parallel.max_over_ranks(elapsed, device=dev)
 
+    dom = timers.summary(a.steps).get(DOMINANT, {})
+    # per-kernel detail: a separate, untimed, non-overlapped pass (an event pair around each of the
+    # ~130 launches costs ~1.5 ms of host time per step, which the timed loop does not pay)
+    detail_steps = min(a.steps, 10)
+    timers.records = []
+    timers.only = None
+    timers.enabled = True
+    with torch.set_grad_enabled(a.train):
+        for i in range(detail_steps):
+            step(i)
+    torch.cuda.synchronize()
+    timers.enabled = False
+    kernels = timers.summary(detail_steps)
     if rank == 0:
-        kernels = timers.summary(a.steps)
-        dom = kernels.get('gconv_128x128_g', {})
         roofline = {'bound': 'mfma', 'achieved': dom.get('achieved'), 'peak': MFMA_F32_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': dom.get('frac'), 'traffic': None,
                     'kernel': 'k_gconv<128,128,2,2,true,15> (fp32-MFMA gather-GEMM, 15-tap stencil: blur convs of bcn1_/bcn2_)',
@@ -331,7 +357,8 @@ def main():
                            'lattice_overlapped_on_second_stream': bool(overlap),
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
-                'roofline': roofline, 'kernels': kernels}
+                'roofline': roofline, 'kernels': kernels,
+                'host_ms_per_step': {k: v / a.steps for k, v in host.items()} if overlap else None}
         if world == 1 and not a.no_cpu_baseline and not a.train:
             p1, p2, sf = pairs_np[0]
             base, flow_cpu, epe_cpu = cpu_baseline(p1, p2, sf, SCALES_FILTER_MAP, state)
