@@ -329,7 +329,7 @@ def main():
     if rank == 0:
         roofline = {'bound': 'mfma', 'achieved': dom.get('achieved'), 'peak': MFMA_F32_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': dom.get('frac'), 'traffic': None,
-                    'kernel': 'k_gconv<128,128,2,2,true,15> (fp32-MFMA gather-GEMM, 15-tap stencil: blur convs of bcn1_/bcn2_)',
+                    'kernel': 'k_gconv<128,128,2,4,true,15> (fp32-MFMA gather-GEMM, 15-tap stencil: blur convs of bcn1_/bcn2_)',
                     'measured_mfma_ceiling': ceiling,
                     'launches_per_step': dom.get('launches_per_step'), 'avg_launch_us': dom.get('avg_launch_us'),
                     'gflop_per_step': dom.get('gflop_per_step')}
