@@ -9,7 +9,7 @@ configuration ("point-pairs/sec + EPE3D, N=8192").  Pairs shard over GPUs as ind
 `--gpus N` is weak scaling: every rank runs K steps on its own pairs, value = N*K / max-rank time.
 
 Printed JSON (rank 0, one line): the contract fields plus
-  roofline      dominant kernel (fp32-MFMA gather-GEMM, 128x128 tiles): algorithmic flops of its
+  roofline      dominant kernel (fp32-MFMA gather-GEMM, 64x128 tiles, 8 waves): algorithmic flops of its
                 launches / their HIP-event time, measured inside the timed region;
   kernels       per-kernel-class breakdown (gather-GEMM classes by MFMA roofline, splat / slice by
                 HBM roofline with the algorithmic bytes of SURVEY.md §8 d2);
@@ -39,15 +39,13 @@ def gconv_class(M, N, K=1 << 20):
     t128, t64 = (M + 127) // 128, (M + 63) // 64
     if N > 64:
         tn = (N + 127) // 128
-        if t128 * tn >= 448:
-            return '128x128'
-        return '64x128' if (t64 * tn >= 448 or N > 128) else '64x64'
+        return '64x128' if t64 * tn >= 512 else '64x64'
     if N > 32:
         return '128x64' if t128 >= 512 else '64x64'
     return '128x32' if t128 >= 512 else '64x32'
 
 
-DOMINANT = 'gconv_128x128_g'
+DOMINANT = 'gconv_64x128_g'
 
 
 class KernelTimers(object):
@@ -135,7 +133,7 @@ def mfma_ceiling(dev):
     return best
 
 
-def needed_slice_fraction(tbl, C, BM=128, BK=32):
+def needed_slice_fraction(tbl, C, BM=64, BK=32):
     """Fraction of (tile, 32-wide contraction slice) pairs the gather-GEMM executes for neighbour
     table `tbl` (NbrTable) after tap-mask row sorting: mirrors the slice list built per tile in
     csrc/gconv.hip (a slice is skipped when its taps are absent for all BM rows of the tile)."""
@@ -329,14 +327,14 @@ def main():
     if rank == 0:
         roofline = {'bound': 'mfma', 'achieved': dom.get('achieved'), 'peak': MFMA_F32_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': dom.get('frac'), 'traffic': None,
-                    'kernel': 'k_gconv<128,128,2,4,true,15> (fp32-MFMA gather-GEMM, 15-tap stencil: blur convs of bcn1_/bcn2_)',
+                    'kernel': 'k_gconv<64,128,2,4,true,15> (fp32-MFMA gather-GEMM, 15-tap stencil: blur convs of bcn1_/bcn2_)',
                     'measured_mfma_ceiling': ceiling,
                     'launches_per_step': dom.get('launches_per_step'), 'avg_launch_us': dom.get('avg_launch_us'),
                     'gflop_per_step': dom.get('gflop_per_step')}
         # how much of the algorithmic work the dominant kernel really executes (absent taps are skipped)
         lat0 = gen.build(*pairs[0])
         fl = [2.0 * lat0.levels[L].H[0] * 15 * c * o for L, c, o in ((0, 580, 1024), (1, 324, 512))]
-        fr = [needed_slice_fraction(lat0.levels[L].blur[0], c) for L, c in ((0, 580), (1, 324))]
+        fr = [needed_slice_fraction(lat0.levels[L].blur[0], c, BM=64) for L, c in ((0, 580), (1, 324))]
         roofline['executed_fraction'] = (fl[0] * fr[0] + fl[1] * fr[1]) / (fl[0] + fl[1])
         roofline['achieved_executed'] = (roofline['achieved'] or 0.0) * roofline['executed_fraction']
         roofline['note'] = ('achieved = algorithmic flops (2*H*15*C_in*C_out, what the reference multiplies) / time; '
@@ -344,7 +342,7 @@ def main():
         prof = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(prof):
             try:
-                roofline['traffic'] = json.load(open(prof)).get('k_gconv_128x128_bytes_per_launch')
+                roofline['traffic'] = json.load(open(prof)).get('k_gconv_64x128_bytes_per_launch')
             except Exception:
                 pass
         line = {'metric': 'point-pairs/sec + EPE3D, N=8192 FlyingThings3D, 1/2/4/8 MI355X',

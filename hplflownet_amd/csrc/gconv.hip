@@ -16,6 +16,8 @@
 //
 // Roofline: MFMA fp32 (157.3 TFLOP/s); flops = 2*M*F*C*N.
 #include "common.h"
+#include <cstdlib>
+#include <string>
 
 #include <stdlib.h>
 #include <type_traits>
@@ -473,7 +475,7 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.row_perm = d->row_perm;
     {
         const char *e = getenv("HPL_PERM_CHUNK");
-        p.perm_chunk = e ? atoi(e) : 2;      // measured on bcn1_/bcn2_: 1: 3.06/1.56 ms, 2: 2.90/1.41, 4: 2.94/1.49, 8: 3.40/1.48
+        p.perm_chunk = e ? atoi(e) : 4;      // measured on bcn1_/bcn2_ (64-row tiles): 1: 2.61/1.33 ms, 2: 2.73/1.31, 4: 2.62/1.26, 8: 2.66/1.26, 16: 2.96/1.27
         if (p.perm_chunk < 1) p.perm_chunk = 1;
     }
     p.ws = d->ws; p.ws_bytes = d->ws ? d->ws_bytes : 0; p.splits = 1; p.partial = nullptr;
@@ -521,16 +523,29 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     if (p.M == 0) return HPL_OK;
     hipStream_t s = to_stream(stream);
     const bool avec = (p.C % 4 == 0) && (p.lda % 4 == 0) && aligned16(p.A);
-    // Tile selection.  The chip holds 512 workgroups of the 128x128 kernel (2 per CU): prefer the
-    // largest tile that still yields >= ~512 tiles, otherwise shrink BM first (keeps weight reuse).
+    // Tile selection.
     const int64_t t128 = cdiv(p.M, 128), t64 = cdiv(p.M, 64);
-    if (p.N > 64) {
+    // HPL_TILE=<name>: force one tile configuration (tools/bench_gconv.py sweeps them)
+    static const char *force = getenv("HPL_TILE");
+    if (force && *force) {
+        const std::string f(force);
+        if (f == "128x128") launch_cfg<128, 128, 2, 4>(p, avec, s);
+        else if (f == "128x128w4") launch_cfg<128, 128, 2, 2>(p, avec, s);
+        else if (f == "64x128") launch_cfg<64, 128, 2, 2>(p, avec, s);
+        else if (f == "64x128w8") launch_cfg<64, 128, 2, 4>(p, avec, s);
+        else if (f == "128x64") launch_cfg<128, 64, 2, 2>(p, avec, s);
+        else if (f == "128x64w8") launch_cfg<128, 64, 4, 2>(p, avec, s);
+        else if (f == "64x64") launch_cfg<64, 64, 2, 2>(p, avec, s);
+        else if (f == "128x32") launch_cfg<128, 32, 4, 1>(p, avec, s);
+        else if (f == "64x32") launch_cfg<64, 32, 2, 1>(p, avec, s);
+        else { set_error("hpl_gconv_forward: unknown HPL_TILE '%s'", force); return HPL_EINVAL; }
+    } else if (p.N > 64) {
+        // Measured on the model's shapes (tools/bench_gconv.py, HPL_TILE sweep): 4 waves per SIMD beat
+        // bigger tiles everywhere -- 64x128 with 8 waves (2 workgroups per CU) when it yields >= 512
+        // tiles, else 64x64 with 4 waves (4 workgroups per CU); 64-row tiles also skip more absent
+        // taps than 128-row tiles (58.6 % vs 62.5 % of the slices executed on bcn1_).
         const int64_t tn = cdiv(p.N, 128);
-        // 128x128: 8 waves (2x4, 64x32 per wave) -> 4 waves/SIMD with 2 workgroups per CU; measured
-        // 3 % faster than 4 waves of 64x64 on the dominant launches (more waves hide the barrier
-        // and LDS-read bubbles; operand reads from LDS stay far below its bandwidth)
-        if (t128 * tn >= 448) launch_cfg<128, 128, 2, 4>(p, avec, s);
-        else if (t64 * tn >= 448 || p.N > 128) launch_cfg<64, 128, 2, 2>(p, avec, s);
+        if (t64 * tn >= 512) launch_cfg<64, 128, 2, 4>(p, avec, s);
         else launch_cfg<64, 64, 2, 2>(p, avec, s);
     } else if (p.N > 32) {
         if (t128 >= 512) launch_cfg<128, 64, 2, 2>(p, avec, s);

@@ -17,16 +17,24 @@ shapes = [  # name, level, C_in, C_out, F
     ('bcn1_ blur', 0, 580, 1024, 15), ('bcn1_ 1x1', 0, 1024, 1024, 1),
     ('bcn2_ blur', 1, 324, 512, 15), ('bcn2_ 1x1', 1, 512, 512, 1),
     ('bcn3_ blur', 2, 388, 256, 15), ('bcn1 blur', 0, 68, 64, 15), ('bcn2 blur', 1, 68, 64, 15),
-    ('conv2', -1, 1024, 1024, 1),
+    ('conv2', -1, 1024, 1024, 1), ('conv3', -1, 1024, 512, 1),
+    ('bcn4_ blur', 3, 260, 256, 15), ('corr1 B-term', -2, 64, 32, 15),
 ]
+only = os.environ.get('SHAPES')          # comma-separated substrings
+if only:
+    shapes = [s_ for s_ in shapes if any(o in s_[0] for o in only.split(','))]
+brief = bool(os.environ.get('BRIEF'))
 reps = int(os.environ.get('REPS', '5'))
 for name, lvl, C, O, F in shapes:
     if lvl >= 0:
         tbl = lat.levels[lvl].blur[0].t
         M = tbl.shape[1]
+    elif lvl == -2:                      # corr B-term of level 2: 15*H1 virtual vertices, permuted corr2 table
+        tbl = lat.levels[2].corr2.t
+        M = tbl.shape[1]
     else:
         tbl, M = None, 8192
-    A = torch.randn(M, C, device=dev)
+    A = torch.randn(M if lvl != -2 else lat.levels[2].H[1], C, device=dev)
     W = torch.randn(O, C, F, device=dev) / (C * F) ** 0.5
     Wt = ops.weight_relayout(W, C, O, F, F, C * F, 1)
     nbr = tbl if F > 1 else None
@@ -40,8 +48,17 @@ for name, lvl, C, O, F in shapes:
     ms = s.elapsed_time(e) / reps
     fl = 2.0 * M * F * C * O
     valid = float((tbl >= 0).float().mean()) if nbr is not None else 1.0
+    if brief and nbr is not None and M >= 16384:     # what the model launches: rows sorted by tap mask
+        perm = ops.tap_order(nbr)
+        ops.gconv_raw(A, nbr, M, C, F, Wt, O, out=y, row_perm=perm)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(reps):
+            ops.gconv_raw(A, nbr, M, C, F, Wt, O, out=y, row_perm=perm)
+        e.record(); torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
     print('%-12s M=%6d K=%5d N=%5d  %8.3f ms  %6.1f TFLOP/s  (valid taps %.2f)' % (name, M, F * C, O, ms, fl / ms / 1e9, valid))
-    if nbr is not None:
+    if nbr is not None and not brief:
         perm = ops.tap_order(nbr)
         for nm, pm in (('  +row_perm(mask)', perm), ('  +row_perm(random)', torch.randperm(M, device=dev).to(torch.int32))):
             ops.gconv_raw(A, nbr, M, C, F, Wt, O, out=y, row_perm=pm)
