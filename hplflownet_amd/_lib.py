@@ -40,6 +40,8 @@ _SIGNATURES = {
     'hpl_corr2_permute': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_i64, c_vp]),
     'hpl_corr2_permute32': (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_i64, c_vp]),
     'hpl_csr_build': (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'hpl_csr_build_pair': (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp,
+                                          c_vp, c_vp]),
     'hpl_splat': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'hpl_slice': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'hpl_weight_relayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i64, c_i64,
@@ -55,11 +57,11 @@ _SIGNATURES = {
     'hpl_colsum': (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     'hpl_leaky_bwd': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_i64, ctypes.c_int, c_vp]),
     'hpl_transpose': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
-    'hpl_lattice_keys': (ctypes.c_int, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    'hpl_lattice_keys': (ctypes.c_int, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'hpl_lattice_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'hpl_lattice_hash': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'hpl_lattice_neighbors': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, ctypes.c_int,
-                                             ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                             ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'hpl_lattice_next_points': (ctypes.c_int, [c_vp, c_i64, c_i64, c_f32, c_vp, c_vp]),
 }
 

@@ -99,13 +99,30 @@ __global__ void k_zero_i32(int32_t *p, int64_t n) {
     for (; i < n; i += stride) p[i] = 0;
 }
 
-__global__ void k_csr_count(const int32_t *__restrict__ off, int64_t n_entries, int64_t H,
-                            int32_t *__restrict__ cnt) {
+// Entries of one cloud (e = r*N + n over its lattice_offset / barycentric tables) or of a pair of
+// clouds laid end to end: entries of cloud 1 follow those of cloud 0, its vertices and points are
+// renumbered behind cloud 0's (v + H0, n + N0).
+struct Seg2 {
+    const int32_t *off0; const float *w0; int64_t ne0, n0;
+    const int32_t *off1; const float *w1; int64_t ne1, n1;
+    int32_t h0;          // vertices of cloud 0 (shift of cloud 1)
+    __device__ __forceinline__ int32_t vertex(int64_t e, int64_t H) const {
+        if (e < ne0) { const int32_t v = off0[e]; return (v >= 0 && v < H) ? v : -1; }
+        const int32_t v = off1[e - ne0];
+        return (v >= 0 && v + h0 < H) ? v + h0 : -1;
+    }
+    __device__ __forceinline__ int32_t point(int64_t e) const {
+        return e < ne0 ? (int32_t)(e % n0) : (int32_t)(n0 + (e - ne0) % n1);
+    }
+    __device__ __forceinline__ float weight(int64_t e) const { return e < ne0 ? w0[e] : w1[e - ne0]; }
+};
+
+__global__ void k_csr_count(const Seg2 sg, int64_t n_entries, int64_t H, int32_t *__restrict__ cnt) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n_entries; i += stride) {
-        int32_t v = off[i];
-        if (v >= 0 && v < H) atomicAdd(&cnt[v], 1);   // integer atomics: deterministic counts
+        const int32_t v = sg.vertex(i, H);
+        if (v >= 0) atomicAdd(&cnt[v], 1);   // integer atomics: deterministic counts
     }
 }
 
@@ -187,14 +204,14 @@ __global__ void __launch_bounds__(256) k_scan_final(const int32_t *__restrict__ 
     if (blockIdx.x == (unsigned)(nb - 1) && threadIdx.x == 0) out[n] = boff_s + block_sums[nb - 1];
 }
 
-__global__ void k_csr_fill(const int32_t *__restrict__ off, int64_t n_entries, int64_t H,
+__global__ void k_csr_fill(const Seg2 sg, int64_t n_entries, int64_t H,
                            const int32_t *__restrict__ ptr, int32_t *__restrict__ cursor,
                            int32_t *__restrict__ ent) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n_entries; i += stride) {
-        int32_t v = off[i];
-        if (v >= 0 && v < H) {
+        const int32_t v = sg.vertex(i, H);
+        if (v >= 0) {
             int32_t slot = atomicAdd(&cursor[v], 1);
             ent[ptr[v] + slot] = (int32_t)i;
         }
@@ -205,7 +222,7 @@ __global__ void k_csr_fill(const int32_t *__restrict__ off, int64_t n_entries, i
 // every entry among its segment (entries are distinct, segments are short: mean 4..15), which
 // fixes the summation order of the splat, and emits (point, weight) pairs in that order.
 __global__ void __launch_bounds__(256) k_csr_rank(const int32_t *__restrict__ ptr, const int32_t *__restrict__ ent,
-                                                  const float *__restrict__ bary, int64_t pt_mod, int64_t H,
+                                                  const Seg2 sg, int64_t H,
                                                   int32_t *__restrict__ pt_out, float *__restrict__ w_out) {
     const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int lg = threadIdx.x & 15;
@@ -215,8 +232,8 @@ __global__ void __launch_bounds__(256) k_csr_rank(const int32_t *__restrict__ pt
         const int32_t x = ent[i];
         int32_t rank = 0;
         for (int32_t j = b; j < e; ++j) rank += (ent[j] < x) ? 1 : 0;
-        pt_out[b + rank] = (int32_t)(x % pt_mod);
-        w_out[b + rank] = bary[x];
+        pt_out[b + rank] = sg.point(x);
+        w_out[b + rank] = sg.weight(x);
     }
 }
 
@@ -230,6 +247,26 @@ __global__ void k_csr_norm(const int32_t *__restrict__ ptr, const float *__restr
     norm[v] = 1.0f / (s + 1e-5f);
 }
 
+namespace {
+int csr_build_impl(const Seg2 &sg, int64_t H, int32_t *csr_ptr, int32_t *csr_pt, float *csr_w, float *norm,
+                   int32_t *scratch, hipStream_t s, const char *who) {
+    const int64_t ne = sg.ne0 + sg.ne1;
+    int gh = (int)imin(cdiv(H + 1, 256), 2048);
+    int ge = (int)imin(cdiv(ne, 256), 2048);
+    int32_t *cursor = scratch, *ent = scratch + (H + 1), *scan_tmp = ent + ne;
+    k_zero_i32<<<gh, 256, 0, s>>>(cursor, H + 1);
+    k_csr_count<<<ge, 256, 0, s>>>(sg, ne, H, cursor);
+    int rc = exclusive_scan_i32(cursor, H, csr_ptr, scan_tmp, s);
+    if (rc != HPL_OK) return rc;
+    k_zero_i32<<<gh, 256, 0, s>>>(cursor, H + 1);
+    k_csr_fill<<<ge, 256, 0, s>>>(sg, ne, H, csr_ptr, cursor, ent);
+    k_csr_rank<<<(int)cdiv(H * 16, 256), 256, 0, s>>>(csr_ptr, ent, sg, H, csr_pt, csr_w);
+    k_csr_norm<<<(int)cdiv(H, 256), 256, 0, s>>>(csr_ptr, csr_w, H, norm);
+    HPL_CHECK_LAUNCH(who);
+    return HPL_OK;
+}
+}  // namespace
+
 extern "C" int hpl_csr_build(const int32_t *off, const float *bary, int64_t n_entries, int64_t pt_mod,
                              int64_t H, int32_t *csr_ptr, int32_t *csr_pt, float *csr_w, float *norm,
                              int32_t *scratch, hplStream stream) {
@@ -237,22 +274,23 @@ extern "C" int hpl_csr_build(const int32_t *off, const float *bary, int64_t n_en
                 "hpl_csr_build: null pointer");
     HPL_REQUIRE(n_entries > 0 && pt_mod > 0 && H > 0 && n_entries < (int64_t)INT32_MAX,
                 "hpl_csr_build: bad sizes n_entries=%lld H=%lld", (long long)n_entries, (long long)H);
-    hipStream_t s = to_stream(stream);
-    const int64_t ne = n_entries;
-    const int64_t N = pt_mod;
-    int gh = (int)imin(cdiv(H + 1, 256), 2048);
-    int ge = (int)imin(cdiv(ne, 256), 2048);
-    int32_t *cursor = scratch, *ent = scratch + (H + 1), *scan_tmp = ent + ne;
-    k_zero_i32<<<gh, 256, 0, s>>>(cursor, H + 1);
-    k_csr_count<<<ge, 256, 0, s>>>(off, ne, H, cursor);
-    int rc = exclusive_scan_i32(cursor, H, csr_ptr, scan_tmp, s);
-    if (rc != HPL_OK) return rc;
-    k_zero_i32<<<gh, 256, 0, s>>>(cursor, H + 1);
-    k_csr_fill<<<ge, 256, 0, s>>>(off, ne, H, csr_ptr, cursor, ent);
-    k_csr_rank<<<(int)cdiv(H * 16, 256), 256, 0, s>>>(csr_ptr, ent, bary, N, H, csr_pt, csr_w);
-    k_csr_norm<<<(int)cdiv(H, 256), 256, 0, s>>>(csr_ptr, csr_w, H, norm);
-    HPL_CHECK_LAUNCH("hpl_csr_build");
-    return HPL_OK;
+    const Seg2 sg = {off, bary, n_entries, pt_mod, nullptr, nullptr, 0, 1, 0};
+    return csr_build_impl(sg, H, csr_ptr, csr_pt, csr_w, norm, scratch, to_stream(stream), "hpl_csr_build");
+}
+
+extern "C" int hpl_csr_build_pair(const int32_t *off0, const float *bary0, int64_t N0, int64_t H0,
+                                  const int32_t *off1, const float *bary1, int64_t N1, int64_t H1,
+                                  int32_t *csr_ptr, int32_t *csr_pt, float *csr_w, float *norm,
+                                  int32_t *scratch, hplStream stream) {
+    HPL_REQUIRE(off0 && bary0 && off1 && bary1 && csr_ptr && csr_pt && csr_w && norm && scratch,
+                "hpl_csr_build_pair: null pointer");
+    HPL_REQUIRE(N0 > 0 && N1 > 0 && H0 > 0 && H1 > 0 && 4 * (N0 + N1) < (int64_t)INT32_MAX &&
+                    H0 + H1 < (int64_t)INT32_MAX,
+                "hpl_csr_build_pair: bad sizes N=(%lld,%lld) H=(%lld,%lld)", (long long)N0, (long long)N1,
+                (long long)H0, (long long)H1);
+    const Seg2 sg = {off0, bary0, 4 * N0, N0, off1, bary1, 4 * N1, N1, (int32_t)H0};
+    return csr_build_impl(sg, H0 + H1, csr_ptr, csr_pt, csr_w, norm, scratch, to_stream(stream),
+                          "hpl_csr_build_pair");
 }
 
 // ---------------------------------------------------------------- transpose

@@ -59,7 +59,7 @@ __device__ __forceinline__ int canonical(int i, int j) { return (j < 4 - i) ? j 
 // transforms/transforms.py:300-353, same statement order as oracle hpl_keys_and_barycentric
 __global__ void k_lattice_keys(const float *__restrict__ pc, int64_t N, float scale, const Elev E,
                                int32_t *__restrict__ keys, float *__restrict__ bary,
-                               float *__restrict__ emg) {
+                               float *__restrict__ emg, int64_t emg_ld) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float p0 = pc[n] * scale, p1 = pc[N + n] * scale, p2 = pc[2 * N + n] * scale;
@@ -94,7 +94,8 @@ __global__ void k_lattice_keys(const float *__restrict__ pc, int64_t N, float sc
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         res[j] = el[j] - gr[j];
-        emg[(int64_t)j * N + n] = res[j];
+        if (emg_ld) emg[n * emg_ld + j] = res[j];     // point-major (channel-last model input)
+        else emg[(int64_t)j * N + n] = res[j];         // (4, N), the reference layout
     }
     // rank is a permutation of 0..3: resolve the dynamic index with selects (no scratch)
 #pragma unroll
@@ -339,14 +340,15 @@ Offsets make_offsets(int radius) {
 __global__ void k_neighbors(const int32_t *__restrict__ vkeys, int64_t vstride, int64_t H, const Offsets offs,
                             const int32_t *__restrict__ mm, const int64_t *__restrict__ tkeys,
                             const int32_t *__restrict__ tid, uint64_t mask, int32_t *__restrict__ out,
-                            int64_t ostride) {
+                            int64_t ostride, int32_t shift) {
     const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
     if (h >= H) return;
     int k[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) k[c] = vkeys[(int64_t)c * vstride + h] + offs.v[f * 4 + c];
-    out[(int64_t)f * ostride + h] = lookup(tkeys, tid, mask, pack_key(k, mm));
+    const int32_t id = lookup(tkeys, tid, mask, pack_key(k, mm));
+    out[(int64_t)f * ostride + h] = id >= 0 ? id + shift : -1;
 }
 
 // corr2p[k][f*H1 + h] = id in table 2 of (key1_h + coff_k + foff_f)   (transforms.py:223-241)
@@ -384,10 +386,10 @@ __global__ void k_next_points(const int32_t *__restrict__ vkeys, int64_t vstride
 }  // namespace
 
 extern "C" int hpl_lattice_keys(const float *pc, int64_t N, float scale, int32_t *keys, float *bary,
-                                float *emg, hplStream stream) {
-    HPL_REQUIRE(pc && keys && bary && emg && N > 0, "hpl_lattice_keys: bad arguments");
+                                float *emg, int64_t emg_ld, hplStream stream) {
+    HPL_REQUIRE(pc && keys && bary && emg && N > 0 && (emg_ld == 0 || emg_ld >= 4), "hpl_lattice_keys: bad arguments");
     HPL_REQUIRE(aligned16(keys), "hpl_lattice_keys: keys must be 16-byte aligned");
-    k_lattice_keys<<<(int)cdiv(N, 256), 256, 0, to_stream(stream)>>>(pc, N, scale, make_elev(), keys, bary, emg);
+    k_lattice_keys<<<(int)cdiv(N, 256), 256, 0, to_stream(stream)>>>(pc, N, scale, make_elev(), keys, bary, emg, emg_ld);
     HPL_CHECK_LAUNCH("hpl_lattice_keys");
     return HPL_OK;
 }
@@ -435,7 +437,8 @@ extern "C" int hpl_lattice_hash(const int32_t *keys1, int64_t n1, const int32_t 
 extern "C" int hpl_lattice_neighbors(const void *workspace, int64_t n1, int64_t n2, const int32_t *vkeys1,
                                      const int32_t *vkeys2, int64_t H1, int64_t H2, int bcn_radius,
                                      int corr_filter_radius, int corr_corr_radius, int32_t *blur1,
-                                     int32_t *blur2, int32_t *corr1, int32_t *corr2, hplStream stream) {
+                                     int32_t *blur2, int64_t blur_stride, int64_t blur2_shift, int32_t *corr1,
+                                     int32_t *corr2, hplStream stream) {
     HPL_REQUIRE(workspace && vkeys1 && vkeys2 && n1 > 0 && n2 > 0, "hpl_lattice_neighbors: bad arguments");
     HPL_REQUIRE(H1 > 0 && H2 > 0 && H1 <= 4 * n1 && H2 <= 4 * n2, "hpl_lattice_neighbors: bad vertex counts");
     HPL_REQUIRE(bcn_radius <= 2 && corr_filter_radius <= 2 && corr_corr_radius <= 2,
@@ -445,17 +448,22 @@ extern "C" int hpl_lattice_neighbors(const void *workspace, int64_t n1, int64_t 
     hipStream_t s = to_stream(stream);
     if (bcn_radius != -1) {
         HPL_REQUIRE(blur1 && blur2, "hpl_lattice_neighbors: null blur table");
+        HPL_REQUIRE(blur_stride == 0 || blur_stride >= imax(H1, H2), "hpl_lattice_neighbors: blur_stride too small");
+        HPL_REQUIRE(blur2_shift >= 0 && blur2_shift + H2 < (int64_t)INT32_MAX, "hpl_lattice_neighbors: bad blur2_shift");
         const Offsets o = make_offsets(bcn_radius);
         k_neighbors<<<dim3((unsigned)cdiv(H1, 256), o.n), 256, 0, s>>>(vkeys1, 4 * n1, H1, o, w.mm, w.c[0].tkeys,
-                                                                       w.c[0].tid, w.c[0].mask, blur1, H1);
+                                                                       w.c[0].tid, w.c[0].mask, blur1,
+                                                                       blur_stride ? blur_stride : H1, 0);
         k_neighbors<<<dim3((unsigned)cdiv(H2, 256), o.n), 256, 0, s>>>(vkeys2, 4 * n2, H2, o, w.mm, w.c[1].tkeys,
-                                                                       w.c[1].tid, w.c[1].mask, blur2, H2);
+                                                                       w.c[1].tid, w.c[1].mask, blur2,
+                                                                       blur_stride ? blur_stride : H2,
+                                                                       (int32_t)blur2_shift);
     }
     if (corr_filter_radius != -1) {
         HPL_REQUIRE(corr1 && corr2, "hpl_lattice_neighbors: null corr table");
         const Offsets co = make_offsets(corr_corr_radius), fo = make_offsets(corr_filter_radius);
         k_neighbors<<<dim3((unsigned)cdiv(H1, 256), co.n), 256, 0, s>>>(vkeys1, 4 * n1, H1, co, w.mm, w.c[0].tkeys,
-                                                                        w.c[0].tid, w.c[0].mask, corr1, H1);
+                                                                        w.c[0].tid, w.c[0].mask, corr1, H1, 0);
         k_neighbors_corr2<<<dim3((unsigned)cdiv(H1, 256), co.n * fo.n), 256, 0, s>>>(
             vkeys1, 4 * n1, H1, co, fo, w.mm, w.c[1].tkeys, w.c[1].tid, w.c[1].mask, corr2);
     }

@@ -11,6 +11,8 @@ the reference forward by writes into column slices of one buffer per layer input
 Level L (0-based) hosts bcn{L+1} (Down, shared by both clouds), bcn{L+1}_ (Up) and, for
 L >= 2, corr{L-1}.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -18,12 +20,42 @@ from . import _lib, ops
 from .bcl import (BilateralConvFlex, BilateralCorrelationFlex, Conv1dReLU, NbrTable, pointwise_conv,
                   to_channel_first, to_channel_last)
 
-__all__ = ['HPLFlowNet', 'HPLFlowNetShallow', 'DeviceLattice']
+__all__ = ['HPLFlowNet', 'HPLFlowNetShallow', 'DeviceLattice', 'PairBlur']
 
 
 # ----------------------------------------------------------------------------- lattice container
 class _Level(object):
-    __slots__ = ('clouds', 'blur', 'emg', 'corr1', 'corr2', 'H')
+    # pair / emg_pair: both clouds as one (ops.PairTables, el_minus_gr [N0+N1, 4]); None when the
+    # lattice came from the reference's per-cloud wire format
+    __slots__ = ('clouds', 'blur', 'emg', 'corr1', 'corr2', 'H', 'pair', 'emg_pair')
+
+    def __init__(self):
+        self.pair = None
+        self.emg_pair = None
+
+
+class PairBlur(object):
+    """Blur tables of the two clouds of a level as ONE int32 table [F, H0+H1]: columns [0,H0) are
+    cloud 1's vertices, columns [H0,H0+H1) cloud 2's with neighbour ids shifted by H0 (so the table
+    indexes the pair's stacked feature matrix).  Behaves like the list [blur1, blur2]:
+    [0] is a zero-copy view, [1] (cloud 2's own numbering) is materialised on first use."""
+
+    def __init__(self, table, H0):
+        self.pair = NbrTable(table)
+        self.H0 = H0
+        self._own = [NbrTable(table[:, :H0]), None]
+
+    def __len__(self):
+        return 2
+
+    def __getitem__(self, i):
+        if i == 1 and self._own[1] is None:
+            t = self.pair.t[:, self.H0:]
+            self._own[1] = NbrTable(torch.where(t >= 0, t - self.H0, t).contiguous())
+        return self._own[i]
+
+    def __iter__(self):
+        return iter((self[0], self[1]))
 
 
 class DeviceLattice(object):
@@ -38,10 +70,19 @@ class DeviceLattice(object):
     def prepare(self):
         """Build every lazily constructed table (the CSR of each splat) now, on the current stream,
         so that a lattice built on a side stream is complete before it is handed to the forward."""
-        for lv in self.levels:
-            for c in lv.clouds:
-                c.csr()
-            for tbl in list(lv.blur) + [lv.corr1]:
+        for L, lv in enumerate(self.levels):
+            if lv.pair is not None:
+                # inference path: the Down layers run once per pair; cloud 1 alone is splatted only by the
+                # correlation layers that take a previous correlation (levels >= 3)
+                lv.pair.csr()
+                if lv.corr1 is not None and L >= 3:
+                    lv.clouds[0].csr()
+                tables = [lv.blur.pair, lv.blur[0], lv.corr1] if isinstance(lv.blur, PairBlur) else [lv.corr1]
+            else:
+                for c in lv.clouds:
+                    c.csr()
+                tables = list(lv.blur) + [lv.corr1]
+            for tbl in tables:
                 if tbl is not None:
                     tbl.perm
         return self
@@ -112,6 +153,9 @@ class _FlowNetBase(nn.Module):
     UP = None            # per level L: num_output of bcn{L+1}_
     REFINE = False       # corr{j}_refine Conv1d stacks (shallow model)
     HEAD_IN = None
+    #: inference on a device-built lattice runs the Down path once per PAIR (both clouds stacked);
+    #: False forces the per-cloud path (what training and reference-format lattices use)
+    pair_batched = not os.environ.get('HPL_NO_PAIR')      # env: A/B switch for benchmarking
 
     def __init__(self, args):
         super(_FlowNetBase, self).__init__()
@@ -167,6 +211,19 @@ class _FlowNetBase(nn.Module):
             x = pointwise_conv(x, m.conv, True, self.use_leaky, out=out if i == len(mods) - 1 else None)
         return x
 
+    def _corr(self, L, lat, feats, prev, corrs, dev):
+        lv = lat.levels[L]
+        j = L - 1
+        c = getattr(self, 'corr%d' % j).forward_cl(feats[0], feats[1], prev,
+                                                  lv.clouds[0] if prev is not None else None,
+                                                  lv.corr1, lv.corr2)
+        if self.REFINE:
+            if L + 1 < self.NLEV:
+                c = _assemble(c.shape[0], [(4, lat.levels[L + 1].emg[0]), (c.shape[1], c)], dev)
+            c = self._stack(c, getattr(self, 'corr%d_refine' % j))
+        corrs[L] = c
+        return c
+
     def forward(self, pc1, pc2, generated_data):
         dev = pc1.device
         if not pc1.is_cuda:
@@ -174,29 +231,53 @@ class _FlowNetBase(nn.Module):
         lat = generated_data if isinstance(generated_data, DeviceLattice) else \
             DeviceLattice.from_generated_data(generated_data[:self.NLEV], dev)
         nlev = self.NLEV
-        feats = [self._stack(to_channel_last(pc1), self.conv1), self._stack(to_channel_last(pc2), self.conv1)]
+        pair = (not torch.is_grad_enabled()) and self.pair_batched and \
+            all(lv.pair is not None and isinstance(lv.blur, PairBlur) for lv in lat.levels[:nlev])
         down = [[], []]
         corrs = {}
         prev = None
-        for L in range(nlev):
-            lv = lat.levels[L]
-            layer = getattr(self, 'bcn%d' % (L + 1))
-            for ci in (0, 1):
-                cloud = lv.clouds[ci]
-                x = _assemble(cloud.N, [(4, lv.emg[ci]), (feats[ci].shape[1], feats[ci])], dev)
-                feats[ci] = layer.forward_cl(x, cloud, lv.blur[ci], None)
-                down[ci].append(feats[ci])
-            if L >= 2:
-                j = L - 1
-                c = getattr(self, 'corr%d' % j).forward_cl(feats[0], feats[1], prev,
-                                                          lv.clouds[0] if prev is not None else None,
-                                                          lv.corr1, lv.corr2)
-                if self.REFINE:
-                    if L + 1 < nlev:
-                        c = _assemble(c.shape[0], [(4, lat.levels[L + 1].emg[0]), (c.shape[1], c)], dev)
-                    c = self._stack(c, getattr(self, 'corr%d_refine' % j))
-                corrs[L] = c
-                prev = c
+        if pair:
+            # Both clouds go through conv1 and the Down BCLs as ONE stacked matrix (cloud 2's points and
+            # vertices behind cloud 1's; pair CSR, pair blur table): half the launches, and the output
+            # of level L is written straight into columns [4, 4+C) of level L+1's input.
+            feat_c = self.conv1[-1].conv.out_channels
+            n0 = lat.levels[0].pair.N
+            xin = torch.empty((n0, pc1.shape[1]), dtype=torch.float32, device=dev)
+            if lat.levels[0].clouds[0].N != pc1.shape[2] or lat.levels[0].clouds[1].N != pc2.shape[2]:
+                raise _lib.HplError('lattice was built for %d / %d points, got %d / %d'
+                                    % (lat.levels[0].clouds[0].N, lat.levels[0].clouds[1].N, pc1.shape[2],
+                                       pc2.shape[2]))
+            h = pc1.shape[2]
+            xin[:h].copy_(to_channel_last(pc1))
+            xin[h:].copy_(to_channel_last(pc2))
+            x = torch.empty((n0, 4 + feat_c), dtype=torch.float32, device=dev)
+            self._stack(xin, self.conv1, out=x[:, 4:])
+            for L in range(nlev):
+                lv = lat.levels[L]
+                layer = getattr(self, 'bcn%d' % (L + 1))
+                x[:, :4].copy_(lv.emg_pair)
+                c_out = layer.num_output[-1]
+                H0, Hp = lv.H[0], lv.pair.H
+                nxt = torch.empty((Hp, 4 + c_out), dtype=torch.float32, device=dev) if L + 1 < nlev else None
+                y = layer.forward_cl(x, lv.pair, lv.blur.pair, None, out=nxt[:, 4:] if nxt is not None else None)
+                feats = [y[:H0], y[H0:]]
+                down[0].append(feats[0])
+                down[1].append(feats[1])
+                x = nxt
+                if L >= 2:
+                    prev = self._corr(L, lat, feats, prev, corrs, dev)
+        else:
+            feats = [self._stack(to_channel_last(pc1), self.conv1), self._stack(to_channel_last(pc2), self.conv1)]
+            for L in range(nlev):
+                lv = lat.levels[L]
+                layer = getattr(self, 'bcn%d' % (L + 1))
+                for ci in (0, 1):
+                    cloud = lv.clouds[ci]
+                    x = _assemble(cloud.N, [(4, lv.emg[ci]), (feats[ci].shape[1], feats[ci])], dev)
+                    feats[ci] = layer.forward_cl(x, cloud, lv.blur[ci], None)
+                    down[ci].append(feats[ci])
+                if L >= 2:
+                    prev = self._corr(L, lat, feats, prev, corrs, dev)
         up = None        # callable(out_view) producing the previous Up output, or None
         up_c = 0
         for L in reversed(range(nlev)):

@@ -20,7 +20,7 @@ import torch
 from . import _lib, ops
 from ._lib import check, ptr, stream
 from .bcl import NbrTable
-from .flownet import DeviceLattice, _Level
+from .flownet import DeviceLattice, PairBlur, _Level
 
 
 def _filter_size(radius, d1=4):
@@ -46,14 +46,15 @@ class GenerateDataUnsymmetric(object):
         nlev = len(self.scales_filter_map)
         for idx, (scale, bcn_r, cf_r, cc_r) in enumerate(self.scales_filter_map):
             n = [int(last[0].shape[1]), int(last[1].shape[1])]
-            keys, bary, emg = [], [], []
+            keys, bary = [], []
+            emg_p = torch.empty((n[0] + n[1], 4), dtype=torch.float32, device=dev)     # both clouds, point-major
+            emg = [emg_p[:n[0]], emg_p[n[0]:]]
             for c in (0, 1):
                 k = torch.empty((4, n[c], 4), dtype=torch.int32, device=dev)
                 b = torch.empty((4, n[c]), dtype=torch.float32, device=dev)
-                e = torch.empty((4, n[c]), dtype=torch.float32, device=dev)
-                check(L.hpl_lattice_keys(ptr(last[c]), n[c], float(scale), ptr(k), ptr(b), ptr(e), stream()),
+                check(L.hpl_lattice_keys(ptr(last[c]), n[c], float(scale), ptr(k), ptr(b), ptr(emg[c]), 4, stream()),
                       'hpl_lattice_keys')
-                keys.append(k); bary.append(b); emg.append(e)
+                keys.append(k); bary.append(b)
             wsb = int(L.hpl_lattice_workspace_bytes(n[0], n[1]))
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             off = [torch.empty((4, n[c]), dtype=torch.int32, device=dev) for c in (0, 1)]
@@ -62,22 +63,27 @@ class GenerateDataUnsymmetric(object):
             check(L.hpl_lattice_hash(ptr(keys[0]), n[0], ptr(keys[1]), n[1], ptr(off[0]), ptr(off[1]), ptr(vk[0]),
                                      ptr(vk[1]), ptr(counts), ptr(ws), wsb, stream()), 'hpl_lattice_hash')
             H = [int(v) for v in counts.tolist()]                  # host sync: sizes of the next arrays
-            blur = [None, None]
+            blur_p = None
+            blur_ptr = [None, None]
             corr1 = corr2 = None
             if bcn_r != -1:
+                # one table for the pair: columns [0,H0) cloud 1, [H0,H0+H1) cloud 2 with ids shifted by H0
                 F = _filter_size(bcn_r)
-                blur = [torch.empty((F, H[c]), dtype=torch.int32, device=dev) for c in (0, 1)]
+                blur_p = torch.empty((F, H[0] + H[1]), dtype=torch.int32, device=dev)
+                blur_ptr = [ptr(blur_p), blur_p.data_ptr() + 4 * H[0]]
             if cf_r != -1:
                 corr1 = torch.empty((_filter_size(cc_r), H[0]), dtype=torch.int32, device=dev)
                 corr2 = torch.empty((_filter_size(cc_r), _filter_size(cf_r) * H[0]), dtype=torch.int32, device=dev)
             check(L.hpl_lattice_neighbors(ptr(ws), n[0], n[1], ptr(vk[0]), ptr(vk[1]), H[0], H[1], int(bcn_r),
-                                          int(cf_r), int(cc_r), ptr(blur[0]), ptr(blur[1]), ptr(corr1),
-                                          ptr(corr2), stream()), 'hpl_lattice_neighbors')
+                                          int(cf_r), int(cc_r), blur_ptr[0], blur_ptr[1], H[0] + H[1], H[0],
+                                          ptr(corr1), ptr(corr2), stream()), 'hpl_lattice_neighbors')
             lv = _Level()
             lv.H = (H[0], H[1])
             lv.clouds = [ops.CloudTables(bary[c], off[c], H[c]) for c in (0, 1)]
-            lv.blur = [NbrTable(b) if b is not None else None for b in blur]
-            lv.emg = [emg[c].t().contiguous() for c in (0, 1)]
+            lv.blur = PairBlur(blur_p, H[0]) if blur_p is not None else [None, None]
+            lv.emg = emg
+            lv.emg_pair = emg_p
+            lv.pair = ops.PairTables(lv.clouds[0], lv.clouds[1])
             lv.corr1 = NbrTable(corr1) if corr1 is not None else None
             if lv.corr1 is not None and cc_r == bcn_r:
                 lv.corr1 = lv.blur[0]          # same offsets, same table: share it

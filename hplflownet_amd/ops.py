@@ -81,6 +81,33 @@ class CloudTables(object):
         return self._csr
 
 
+class PairTables(object):
+    """Both clouds of one lattice level treated as one cloud: points [0,N0) + [N0,N0+N1), vertices
+    [0,H0) + [H0,H0+H1).  Only what the splat needs (the pair CSR); a vertex belongs to one cloud,
+    so every segment equals the per-cloud CSR and the result rows equal the per-cloud results."""
+
+    def __init__(self, c0, c1):
+        self.c0, self.c1 = c0, c1
+        self.N = c0.N + c1.N
+        self.H = c0.H + c1.H
+        self._csr = None
+
+    def csr(self):
+        if self._csr is None:
+            c0, c1 = self.c0, self.c1
+            dev = c0.bary.device
+            csr_ptr = torch.empty(self.H + 1, dtype=torch.int32, device=dev)
+            csr_pt = torch.empty(4 * self.N, dtype=torch.int32, device=dev)
+            csr_w = torch.empty(4 * self.N, dtype=torch.float32, device=dev)
+            norm = torch.empty(self.H, dtype=torch.float32, device=dev)
+            scratch = torch.empty(self.H + 1 + 4 * self.N + 1026, dtype=torch.int32, device=dev)
+            check(_lib.load().hpl_csr_build_pair(ptr(c0.off), ptr(c0.bary), c0.N, c0.H, ptr(c1.off), ptr(c1.bary),
+                                                 c1.N, c1.H, ptr(csr_ptr), ptr(csr_pt), ptr(csr_w), ptr(norm),
+                                                 ptr(scratch), stream()), 'hpl_csr_build_pair')
+            self._csr = (csr_ptr, csr_pt, csr_w, norm)
+        return self._csr
+
+
 def tap_order(nbr):
     """int32 [F<=15, M] neighbour table -> int32 [M] permutation grouping the rows by tap-presence mask."""
     F, M = nbr.shape
@@ -151,8 +178,8 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
     d.A, d.lda, d.rows_a = ptr(A), _ld(A), A.shape[0]
     if nbr is not None:
         if nbr.dtype != torch.int32 or nbr.dim() != 2 or nbr.shape[0] != F or nbr.shape[1] != M or \
-                not nbr.is_contiguous():
-            raise _lib.HplError('neighbour table must be contiguous int32 [F=%d, M=%d], got %s %s'
+                nbr.stride(1) != 1:
+            raise _lib.HplError('neighbour table must be int32 [F=%d, M=%d] with unit column stride, got %s %s'
                                 % (F, M, tuple(nbr.shape), nbr.dtype))
         d.nbr, d.nbr_stride = ptr(nbr), nbr.stride(0)
     else:

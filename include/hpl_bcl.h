@@ -76,6 +76,14 @@ int hpl_corr2_permute32(const int32_t *src, int32_t *dst, int F, int K, int64_t 
 int hpl_csr_build(const int32_t *off, const float *bary, int64_t n_entries, int64_t pt_mod, int64_t H,
                   int32_t *csr_ptr, int32_t *csr_pt, float *csr_w, float *norm,
                   int32_t *scratch, hplStream stream);
+/* The same for a pair of clouds treated as one: points [0,N0) + [N0,N0+N1), vertices [0,H0) +
+ * [H0,H0+H1) (off1 values are shifted by H0 here).  off0, off1, bary0, bary1 are the per-cloud [4][N] tables.
+ * Outputs sized for H = H0+H1 and 4*(N0+N1) entries; scratch (H+1) + 4*(N0+N1) + 1026 int32.
+ * A vertex belongs to one cloud, so each segment is identical to the per-cloud CSR. */
+int hpl_csr_build_pair(const int32_t *off0, const float *bary0, int64_t N0, int64_t H0,
+                       const int32_t *off1, const float *bary1, int64_t N1, int64_t H1,
+                       int32_t *csr_ptr, int32_t *csr_pt, float *csr_w, float *norm,
+                       int32_t *scratch, hplStream stream);
 
 /* ------------------------------------------------------------------------ *
  * Splat / slice  (HBM-bound gathers)
@@ -194,11 +202,13 @@ int hpl_transpose(const float *src, int64_t lds, float *dst, int64_t ldd, int64_
  * transforms/transforms.py:133-261,300-353,358-485 and models/khash_int2int.h:8-33)
  * ------------------------------------------------------------------------ */
 /* Float part, transforms/transforms.py:300-353.  pc (3, N) float32 (unscaled), the level
- * scale is applied inside (:377-378).  keys: int32 [4 coord][N][4 remainder]; bary, emg
- * (4, N).  Bit-identical to oracle/lattice_oracle.c (explicit fmaf chain, half-even
- * rounding, stable descending rank). */
+ * scale is applied inside (:377-378).  keys: int32 [4 coord][N][4 remainder]; bary (4, N);
+ * emg (el_minus_gr): (4, N) like the reference when emg_ld == 0, else point-major
+ * emg[n*emg_ld + j] (emg_ld >= 4: the channel-last layout the layers consume, so that both
+ * clouds of a pair can be written into one matrix).  Bit-identical to oracle/lattice_oracle.c
+ * (explicit fmaf chain, half-even rounding, stable descending rank). */
 int hpl_lattice_keys(const float *pc, int64_t N, float scale, int32_t *keys, float *bary,
-                     float *emg, hplStream stream);
+                     float *emg, int64_t emg_ld, hplStream stream);
 
 /* Integer part, stage 1 (transforms/transforms.py:171-207 and :384-391): per-coordinate
  * key range over both clouds, mixed-radix packing (key2int, :70-86), one open-addressing
@@ -218,12 +228,16 @@ int hpl_lattice_hash(const int32_t *keys1, int64_t n1, const int32_t *keys2, int
  * Radius -1 skips a table (pointer may be NULL).  H1, H2 are the counts read back from
  * stage 1.  blur1 [F][H1], blur2 [F][H2], corr1 [K][H1]; corr2 is written directly in the
  * kernel-ready permuted layout [K][F*H1] (see hpl_corr2_permute).  Misses are -1; like the
- * reference, neighbour keys are packed without a range check. */
+ * reference, neighbour keys are packed without a range check.
+ * blur_stride == 0: both blur tables are dense ([F][H1], [F][H2]).  Otherwise both have row
+ * stride blur_stride and the ids in blur2 are shifted by blur2_shift: with blur2 = blur1 + H1,
+ * blur_stride = H1 + H2, blur2_shift = H1 the two tables form ONE table [F][H1+H2] of the pair
+ * (cloud 2's vertices numbered behind cloud 1's) -- the Down layers then run once per pair. */
 int hpl_lattice_neighbors(const void *workspace, int64_t n1, int64_t n2,
                           const int32_t *vkeys1, const int32_t *vkeys2, int64_t H1, int64_t H2,
                           int bcn_radius, int corr_filter_radius, int corr_corr_radius,
-                          int32_t *blur1, int32_t *blur2, int32_t *corr1, int32_t *corr2,
-                          hplStream stream);
+                          int32_t *blur1, int32_t *blur2, int64_t blur_stride, int64_t blur2_shift,
+                          int32_t *corr1, int32_t *corr2, hplStream stream);
 
 /* Next level's points (transforms.py:461-467): out (3, H) = E^T (vkeys / divisor), divisor =
  * (float)(expected_std * scale) computed by the caller in double like the reference. */

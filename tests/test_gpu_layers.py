@@ -245,3 +245,34 @@ def test_config3_full_n8192_mfma_vs_naive_and_determinism():
     epe = lambda y: float(torch.norm(y - tsf[None], p=2, dim=1).mean())
     assert abs(epe(y1) - epe(y3)) < 1e-4
     assert float((y1 - y3).abs().max()) < 2e-4 * max(1.0, float(y3.abs().max()))
+
+
+@pytest.mark.parametrize('cls,nsc,n1,n2', [('HPLFlowNet', 7, 1024, 1024), ('HPLFlowNetShallow', 5, 2048, 1500)])
+def test_pair_batched_down_path_equals_per_cloud(cls, nsc, n1, n2):
+    """Inference runs conv1 + the Down BCLs once per PAIR (stacked clouds, pair CSR, pair blur table);
+    the per-cloud path (training, reference-format lattices) must give the same flow.  Rows of a
+    GEMM are independent and a vertex belongs to one cloud, so only the split-K decisions differ."""
+    import hplflownet_amd as H
+    from hplflownet_amd import ops
+    pc1, pc2, sf = synthetic_pair(max(n1, n2), 2)
+    pc1, pc2 = pc1[:n1], pc2[:n2]
+    args = model_args(nsc)
+    gen = H.GenerateDataUnsymmetric(args, device=DEV)
+    t1, t2, _, lat = gen([pc1, pc2, pc1])
+    # pair CSR == per-cloud CSRs laid end to end
+    for lv in lat.levels:
+        p, q0, q1 = lv.pair.csr(), lv.clouds[0].csr(), lv.clouds[1].csr()
+        assert torch.equal(p[0][:lv.H[0] + 1], q0[0]) and torch.equal(p[0][lv.H[0]:] - p[0][lv.H[0]], q1[0])
+        assert torch.equal(p[1], torch.cat([q0[1], q1[1] + lv.clouds[0].N]))
+        assert torch.equal(p[2], torch.cat([q0[2], q1[2]])) and torch.equal(p[3], torch.cat([q0[3], q1[3]]))
+    m = getattr(H, cls)(args)
+    fill_module_(m, 1.0, 'hash')
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        y_pair = m(t1[None], t2[None], lat)
+        m.pair_batched = False
+        y_sep = m(t1[None], t2[None], lat)
+        y_ref = m(t1[None], t2[None], H.to_reference_format(lat))      # per-cloud, reference wire format
+    assert torch.equal(y_sep, y_ref)
+    scale = max(1.0, float(y_sep.abs().max()))
+    assert float((y_pair - y_sep).abs().max()) < 1e-5 * scale
