@@ -78,7 +78,8 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise HplError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                            '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
-        lib = ctypes.CDLL(LIB_PATH)
+        # HPL_LIB: load an experimental build of the same ABI instead (kernel A/B tests on one box)
+        lib = ctypes.CDLL(os.environ.get('HPL_LIB') or LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError here = ABI/header mismatch
             fn.restype = res
