@@ -234,10 +234,8 @@ def main():
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
         sfs = [torch.from_numpy(sf.T.copy()).to(dev) for _, _, sf in pairs_np]
 
-        def step(i):                                           # noqa: F811
+        def compute(i, lat):
             p1, p2 = pairs[i % a.pool]
-            with torch.no_grad():
-                lat = fixed_lat[i % a.pool] if a.no_lattice else gen.build(p1, p2)
             flow = model(p1[None], p2[None], lat)
             loss = torch.norm(flow - sfs[i % a.pool][None], p=2, dim=1).mean()      # EPE3DLoss, main.py:213
             opt.zero_grad(set_to_none=True)
@@ -246,7 +244,17 @@ def main():
             opt.step()
             return flow
 
-    overlap = not (a.train or a.no_lattice or a.no_overlap)
+        def step(i):                                           # noqa: F811
+            p1, p2 = pairs[i % a.pool]
+            with torch.no_grad():
+                lat = fixed_lat[i % a.pool] if a.no_lattice else gen.build(p1, p2)
+            return compute(i, lat)
+    else:
+        def compute(i, lat):
+            p1, p2 = pairs[i % a.pool]
+            return model(p1[None], p2[None], lat)
+
+    overlap = not (a.no_lattice or a.no_overlap)
     # HPL_PRIO: which stream gets the high hardware-queue priority ('lattice' | 'forward' | 'none')
     prio = os.environ.get('HPL_PRIO', 'lattice')
     side = torch.cuda.Stream(device=dev, priority=-1 if prio == 'lattice' else 0) if overlap else None
@@ -261,8 +269,8 @@ def main():
 
         def build(i):
             t = time.perf_counter()
-            with torch.cuda.stream(side):
-                lat = gen.build(*pairs[i % a.pool]).prepare()
+            with torch.cuda.stream(side), torch.no_grad():
+                lat = gen.build(*pairs[i % a.pool]).prepare(for_training=a.train)
                 ev = torch.cuda.Event()
                 ev.record(side)
             host['lattice_build_ms'] += (time.perf_counter() - t) * 1e3
@@ -273,10 +281,9 @@ def main():
         for i in range(first, first + count):
             lat, ev = nxt
             main.wait_event(ev)
-            p1, p2 = pairs[i % a.pool]
             t = time.perf_counter()
             with torch.cuda.stream(main):
-                out = model(p1[None], p2[None], lat)
+                out = compute(i, lat)
             host['forward_enqueue_ms'] += (time.perf_counter() - t) * 1e3
             fin = torch.cuda.Event()
             fin.record(main)

@@ -430,3 +430,26 @@ extern "C" int hpl_tap_order(const int32_t *nbr, int64_t nbr_stride, int F, int6
     HPL_CHECK_LAUNCH("hpl_tap_order");
     return HPL_OK;
 }
+
+// ---------------------------------------------------------------- table symmetry
+// flag[0] &= (nbr[0][m] == m) and (nbr[f][m] = g >= 0  =>  g < M and nbr[F-f][g] == m) for all m, f >= 1
+// (holds by construction unless an unchecked key packing aliased, A.2 quirk).
+__global__ void k_table_symmetric(const int32_t *__restrict__ nbr, int64_t stride, int F, int64_t M,
+                                  int32_t *__restrict__ flag) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (m >= M) return;
+    const int32_t g = nbr[(int64_t)f * stride + m];
+    bool ok;
+    if (f == 0) ok = (g == (int32_t)m);
+    else ok = (g < 0) || (g < M && nbr[(int64_t)(F - f) * stride + g] == (int32_t)m);
+    if (!ok) *flag = 0;
+}
+
+extern "C" int hpl_table_symmetric(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *flag,
+                                   hplStream stream) {
+    HPL_REQUIRE(nbr && flag && F >= 1 && M > 0 && nbr_stride >= M, "hpl_table_symmetric: bad arguments");
+    k_table_symmetric<<<dim3((unsigned)cdiv(M, 256), F), 256, 0, to_stream(stream)>>>(nbr, nbr_stride, F, M, flag);
+    HPL_CHECK_LAUNCH("hpl_table_symmetric");
+    return HPL_OK;
+}

@@ -52,6 +52,7 @@ class PairBlur(object):
         if i == 1 and self._own[1] is None:
             t = self.pair.t[:, self.H0:]
             self._own[1] = NbrTable(torch.where(t >= 0, t - self.H0, t).contiguous())
+            self._own[1]._sym = self.pair._sym
         return self._own[i]
 
     def __iter__(self):
@@ -67,11 +68,12 @@ class DeviceLattice(object):
     def __init__(self, levels):
         self.levels = levels
 
-    def prepare(self):
-        """Build every lazily constructed table (the CSR of each splat) now, on the current stream,
-        so that a lattice built on a side stream is complete before it is handed to the forward."""
+    def prepare(self, for_training=False):
+        """Build every lazily constructed table (CSRs, tap orders, symmetry verdicts) now, on the
+        current stream, so that a lattice built on a side stream is complete before it is handed to
+        the forward.  for_training: the tables of the per-cloud path + the symmetry read-back."""
         for L, lv in enumerate(self.levels):
-            if lv.pair is not None:
+            if lv.pair is not None and not for_training:
                 # inference path: the Down layers run once per pair; cloud 1 alone is splatted only by the
                 # correlation layers that take a previous correlation (levels >= 3)
                 lv.pair.csr()
@@ -85,6 +87,32 @@ class DeviceLattice(object):
             for tbl in tables:
                 if tbl is not None:
                     tbl.perm
+        if for_training:
+            self.resolve_symmetry()
+        return self
+
+    def resolve_symmetry(self):
+        """Decide `symmetric` of every blur / corr1 table that has not been checked yet with ONE host
+        read-back (the backward picks the mirrored-gather or the atomic-scatter form from it)."""
+        todo = []
+        for lv in self.levels:
+            tables = [lv.corr1]
+            if isinstance(lv.blur, PairBlur):
+                tables += [lv.blur.pair]
+            else:
+                tables += list(lv.blur)
+            for t in tables:
+                if t is not None and t._sym is None and t.t.shape[0] == 15 and all(t is not u for u, _ in todo):
+                    todo.append((t, ops.table_symmetry_flag(t.t)))
+        if todo:
+            flags = torch.cat([f for _, f in todo]).tolist()
+            for (t, _), v in zip(todo, flags):
+                t._sym = bool(v)
+        for lv in self.levels:
+            if isinstance(lv.blur, PairBlur):            # the per-cloud views inherit the pair's verdict
+                for i in (0, 1):
+                    if lv.blur._own[i] is not None and lv.blur._own[i]._sym is None:
+                        lv.blur._own[i]._sym = lv.blur.pair._sym
         return self
 
     @staticmethod
@@ -231,6 +259,8 @@ class _FlowNetBase(nn.Module):
         lat = generated_data if isinstance(generated_data, DeviceLattice) else \
             DeviceLattice.from_generated_data(generated_data[:self.NLEV], dev)
         nlev = self.NLEV
+        if torch.is_grad_enabled():
+            lat.resolve_symmetry()
         pair = (not torch.is_grad_enabled()) and self.pair_batched and \
             all(lv.pair is not None and isinstance(lv.blur, PairBlur) for lv in lat.levels[:nlev])
         down = [[], []]

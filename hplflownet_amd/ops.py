@@ -117,11 +117,22 @@ def tap_order(nbr):
     return perm
 
 
+def table_symmetry_flag(nbr):
+    """Launch the symmetry check of an int32 [F, M] table; -> int32 device tensor [1] (1 = symmetric).
+    No host sync: read several flags back together (DeviceLattice.resolve_symmetry)."""
+    F, M = nbr.shape
+    flag = torch.ones(1, dtype=torch.int32, device=nbr.device)
+    check(_lib.load().hpl_table_symmetric(ptr(nbr), nbr.stride(0), F, M, ptr(flag), stream()), 'hpl_table_symmetric')
+    return flag
+
+
 def table_is_symmetric(nbr):
     """nbr[f, h] = g  =>  nbr[(F - f) % F, g] = h  (SURVEY.md fact 7).  One host sync."""
     F, H = nbr.shape
     if F != 15:
         return False
+    if nbr.is_cuda and nbr.dtype == torch.int32 and nbr.stride(1) == 1:
+        return bool(table_symmetry_flag(nbr).item())
     f = torch.arange(1, F, device=nbr.device)
     g = nbr[f].long()
     valid = g >= 0
@@ -293,9 +304,15 @@ class SliceFn(torch.autograd.Function):
         return gY, None, gb
 
 
+_MIRROR = {}
+
+
 def _mirror_map(F, device):
     # tap f of the forward table is tap (F - f) % F seen from the neighbour
-    return ((F - torch.arange(F, device=device)) % F).to(torch.int32)
+    key = (F, str(device))
+    if key not in _MIRROR:
+        _MIRROR[key] = ((F - torch.arange(F, device=device)) % F).to(torch.int32)
+    return _MIRROR[key]
 
 
 class GConvFn(torch.autograd.Function):

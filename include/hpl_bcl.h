@@ -193,6 +193,14 @@ int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStre
 /* dX = dY * (Y > 0 ? 1 : slope)   element-wise on [M][N] views (LeakyReLU backward) */
 int hpl_leaky_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, float slope,
                   float *dX, int64_t lddx, int64_t M, int N, hplStream stream);
+/* *flag (int32, DEVICE, set to 1 by the caller) is cleared unless the table is symmetric:
+ * nbr[0][m] == m and nbr[f][m] = g >= 0  =>  nbr[F-f][g] == m (f >= 1).  A symmetric blur / corr
+ * table lets the backward w.r.t. the features run as a gather with mirrored taps instead of
+ * fp32 atomics (true by construction unless the reference's unchecked key
+ * packing aliased a neighbour key, A.2).  Several tables can share one stream and be read back once. */
+int hpl_table_symmetric(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *flag,
+                        hplStream stream);
+
 /* dst[m*ldd + c] = src[c*lds + m]  (channel-first <-> channel-last at the API edge) */
 int hpl_transpose(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t rows_src,
                   int64_t cols_src, hplStream stream);
