@@ -106,6 +106,7 @@ class NbrTable(object):
         self.t = t
         self._sym = None
         self._perm = False      # False = not computed yet, None = not applicable
+        self._taps = False
 
     @property
     def perm(self):
@@ -114,6 +115,17 @@ class NbrTable(object):
             F, M = self.t.shape
             self._perm = ops.tap_order(self.t) if (1 < F <= 15 and M >= self.PERM_MIN_ROWS) else None
         return self._perm
+
+    #: per-tap vertex lists pay for wide layers only (wgrad tap mode needs C >= 128-ish) and big tables
+    TAPS_MIN_ROWS = 4096
+
+    def taps(self):
+        """(list, tap_ptr) of the present vertices of every tap (ops.tap_lists), built on first use
+        (training only: the weight gradient sums over present vertex-tap pairs)."""
+        if self._taps is False:
+            F, M = self.t.shape
+            self._taps = ops.tap_lists(self.t) if (1 < F <= 15 and M >= self.TAPS_MIN_ROWS) else None
+        return self._taps
 
     @property
     def symmetric(self):
@@ -260,7 +272,7 @@ def _run_conv_stack(x, stack, table, M, F, use_leaky, out=None):
             x = ops.gconv(x, conv.weight, conv.bias, table.t, M, F, act=act,
                           bwd_mode=table.bwd_mode(x.shape[0]) if torch.is_grad_enabled() else 'scatter',
                           out=o, slope=_slope(use_leaky),
-                          row_perm=table.perm)
+                          row_perm=table.perm, taps=table.taps if conv.in_channels >= 100 else None)
         else:
             x = ops.gconv(x, conv.weight, conv.bias, None, M, 1, act=act, bwd_mode='dense', out=o,
                           slope=_slope(use_leaky))

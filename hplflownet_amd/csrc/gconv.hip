@@ -657,31 +657,43 @@ struct WParams {
     const float *dY; int64_t lddy; int N;
     float *dWt; int64_t ldw;
     int tiles_n; int64_t m_per_split;
+    // tap mode: k tiles are (tap f, 128-channel block) and the vertex loop of tap f runs over its
+    // compacted list of present (vertex, source row) pairs tap_m / tap_row[tap_ptr[f] .. tap_ptr[f+1])
+    // (hpl_tap_lists)
+    const int32_t *tap_m; const int32_t *tap_row; const int32_t *tap_ptr; int c_tiles;
 };
 
-template <int BN, bool VEC>
-__global__ void __launch_bounds__(256) k_wgrad(const WParams p) {
+template <int BN, bool VEC, bool TAP, int NT = 256>
+__global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
     constexpr int BKR = 128;                 // rows of dWt per tile (flat k)
     constexpr int BMS = 32;                  // vertices per step
-    constexpr int WGM = 2, WGN = (BN >= 64) ? 2 : 1;
-    constexpr int WGM_EFF = (BN >= 64) ? 2 : 4;
+    // wave grid: 4 waves = 2x2 (BN >= 64) or 4x1; 8 waves (BN = 128 only) = 2x4
+    constexpr int WGN = (NT == 512) ? 4 : ((BN >= 64) ? 2 : 1);
+    constexpr int WGM_EFF = (NT / 64) / WGN;
     constexpr int WTM = BKR / WGM_EFF, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_F4 = BKR / 4;            // float4 per gathered row slice
-    constexpr int A_ROWS_PER_PASS = 256 / A_F4;
+    constexpr int A_ROWS_PER_PASS = NT / A_F4;
     constexpr int A_PASSES = BMS / A_ROWS_PER_PASS;
     constexpr int B_F4 = BN / 4;
-    constexpr int B_ROWS_PER_PASS = 256 / B_F4;
+    constexpr int B_ROWS_PER_PASS = NT / B_F4;
     constexpr int B_PASSES = (BMS + B_ROWS_PER_PASS - 1) / B_ROWS_PER_PASS;
-    (void)WGM;
+    static_assert(TM >= 1 && TN >= 1 && A_PASSES >= 1, "wave grid does not fit the tile");
     __shared__ __attribute__((aligned(16))) float smem[2 * BMS * BKR + 2 * BMS * BN];
     float *As = smem;
     float *Bs = smem + 2 * BMS * BKR;
 
     const int tile_k = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
-    const int k0 = tile_k * BKR, n0 = tile_n * BN;
+    const int n0 = tile_n * BN;
+    // TAP: [mb, me) indexes the tap's vertex list, c0_tile is the first channel of the block
+    const int tap = TAP ? tile_k / p.c_tiles : 0;
+    const int c0_tile = TAP ? (tile_k - tap * p.c_tiles) * BKR : 0;
+    const int k0 = TAP ? tap * p.C + c0_tile : tile_k * BKR;
+    const int32_t *vm = TAP ? p.tap_m + p.tap_ptr[tap] : nullptr;
+    const int32_t *vrow = TAP ? p.tap_row + p.tap_ptr[tap] : nullptr;
+    const int64_t m_total = TAP ? (int64_t)(p.tap_ptr[tap + 1] - p.tap_ptr[tap]) : p.M;
     const int64_t mb = (int64_t)blockIdx.y * p.m_per_split;
-    const int64_t me = imin(p.M, mb + p.m_per_split);
+    const int64_t me = imin(m_total, mb + p.m_per_split);
     if (mb >= me) return;
 
     const int t = threadIdx.x, lane = t & 63;
@@ -691,21 +703,43 @@ __global__ void __launch_bounds__(256) k_wgrad(const WParams p) {
 
     const int ak4 = t % A_F4, arow0 = t / A_F4;
     const int kk = k0 + ak4 * 4;                          // fixed flat k of this thread's float4
-    const int f_t = kk / p.C, c_t = kk - f_t * p.C;
-    const bool k_ok = kk < p.K;
+    const int f_t = TAP ? tap : kk / p.C, c_t = kk - f_t * p.C;
+    const bool k_ok = TAP ? (c_t < p.C) : (kk < p.K);
     const int bn4 = t % B_F4, brow0 = t / B_F4;
 
     float4 ra[A_PASSES], rb[B_PASSES];
-    auto load_regs = [&](int64_t ms) {
+    // Indices of a step are fetched one step before its data (source row of every gathered A row,
+    // vertex of every dY row): the data loads of step s+1 and the index loads of step s+2 are in
+    // flight while step s is multiplied.
+    int rowi[A_PASSES], mi[B_PASSES];
+    auto load_idx = [&](int64_t ms) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
-            const int64_t m = ms + arow0 + i * A_ROWS_PER_PASS;
+            const int64_t j = ms + arow0 + i * A_ROWS_PER_PASS;
+            int row = -1;
+            if (j < me && k_ok) {
+                if (TAP) row = vrow[j];
+                else if (VEC) row = p.nbr ? p.nbr[(int64_t)f_t * p.nbr_stride + j] : (int)((int64_t)f_t * p.reg_stride + j);
+                else row = 0;       // scalar path resolves rows per element below
+            }
+            rowi[i] = row;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int r = brow0 + i * B_ROWS_PER_PASS;
+            const int64_t j = ms + r;
+            mi[i] = (r < BMS && j < me) ? (TAP ? vm[j] : (int)j) : -1;
+        }
+    };
+    auto load_data = [&](int64_t ms) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < me && k_ok) {
+            if (rowi[i] >= 0) {
                 if (VEC) {
-                    int64_t row = p.nbr ? (int64_t)p.nbr[(int64_t)f_t * p.nbr_stride + m] : (int64_t)f_t * p.reg_stride + m;
-                    if (row >= 0) v = *reinterpret_cast<const float4 *>(p.A + row * p.lda + c_t);
+                    v = *reinterpret_cast<const float4 *>(p.A + (int64_t)rowi[i] * p.lda + c_t);
                 } else {
+                    const int64_t m = ms + arow0 + i * A_ROWS_PER_PASS;
                     float e[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -724,11 +758,10 @@ __global__ void __launch_bounds__(256) k_wgrad(const WParams p) {
         }
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
-            const int r = brow0 + i * B_ROWS_PER_PASS;
-            const int64_t m = ms + r;
+            const int64_t m = mi[i];
             const int col = n0 + bn4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < BMS && m < me) {
+            if (m >= 0) {
                 if (VEC && col + 3 < p.N) v = *reinterpret_cast<const float4 *>(p.dY + m * p.lddy + col);
                 else {
                     float e[4];
@@ -760,13 +793,16 @@ __global__ void __launch_bounds__(256) k_wgrad(const WParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int64_t nsteps = (me - mb + BMS - 1) / BMS;
-    load_regs(mb);
+    load_idx(mb);
+    load_data(mb);
+    if (nsteps > 1) load_idx(mb + BMS);
     store_lds(0);
     __syncthreads();
     int cur = 0;
     for (int64_t st = 0; st < nsteps; ++st) {
         const bool more = st + 1 < nsteps;
-        if (more) load_regs(mb + (st + 1) * BMS);
+        if (more) load_data(mb + (st + 1) * BMS);
+        if (st + 2 < nsteps) load_idx(mb + (st + 2) * BMS);
         const float *a = As + cur * BMS * BKR + wm * WTM + li;
         const float *b = Bs + cur * BMS * BN + wn * WTN + li;
 #pragma unroll
@@ -794,8 +830,9 @@ __global__ void __launch_bounds__(256) k_wgrad(const WParams p) {
             if (n >= p.N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = k0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (k < p.K) atomicAdd(p.dWt + (int64_t)k * p.ldw + n, acc[i][j][r]);
+                const int kr = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;   // row inside the tile
+                const int k = k0 + kr;
+                if (TAP ? (c0_tile + kr < p.C) : (k < p.K)) atomicAdd(p.dWt + (int64_t)k * p.ldw + n, acc[i][j][r]);
             }
         }
 }
@@ -804,28 +841,50 @@ __global__ void __launch_bounds__(256) k_wgrad(const WParams p) {
 extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, const int32_t *nbr,
                                int64_t nbr_stride, int64_t reg_stride, int64_t M, int C, int F,
                                const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
-                               hplStream stream) {
+                               const int32_t *tap_m, const int32_t *tap_row, const int32_t *tap_ptr,
+                               int64_t tap_max, hplStream stream) {
     (void)rows_a;
     HPL_REQUIRE(A && dY && dWt, "hpl_gconv_wgrad: null pointer");
     HPL_REQUIRE(M >= 0 && C > 0 && F > 0 && N > 0 && lda >= C && lddy >= N && ldw >= N,
                 "hpl_gconv_wgrad: bad sizes");
     HPL_REQUIRE(nbr || F == 1 || reg_stride > 0, "hpl_gconv_wgrad: F > 1 needs a table or reg_stride");
+    HPL_REQUIRE(nbr || (int64_t)F * reg_stride + M < (int64_t)INT32_MAX, "hpl_gconv_wgrad: regular table too large");
     if (M == 0) return HPL_OK;
     WParams p;
     p.A = A; p.lda = lda; p.nbr = nbr; p.nbr_stride = nbr_stride; p.reg_stride = reg_stride;
     p.M = M; p.C = C; p.F = F; p.K = F * C; p.dY = dY; p.lddy = lddy; p.N = N; p.dWt = dWt; p.ldw = ldw;
     const bool vec = (C % 4 == 0) && (lda % 4 == 0) && (lddy % 4 == 0) && aligned16(A) && aligned16(dY);
     const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
-    const int tiles_k = (int)cdiv(p.K, 128);
+    // Tap mode (per-tap lists of present vertices given, wide layers): k tiles are aligned to taps so
+    // that a tile walks only the vertices whose tap is present -- exact skipping of absent neighbours
+    // (42 % / 72 % of the vertex-tap pairs exist at levels 0 / 1).  It pads C to a multiple of 128,
+    // so it is used when that costs < 25 %.
+    const int c_tiles = (int)cdiv(C, 128);
+    const bool tap = tap_m && tap_row && tap_ptr && nbr && vec && F > 1 && tap_max > 0 && c_tiles * 128 * 4 <= C * 5;
+    p.tap_m = tap ? tap_m : nullptr;
+    p.tap_row = tap ? tap_row : nullptr;
+    p.tap_ptr = tap ? tap_ptr : nullptr;
+    p.c_tiles = c_tiles;
+    const int tiles_k = tap ? F * c_tiles : (int)cdiv(p.K, 128);
+    const int64_t m_len = tap ? tap_max : M;                 // longest vertex loop of a tile
     p.tiles_n = (int)cdiv(N, bn);
     const int tiles = tiles_k * p.tiles_n;
     // split the vertex axis so that ~4 workgroups per CU exist, each with >= 256 vertices
-    int64_t splits = imax(1, imin(cdiv(1024, tiles), cdiv(M, 256)));
-    p.m_per_split = cdiv(cdiv(M, splits), 32) * 32;
-    splits = cdiv(M, p.m_per_split);
+    int64_t splits = imax(1, imin(cdiv(1024, tiles), cdiv(m_len, 256)));
+    p.m_per_split = cdiv(cdiv(m_len, splits), 32) * 32;
+    splits = cdiv(m_len, p.m_per_split);
     dim3 grid(tiles, (unsigned)splits);
     hipStream_t s = to_stream(stream);
-#define LAUNCH(BN_) (vec ? k_wgrad<BN_, true><<<grid, 256, 0, s>>>(p) : k_wgrad<BN_, false><<<grid, 256, 0, s>>>(p))
+#define LAUNCH(BN_)                                                          \
+    do {                                                                     \
+        if (tap) k_wgrad<BN_, true, true><<<grid, 256, 0, s>>>(p);           \
+        else if (vec) k_wgrad<BN_, true, false><<<grid, 256, 0, s>>>(p);     \
+        else k_wgrad<BN_, false, false><<<grid, 256, 0, s>>>(p);             \
+    } while (0)
+    if (bn == 128 && vec) {     // 8 waves (2x4): 4 waves per SIMD, 2-5 % over 4 waves
+        if (tap) k_wgrad<128, true, true, 512><<<grid, 512, 0, s>>>(p);
+        else k_wgrad<128, true, false, 512><<<grid, 512, 0, s>>>(p);
+    } else
     if (bn == 128) LAUNCH(128); else if (bn == 64) LAUNCH(64); else LAUNCH(32);
 #undef LAUNCH
     HPL_CHECK_LAUNCH("hpl_gconv_wgrad");

@@ -431,6 +431,67 @@ extern "C" int hpl_tap_order(const int32_t *nbr, int64_t nbr_stride, int F, int6
     return HPL_OK;
 }
 
+// ---------------------------------------------------------------- per-tap vertex lists
+// list_m / list_row[tap_ptr[f] .. tap_ptr[f+1]) = the vertices m with nbr[f][m] >= 0 (ascending,
+// deterministic) and their source rows nbr[f][m].
+// Chunks of 1024 vertices per workgroup: count -> scan of the F x chunks counts -> fill.
+constexpr int TL_CHUNK = 1024;
+
+__global__ void __launch_bounds__(256) k_taplist_count(const int32_t *__restrict__ nbr, int64_t stride, int64_t M,
+                                                       int nb, int32_t *__restrict__ cnt) {
+    const int b = blockIdx.x, f = blockIdx.y;
+    const int64_t m0 = (int64_t)b * TL_CHUNK + threadIdx.x * 4;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c += (m0 + j < M && nbr[(int64_t)f * stride + m0 + j] >= 0) ? 1 : 0;
+    int total;
+    block_exclusive_scan_256(c, &total);
+    if (threadIdx.x == 0) cnt[f * nb + b] = total;
+}
+
+__global__ void __launch_bounds__(256) k_taplist_fill(const int32_t *__restrict__ nbr, int64_t stride, int F,
+                                                      int64_t M, int nb, const int32_t *__restrict__ off,
+                                                      int32_t *__restrict__ list_m, int32_t *__restrict__ list_row,
+                                                      int32_t *__restrict__ tap_ptr) {
+    const int b = blockIdx.x, f = blockIdx.y;
+    const int64_t m0 = (int64_t)b * TL_CHUNK + threadIdx.x * 4;
+    int32_t row[4];
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        row[j] = (m0 + j < M) ? nbr[(int64_t)f * stride + m0 + j] : -1;
+        c += row[j] >= 0 ? 1 : 0;
+    }
+    int pos = off[f * nb + b] + block_exclusive_scan_256(c, nullptr);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (row[j] >= 0) {
+            list_m[pos] = (int32_t)(m0 + j);
+            list_row[pos] = row[j];
+            ++pos;
+        }
+    if (b == 0 && threadIdx.x == 0) {
+        tap_ptr[f] = off[f * nb];
+        if (f == F - 1) tap_ptr[F] = off[F * nb];
+    }
+}
+
+extern "C" int hpl_tap_lists(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *list_m,
+                             int32_t *list_row, int32_t *tap_ptr, int32_t *scratch, hplStream stream) {
+    HPL_REQUIRE(nbr && list_m && list_row && tap_ptr && scratch && F >= 1 && F <= 64 && M > 0 && nbr_stride >= M &&
+                    (int64_t)F * M < (int64_t)INT32_MAX,
+                "hpl_tap_lists: bad arguments (F=%d M=%lld)", F, (long long)M);
+    hipStream_t s = to_stream(stream);
+    const int nb = (int)cdiv(M, TL_CHUNK);
+    int32_t *cnt = scratch, *off = cnt + (int64_t)F * nb, *tmp = off + (int64_t)F * nb + 1;
+    k_taplist_count<<<dim3(nb, F), 256, 0, s>>>(nbr, nbr_stride, M, nb, cnt);
+    int rc = exclusive_scan_i32(cnt, (int64_t)F * nb, off, tmp, s);
+    if (rc != HPL_OK) return rc;
+    k_taplist_fill<<<dim3(nb, F), 256, 0, s>>>(nbr, nbr_stride, F, M, nb, off, list_m, list_row, tap_ptr);
+    HPL_CHECK_LAUNCH("hpl_tap_lists");
+    return HPL_OK;
+}
+
 // ---------------------------------------------------------------- table symmetry
 // flag[0] &= (nbr[0][m] == m) and (nbr[f][m] = g >= 0  =>  g < M and nbr[F-f][g] == m) for all m, f >= 1
 // (holds by construction unless an unchecked key packing aliased, A.2 quirk).

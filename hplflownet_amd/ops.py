@@ -117,6 +117,19 @@ def tap_order(nbr):
     return perm
 
 
+def tap_lists(nbr):
+    """int32 [F, M] table -> (list_m, list_row int32 [F*M], tap_ptr int32 [F+1]): the present vertices of
+    every tap and their source rows."""
+    F, M = nbr.shape
+    lm = torch.empty(F * M, dtype=torch.int32, device=nbr.device)
+    lr = torch.empty(F * M, dtype=torch.int32, device=nbr.device)
+    tp = torch.empty(F + 1, dtype=torch.int32, device=nbr.device)
+    scratch = torch.empty(2 * F * ((M + 1023) // 1024) + 1100, dtype=torch.int32, device=nbr.device)
+    check(_lib.load().hpl_tap_lists(ptr(nbr), nbr.stride(0), F, M, ptr(lm), ptr(lr), ptr(tp), ptr(scratch),
+                                    stream()), 'hpl_tap_lists')
+    return lm, lr, tp
+
+
 def table_symmetry_flag(nbr):
     """Launch the symmetry check of an int32 [F, M] table; -> int32 device tensor [1] (1 = symmetric).
     No host sync: read several flags back together (DeviceLattice.resolve_symmetry)."""
@@ -243,12 +256,15 @@ def _splitk_workspace(device):
     return ws
 
 
-def wgrad_raw(A, nbr, M, C, F, dY, N):
-    """-> dWt [roundup(F*C,32), roundup(N,4)] = sum_m A[nbr[f,m], c] * dY[m, n]."""
+def wgrad_raw(A, nbr, M, C, F, dY, N, taps=None):
+    """-> dWt [roundup(F*C,32), roundup(N,4)] = sum_m A[nbr[f,m], c] * dY[m, n].
+    taps = tap_lists(nbr): sum over the present vertices of each tap only (wide layers)."""
     A, dY = _cl(A), _cl(dY, 'dY')
     dWt = torch.zeros((round_up(F * C, 32), round_up(N, 4)), dtype=torch.float32, device=A.device)
+    tl, tr, tp = taps if (taps is not None and nbr is not None) else (None, None, None)
     check(_lib.load().hpl_gconv_wgrad(ptr(A), _ld(A), A.shape[0], ptr(nbr), nbr.stride(0) if nbr is not None else 0,
-                                      0, M, C, F, ptr(dY), _ld(dY), N, ptr(dWt), dWt.shape[1], stream()),
+                                      0, M, C, F, ptr(dY), _ld(dY), N, ptr(dWt), dWt.shape[1], ptr(tl), ptr(tr), ptr(tp),
+                                      M if tl is not None else 0, stream()),
           'hpl_gconv_wgrad')
     return dWt
 
@@ -323,7 +339,8 @@ class GConvFn(torch.autograd.Function):
               'scatter' (any table: fp32 atomics), 'dense' (no table)."""
 
     @staticmethod
-    def forward(ctx, A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm=None):
+    def forward(ctx, A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm=None,
+                taps=None):
         O = weight.shape[0]
         Ctot = weight.numel() // (O * F)
         Wt = weight_relayout(weight, C, O, F, F, Ctot * F, 1, base=c0 * F)
@@ -331,6 +348,7 @@ class GConvFn(torch.autograd.Function):
                       row_perm=row_perm)
         ctx.slope = slope
         ctx.row_perm = row_perm      # same table in the mirror backward -> same tap masks -> same order
+        ctx.taps = taps
         ctx.save_for_backward(A, weight, nbr, Y if act != ACT_NONE else None)
         ctx.cfg = (M, c0, C, F, act, res is not None, res_mod, bwd_mode, bias is not None, Ctot)
         return Y
@@ -367,7 +385,7 @@ class GConvFn(torch.autograd.Function):
                 gA = torch.zeros_like(A)
                 gA[:, :C] = gA_c
         if ctx.needs_input_grad[1]:
-            dWt = wgrad_raw(A, nbr, M, C, F, g, O)
+            dWt = wgrad_raw(A, nbr, M, C, F, g, O, taps=ctx.taps)
             gW = torch.zeros_like(weight)
             check(_lib.load().hpl_weight_unlayout(ptr(dWt), dWt.shape[1], C, O, F, ptr(gW), c0 * F, F, Ctot * F, 1,
                                                   0, stream()), 'hpl_weight_unlayout')
@@ -378,18 +396,19 @@ class GConvFn(torch.autograd.Function):
                 gres = g.view(M // res_mod, res_mod, O).sum(dim=0)
             else:
                 gres = g
-        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None, None
+        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None, None, None
 
 
 def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_mod=0, bwd_mode='scatter',
-          out=None, slope=LEAKY_RATE, row_perm=None):
+          out=None, slope=LEAKY_RATE, row_perm=None, taps=None):
     """Autograd-aware gathered convolution; with grad disabled it can write into `out`."""
     O = weight.shape[0]
     Ctot = weight.numel() // (O * F)
     C = Ctot if C is None else C
     if torch.is_grad_enabled() and (A.requires_grad or weight.requires_grad or
                                     (res is not None and res.requires_grad)):
-        y = GConvFn.apply(A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm)
+        y = GConvFn.apply(A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm,
+                          taps() if callable(taps) else taps)
         if out is not None:
             out.copy_(y)
             return out

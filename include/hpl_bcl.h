@@ -178,11 +178,14 @@ int hpl_gconv_forward(const hpl_gconv_desc *desc /* HOST */, hplStream stream);
 int hpl_gconv_forward_naive(const hpl_gconv_desc *desc /* HOST */, hplStream stream);
 
 /* dWt[f*C + c, n] (+)= sum_m A[nbr[f][m], c] * dY[m, n]    (weight gradient; split over m
- * with fp32 atomics, so dWt must be zero-initialised by the caller unless accumulating) */
+ * with fp32 atomics, so dWt must be zero-initialised by the caller unless accumulating).
+ * tap_m / tap_row / tap_ptr (optional, from hpl_tap_lists; tap_max = longest list, M if the
+ * centre tap is always present): the sum of tap f then runs over its present vertices only. */
 int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, const int32_t *nbr,
                     int64_t nbr_stride, int64_t reg_stride, int64_t M, int C, int F,
                     const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
-                    hplStream stream);
+                    const int32_t *tap_m, const int32_t *tap_row, const int32_t *tap_ptr,
+                    int64_t tap_max, hplStream stream);
 
 /* Diagnostic: `blocks` workgroups of 4 waves each issue iters*64 v_mfma_f32_32x32x2_f32 per wave
  * with no memory traffic; out needs blocks*256 floats.  flops = blocks*4*iters*64*4096. */
@@ -193,6 +196,13 @@ int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStre
 /* dX = dY * (Y > 0 ? 1 : slope)   element-wise on [M][N] views (LeakyReLU backward) */
 int hpl_leaky_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, float slope,
                   float *dX, int64_t lddx, int64_t M, int N, hplStream stream);
+/* Per-tap lists of present vertices: list_m[tap_ptr[f] .. tap_ptr[f+1]) = { m : nbr[f][m] >= 0 }
+ * ascending, list_row = their source rows nbr[f][m]; both hold up to F*M entries, tap_ptr F+1
+ * (DEVICE).  scratch: 2*F*ceil(M/1024) + 1100 int32.  Consumer: hpl_gconv_wgrad (exact skipping
+ * of absent neighbours, indices prefetched as plain streams). */
+int hpl_tap_lists(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *list_m,
+                  int32_t *list_row, int32_t *tap_ptr, int32_t *scratch, hplStream stream);
+
 /* *flag (int32, DEVICE, set to 1 by the caller) is cleared unless the table is symmetric:
  * nbr[0][m] == m and nbr[f][m] = g >= 0  =>  nbr[F-f][g] == m (f >= 1).  A symmetric blur / corr
  * table lets the backward w.r.t. the features run as a gather with mirrored taps instead of

@@ -219,6 +219,37 @@ def test_wgrad_colsum_leaky(ops, M, rows, C, F, O):
     assert np.array_equal(got, dY * np.where(Y > 0, np.float32(1), np.float32(0.1)))
 
 
+@pytest.mark.parametrize('M,rows,C,F,O,density', [(6000, 6000, 260, 15, 128, 0.4), (5000, 4000, 128, 15, 40, 0.7),
+                                                  (2500, 2500, 580, 15, 96, 0.1)])
+def test_tap_lists_and_wgrad_tap_mode(ops, M, rows, C, F, O, density):
+    """Per-tap lists of present vertices (hpl_tap_lists) and the weight gradient summed over them
+    (tap-aligned k tiles): same result as the full vertex loop and as float64."""
+    rng = np.random.RandomState(C + M)
+    A = rng.randn(rows, C).astype(np.float32)
+    nbr = np.where(rng.rand(F, M) < density, rng.randint(0, rows, size=(F, M)), -1).astype(np.int32)
+    nbr[0] = np.arange(M) % rows                                     # centre tap always present
+    if F * M > 3:
+        nbr[3, :] = -1                                               # an empty tap
+    dY = rng.randn(M, O).astype(np.float32)
+    dn = dev(nbr)
+    lst, lrow, tp = ops.tap_lists(dn)
+    tp_h = tp.cpu().numpy()
+    cnt = (nbr >= 0).sum(1)
+    assert np.array_equal(tp_h, np.concatenate([[0], np.cumsum(cnt)]))
+    lst_h, lrow_h = lst.cpu().numpy(), lrow.cpu().numpy()
+    for f in range(F):
+        present = np.nonzero(nbr[f] >= 0)[0]
+        assert np.array_equal(lst_h[tp_h[f]:tp_h[f + 1]], present)
+        assert np.array_equal(lrow_h[tp_h[f]:tp_h[f + 1]], nbr[f][present])
+    got = ops.wgrad_raw(dev(A), dn, M, C, F, dev(dY), O, taps=(lst, lrow, tp)).cpu().numpy()
+    full = ops.wgrad_raw(dev(A), dn, M, C, F, dev(dY), O).cpu().numpy()
+    Ap = np.concatenate([A.astype(np.float64), np.zeros((1, C))], 0)
+    want = np.einsum('fmc,mo->fco', Ap[nbr], dY.astype(np.float64)).reshape(F * C, O)
+    assert rel_err(got[:F * C, :O], want) < 2e-5
+    assert rel_err(got, full) < 2e-5
+    assert not got[F * C:].any() and not got[:, O:].any()
+
+
 def test_gconv_scatter_epilogue(ops):
     rng = np.random.RandomState(11)
     M, rows, O, F, C = 400, 300, 32, 15, 16
