@@ -52,7 +52,7 @@ _SIGNATURES = {
     'hpl_gconv_forward': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
     'hpl_gconv_forward_naive': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
     'hpl_gconv_wgrad': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,
-                                       c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+                                       c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     'hpl_tap_lists': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'hpl_mfma_probe': (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp]),
     'hpl_colsum': (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),

@@ -11,6 +11,9 @@ namespace hpl {
 
 void set_error(const char *fmt, ...);
 
+// out[n] += sum_m X[m*ld + n] (index_ops.hip); `out` is NOT zeroed
+void colsum_accumulate(const float *X, int64_t ld, int64_t M, int N, float *out, hipStream_t s);
+
 inline hipStream_t to_stream(hplStream s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -661,6 +661,7 @@ struct WParams {
     // compacted list of present (vertex, source row) pairs tap_m / tap_row[tap_ptr[f] .. tap_ptr[f+1])
     // (hpl_tap_lists)
     const int32_t *tap_m; const int32_t *tap_row; const int32_t *tap_ptr; int c_tiles;
+    float *dbias;        // optional: dbias[n] += sum_m dY[m, n] (by the k-tile-0 workgroups; not in tap mode)
 };
 
 template <int BN, bool VEC, bool TAP, int NT = 256>
@@ -712,6 +713,8 @@ __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
     // vertex of every dY row): the data loads of step s+1 and the index loads of step s+2 are in
     // flight while step s is multiplied.
     int rowi[A_PASSES], mi[B_PASSES];
+    const bool do_bias = !TAP && p.dbias != nullptr && tile_k == 0;      // workgroup-uniform
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_idx = [&](int64_t ms) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
@@ -771,6 +774,7 @@ __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
                 }
             }
             rb[i] = v;
+            if (!TAP && do_bias) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
         }
     };
     auto store_lds = [&](int buf) {
@@ -822,6 +826,24 @@ __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
         __syncthreads();
         cur ^= 1;
     }
+    if (!TAP && do_bias) {
+        // column sums of this workgroup's dY slab: threads with the same float4 column combine in LDS
+        float4 *red = reinterpret_cast<float4 *>(As);     // the last step's barrier has passed
+        red[t] = bsum;
+        __syncthreads();
+        if (t < B_F4) {
+            float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < NT / B_F4; ++r) {
+                const float4 v = red[t + r * B_F4];
+                sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+            }
+            const int col = n0 + t * 4;
+            if (col + 0 < p.N) atomicAdd(p.dbias + col + 0, sacc.x);
+            if (col + 1 < p.N) atomicAdd(p.dbias + col + 1, sacc.y);
+            if (col + 2 < p.N) atomicAdd(p.dbias + col + 2, sacc.z);
+            if (col + 3 < p.N) atomicAdd(p.dbias + col + 3, sacc.w);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -842,7 +864,7 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
                                int64_t nbr_stride, int64_t reg_stride, int64_t M, int C, int F,
                                const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
                                const int32_t *tap_m, const int32_t *tap_row, const int32_t *tap_ptr,
-                               int64_t tap_max, hplStream stream) {
+                               int64_t tap_max, float *dbias, hplStream stream) {
     (void)rows_a;
     HPL_REQUIRE(A && dY && dWt, "hpl_gconv_wgrad: null pointer");
     HPL_REQUIRE(M >= 0 && C > 0 && F > 0 && N > 0 && lda >= C && lddy >= N && ldw >= N,
@@ -865,6 +887,8 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
     p.tap_row = tap ? tap_row : nullptr;
     p.tap_ptr = tap ? tap_ptr : nullptr;
     p.c_tiles = c_tiles;
+    p.dbias = tap ? nullptr : dbias;
+    if (tap && dbias) colsum_accumulate(dY, lddy, M, N, dbias, to_stream(stream));
     const int tiles_k = tap ? F * c_tiles : (int)cdiv(p.K, 128);
     const int64_t m_len = tap ? tap_max : M;                 // longest vertex loop of a tile
     p.tiles_n = (int)cdiv(N, bn);

@@ -344,14 +344,19 @@ __global__ void k_zero_f32(float *p, int64_t n) {
     if (i < n) p[i] = 0.f;
 }
 
+namespace hpl {
+void colsum_accumulate(const float *X, int64_t ld, int64_t M, int N, float *out, hipStream_t s) {
+    if (M <= 0) return;
+    const int64_t rpb = 256;
+    k_colsum<<<dim3((unsigned)cdiv(M, rpb), (unsigned)cdiv(N, 64)), 256, 0, s>>>(X, ld, M, N, rpb, out);
+}
+}  // namespace hpl
+
 extern "C" int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStream stream) {
     HPL_REQUIRE(X && out && M >= 0 && N > 0, "hpl_colsum: bad arguments");
     hipStream_t s = to_stream(stream);
     k_zero_f32<<<(int)cdiv(N, 256), 256, 0, s>>>(out, N);
-    if (M > 0) {
-        const int64_t rpb = 256;
-        k_colsum<<<dim3((unsigned)cdiv(M, rpb), (unsigned)cdiv(N, 64)), 256, 0, s>>>(X, ld, M, N, rpb, out);
-    }
+    colsum_accumulate(X, ld, M, N, out, s);
     HPL_CHECK_LAUNCH("hpl_colsum");
     return HPL_OK;
 }

@@ -256,17 +256,21 @@ def _splitk_workspace(device):
     return ws
 
 
-def wgrad_raw(A, nbr, M, C, F, dY, N, taps=None):
-    """-> dWt [roundup(F*C,32), roundup(N,4)] = sum_m A[nbr[f,m], c] * dY[m, n].
+def wgrad_raw(A, nbr, M, C, F, dY, N, taps=None, want_bias=False):
+    """-> dWt [roundup(F*C,32), roundup(N,4)] = sum_m A[nbr[f,m], c] * dY[m, n]  (and, with want_bias,
+    the bias gradient sum_m dY[m, :] from the same launch).
     taps = tap_lists(nbr): sum over the present vertices of each tap only (wide layers)."""
     A, dY = _cl(A), _cl(dY, 'dY')
-    dWt = torch.zeros((round_up(F * C, 32), round_up(N, 4)), dtype=torch.float32, device=A.device)
+    kp, ldw = round_up(F * C, 32), round_up(N, 4)
+    buf = torch.zeros(kp * ldw + (ldw if want_bias else 0), dtype=torch.float32, device=A.device)
+    dWt = buf[:kp * ldw].view(kp, ldw)
+    gb = buf[kp * ldw:kp * ldw + N] if want_bias else None
     tl, tr, tp = taps if (taps is not None and nbr is not None) else (None, None, None)
     check(_lib.load().hpl_gconv_wgrad(ptr(A), _ld(A), A.shape[0], ptr(nbr), nbr.stride(0) if nbr is not None else 0,
-                                      0, M, C, F, ptr(dY), _ld(dY), N, ptr(dWt), dWt.shape[1], ptr(tl), ptr(tr), ptr(tp),
-                                      M if tl is not None else 0, stream()),
+                                      0, M, C, F, ptr(dY), _ld(dY), N, ptr(dWt), ldw, ptr(tl), ptr(tr), ptr(tp),
+                                      M if tl is not None else 0, ptr(gb), stream()),
           'hpl_gconv_wgrad')
-    return dWt
+    return (dWt, gb) if want_bias else dWt
 
 
 def colsum(X):
@@ -384,12 +388,16 @@ class GConvFn(torch.autograd.Function):
             else:
                 gA = torch.zeros_like(A)
                 gA[:, :C] = gA_c
+        want_gb = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dWt = wgrad_raw(A, nbr, M, C, F, g, O, taps=ctx.taps)
-            gW = torch.zeros_like(weight)
+            dWt = wgrad_raw(A, nbr, M, C, F, g, O, taps=ctx.taps, want_bias=want_gb)
+            if want_gb:
+                dWt, gb = dWt
+            # the un-layout writes every element of the channel range: zeros only for partial ranges
+            gW = torch.empty_like(weight) if (c0 == 0 and C == Ctot) else torch.zeros_like(weight)
             check(_lib.load().hpl_weight_unlayout(ptr(dWt), dWt.shape[1], C, O, F, ptr(gW), c0 * F, F, Ctot * F, 1,
                                                   0, stream()), 'hpl_weight_unlayout')
-        if has_bias and ctx.needs_input_grad[2]:
+        elif want_gb:
             gb = colsum(g)
         if has_res and ctx.needs_input_grad[9]:
             if res_mod and res_mod != M:

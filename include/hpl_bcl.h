@@ -180,12 +180,14 @@ int hpl_gconv_forward_naive(const hpl_gconv_desc *desc /* HOST */, hplStream str
 /* dWt[f*C + c, n] (+)= sum_m A[nbr[f][m], c] * dY[m, n]    (weight gradient; split over m
  * with fp32 atomics, so dWt must be zero-initialised by the caller unless accumulating).
  * tap_m / tap_row / tap_ptr (optional, from hpl_tap_lists; tap_max = longest list, M if the
- * centre tap is always present): the sum of tap f then runs over its present vertices only. */
+ * centre tap is always present): the sum of tap f then runs over its present vertices only.
+ * dbias (optional, [N], zero-initialised by the caller): dbias[n] += sum_m dY[m, n], the bias
+ * gradient, from the dY tiles the kernel loads anyway. */
 int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, const int32_t *nbr,
                     int64_t nbr_stride, int64_t reg_stride, int64_t M, int C, int F,
                     const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
                     const int32_t *tap_m, const int32_t *tap_row, const int32_t *tap_ptr,
-                    int64_t tap_max, hplStream stream);
+                    int64_t tap_max, float *dbias, hplStream stream);
 
 /* Diagnostic: `blocks` workgroups of 4 waves each issue iters*64 v_mfma_f32_32x32x2_f32 per wave
  * with no memory traffic; out needs blocks*256 floats.  flops = blocks*4*iters*64*4096. */

@@ -207,7 +207,9 @@ def test_wgrad_colsum_leaky(ops, M, rows, C, F, O):
     A = rng.randn(rows, C).astype(np.float32)
     nbr = rng.randint(-1, rows, size=(F, M)).astype(np.int32) if F > 1 else None
     dY = rng.randn(M, O).astype(np.float32)
-    dWt = ops.wgrad_raw(dev(A), dev(nbr) if nbr is not None else None, M, C, F, dev(dY), O).cpu().numpy()
+    dWt, gb = ops.wgrad_raw(dev(A), dev(nbr) if nbr is not None else None, M, C, F, dev(dY), O, want_bias=True)
+    assert rel_err(gb.cpu().numpy(), dY.astype(np.float64).sum(0)) < 2e-5      # bias gradient from the same launch
+    dWt = dWt.cpu().numpy()
     Ap = np.concatenate([A.astype(np.float64), np.zeros((1, C))], 0)
     X = Ap[nbr] if nbr is not None else Ap[:M][None]                 # (F, M, C)
     want = np.einsum('fmc,mo->fco', X, dY.astype(np.float64)).reshape(F * C, O)
@@ -241,7 +243,9 @@ def test_tap_lists_and_wgrad_tap_mode(ops, M, rows, C, F, O, density):
         present = np.nonzero(nbr[f] >= 0)[0]
         assert np.array_equal(lst_h[tp_h[f]:tp_h[f + 1]], present)
         assert np.array_equal(lrow_h[tp_h[f]:tp_h[f + 1]], nbr[f][present])
-    got = ops.wgrad_raw(dev(A), dn, M, C, F, dev(dY), O, taps=(lst, lrow, tp)).cpu().numpy()
+    got, gb = ops.wgrad_raw(dev(A), dn, M, C, F, dev(dY), O, taps=(lst, lrow, tp), want_bias=True)
+    assert rel_err(gb.cpu().numpy(), dY.astype(np.float64).sum(0)) < 2e-5
+    got = got.cpu().numpy()
     full = ops.wgrad_raw(dev(A), dn, M, C, F, dev(dY), O).cpu().numpy()
     Ap = np.concatenate([A.astype(np.float64), np.zeros((1, C))], 0)
     want = np.einsum('fmc,mo->fco', Ap[nbr], dY.astype(np.float64)).reshape(F * C, O)
