@@ -1,0 +1,225 @@
+"""Train / evaluate driver for the HIP hot path.
+
+Own counterpart of the reference's loops (/root/reference/main.py:95-286) and checkpoint helpers
+(/root/reference/main_utils.py:54-64), reduced to what drives the bilateral layers:
+
+* loss `EPE3DLoss` = mean_n ||flow_n - sf_n||_2 (main.py:213, models/epe3d_loss.py:9-10);
+* Adam(lr=1e-4, weight_decay=0) over all parameters (main.py:138-140).  The reference's
+  `adjust_learning_rate` computes a decayed rate and then resets every group to `args.lr`
+  (main_utils.py:14-30), i.e. the rate is constant; so it is here;
+* checkpoint dict {'epoch' (next start epoch), 'arch', 'state_dict', 'min_loss', 'optimizer'}
+  written as checkpoint.pth.tar, copied to checkpoint_<epoch>.pth.tar when epoch % 10 == 1 and to
+  model_best.pth.tar when best (main.py:183-189, main_utils.py:54-64).  The reference saves the
+  state_dict of a DataParallel wrapper, so keys carry a 'module.' prefix; it is written (and
+  accepted on load, see flownet.load_reference_checkpoint) so files are interchangeable;
+* metrics EPE3D / Acc3D strict / Acc3D relax / outliers (evaluation_utils.py:4-19), on the device.
+
+What is new relative to the reference: the permutohedral lattice of pair i+1 is built on the GPU
+on a second HIP stream while pair i trains (the reference builds it in DataLoader worker
+processes on the CPU), and with world_size > 1 every rank trains its own pair and the gradients
+are averaged with one bucketed all-reduce over RCCL (parallel.GradAllReducer) -- mean loss over
+the global batch, as `.mean()` over a batch would give.
+
+    python -m hplflownet_amd.engine --arch HPLFlowNet --points 8192 --pairs 8 --epochs 1 --ckpt-dir /tmp/ck
+    python -m hplflownet_amd.engine --evaluate --resume /tmp/ck/model_best.pth.tar --pairs 4
+"""
+import argparse
+import collections
+import os
+import shutil
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import parallel
+from .flownet import HPLFlowNet, HPLFlowNetShallow, load_reference_checkpoint
+from .lattice import GenerateDataUnsymmetric
+from .synthetic import SCALES_FILTER_MAP, fill_module_, synthetic_pair
+
+ARCHS = {'HPLFlowNet': (HPLFlowNet, 7), 'HPLFlowNetShallow': (HPLFlowNetShallow, 5)}
+
+
+def epe3d_loss(flow, sf):
+    """flow, sf: (B, 3, N) -> scalar mean end-point error."""
+    return torch.norm(flow - sf, p=2, dim=1).mean()
+
+
+def flow_metrics(pred, gt):
+    """pred, gt: (N, 3) tensors -> dict(EPE3D, Acc3DS, Acc3DR, Outliers) (evaluation_utils.py:4-19)."""
+    err = torch.norm(gt - pred, dim=-1)
+    rel = err / (torch.norm(gt, dim=-1) + 1e-4)
+    return {'EPE3D': float(err.mean()),
+            'Acc3DS': float(((err < 0.05) | (rel < 0.05)).float().mean()),
+            'Acc3DR': float(((err < 0.1) | (rel < 0.1)).float().mean()),
+            'Outliers': float(((err > 0.3) | (rel > 0.1)).float().mean())}
+
+
+def model_args(nscales, device='cuda', evaluate=False):
+    """The reference's config keys the layers read (configs/train_ours.yaml)."""
+    return SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP[:nscales], use_leaky=True, bcn_use_bias=True,
+                           bcn_use_norm=True, last_relu=False, DEVICE=device, evaluate=evaluate)
+
+
+class SyntheticPairs(object):
+    """`count` seeded FT3D-like pairs (synthetic.synthetic_pair), resident on the device as (3, N)."""
+
+    def __init__(self, count, num_points, device, first_seed=0):
+        self.items = []
+        for s in range(first_seed, first_seed + count):
+            pc1, pc2, sf = synthetic_pair(num_points, s)
+            self.items.append(tuple(torch.from_numpy(np.ascontiguousarray(a.T)).to(device) for a in (pc1, pc2, sf)))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+class Trainer(object):
+    def __init__(self, arch='HPLFlowNet', device='cuda', lr=1e-4, seed=0, distributed=False, rank=0):
+        cls, nsc = ARCHS[arch]
+        self.rank = rank
+        self.arch, self.device = arch, torch.device(device)
+        self.args = model_args(nsc, evaluate=False)
+        torch.manual_seed(seed)
+        self.model = cls(self.args)
+        fill_module_(self.model, 1.0, 'hash')           # deterministic He-uniform start (no dataset, no RNG state)
+        self.model.to(self.device)
+        self.gen = GenerateDataUnsymmetric(self.args, device=self.device)
+        self.opt = torch.optim.Adam([p for p in self.model.parameters() if p.requires_grad], lr=lr, weight_decay=0)
+        self.reducer = None
+        if distributed:
+            parallel.broadcast_parameters(self.model)
+            self.reducer = parallel.GradAllReducer(self.model.parameters())
+        self.epoch = 0
+        self.min_loss = None
+        self._side = torch.cuda.Stream(device=self.device, priority=-1) if self.device.type == 'cuda' else None
+
+    # ------------------------------------------------------------------ lattice pipeline
+    def _lattices(self, data, order, training):
+        """Yield (index, lattice) for `order`; lattice k+1 is built on the side stream while k is consumed."""
+        main = torch.cuda.current_stream(self.device)
+
+        def build(i):
+            with torch.cuda.stream(self._side), torch.no_grad():
+                lat = self.gen.build(data[i][0], data[i][1]).prepare(for_training=training)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            return lat, ev
+        keep = collections.deque()
+        nxt = build(order[0]) if order else None
+        for k, i in enumerate(order):
+            lat, ev = nxt
+            main.wait_event(ev)
+            if k + 1 < len(order):
+                nxt = build(order[k + 1])
+            yield i, lat
+            fin = torch.cuda.Event()
+            fin.record(main)
+            keep.append((lat, fin))                 # side-stream memory stays alive until its consumer is done
+            while len(keep) > 2:
+                keep.popleft()[1].synchronize()
+        for _, fin in keep:
+            fin.synchronize()
+
+    # ------------------------------------------------------------------ loops
+    def train_epoch(self, data, order=None):
+        self.model.train()
+        order = list(range(len(data))) if order is None else list(order)
+        total = torch.zeros((), device=self.device)
+        for i, lat in self._lattices(data, order, True):
+            pc1, pc2, sf = data[i]
+            flow = self.model(pc1[None], pc2[None], lat)
+            loss = epe3d_loss(flow, sf[None])
+            self.opt.zero_grad(set_to_none=True)
+            loss.backward()
+            if self.reducer is not None:
+                self.reducer()
+            self.opt.step()
+            total += loss.detach()
+        self.epoch += 1
+        return float(total) / max(1, len(order))
+
+    @torch.no_grad()
+    def validate(self, data):
+        self.model.eval()
+        agg = collections.OrderedDict()
+        for i, lat in self._lattices(data, list(range(len(data))), False):
+            pc1, pc2, sf = data[i]
+            flow = self.model(pc1[None], pc2[None], lat)
+            for k, v in flow_metrics(flow[0].t(), sf.t()).items():
+                agg[k] = agg.get(k, 0.0) + v
+        return {k: v / max(1, len(data)) for k, v in agg.items()}
+
+    # ------------------------------------------------------------------ checkpoints
+    def state(self):
+        sd = collections.OrderedDict(('module.' + k, v) for k, v in self.model.state_dict().items())
+        return {'epoch': self.epoch, 'arch': self.arch, 'state_dict': sd, 'min_loss': self.min_loss,
+                'optimizer': self.opt.state_dict()}
+
+    def save_checkpoint(self, ckpt_dir, is_best, filename='checkpoint.pth.tar'):
+        os.makedirs(ckpt_dir, exist_ok=True)
+        path = os.path.join(ckpt_dir, filename)
+        st = self.state()
+        torch.save(st, path)
+        if st['epoch'] % 10 == 1:
+            shutil.copyfile(path, os.path.join(ckpt_dir, 'checkpoint_%d.pth.tar' % st['epoch']))
+        if is_best:
+            shutil.copyfile(path, os.path.join(ckpt_dir, 'model_best.pth.tar'))
+        return path
+
+    def resume(self, path, load_optimizer=True):
+        ck = torch.load(path, map_location='cpu')
+        load_reference_checkpoint(self.model, ck, strict=True)
+        if isinstance(ck, dict):
+            self.epoch = int(ck.get('epoch', 0))
+            self.min_loss = ck.get('min_loss')
+            if load_optimizer and 'optimizer' in ck:
+                self.opt.load_state_dict(ck['optimizer'])
+        return ck
+
+    def fit(self, train_data, val_data, epochs, ckpt_dir=None, log=print):
+        for _ in range(self.epoch, epochs):
+            tr = self.train_epoch(train_data)
+            val = self.validate(val_data)['EPE3D'] if val_data is not None and len(val_data) else tr
+            best = self.min_loss is None or val < self.min_loss
+            if best:
+                self.min_loss = val
+            log('epoch %d  train EPE3D %.5f  val EPE3D %.5f%s' % (self.epoch, tr, val, '  (best)' if best else ''))
+            if ckpt_dir and self.rank == 0:
+                self.save_checkpoint(ckpt_dir, best)
+        return self.min_loss
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--arch', default='HPLFlowNet', choices=sorted(ARCHS))
+    ap.add_argument('--points', type=int, default=8192)
+    ap.add_argument('--pairs', type=int, default=8, help='synthetic pairs per epoch (per rank)')
+    ap.add_argument('--val-pairs', type=int, default=2)
+    ap.add_argument('--epochs', type=int, default=1)
+    ap.add_argument('--lr', type=float, default=1e-4)
+    ap.add_argument('--ckpt-dir', default=None)
+    ap.add_argument('--resume', default=None)
+    ap.add_argument('--evaluate', action='store_true')
+    a = ap.parse_args(argv)
+    rank, world, local_rank = parallel.init_distributed()
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    tr = Trainer(a.arch, dev, lr=a.lr, distributed=world > 1, rank=rank)
+    if a.resume:
+        tr.resume(a.resume, load_optimizer=not a.evaluate)
+    if a.evaluate:
+        res = tr.validate(SyntheticPairs(a.pairs, a.points, dev, first_seed=1000 + rank * a.pairs))
+        if rank == 0:
+            print(' '.join('%s %.4f' % kv for kv in res.items()))
+        return res
+    train = SyntheticPairs(a.pairs, a.points, dev, first_seed=rank * a.pairs)
+    val = SyntheticPairs(a.val_pairs, a.points, dev, first_seed=1000)
+    return tr.fit(train, val, a.epochs, a.ckpt_dir, log=print if rank == 0 else (lambda *_: None))
+
+
+if __name__ == '__main__':
+    main()
