@@ -170,8 +170,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     const int bn4 = t % B_F4_PER_ROW;
     const int brow0 = t / B_F4_PER_ROW;
 
-    float4 ra[A_PASSES];
-    float4 rb[B_PASSES];
+    // two register sets: the global loads of slice t+2 are issued while slice t is multiplied and slice
+    // t+1 (loaded one step earlier) is stored to LDS -- every load has more than a whole step to land
+    float4 ra[2][A_PASSES];
+    float4 rb[2][B_PASSES];
 
     // Stage the tile's source-row indices once: every later step reads them from LDS, so the
     // gather of step t+1 is a burst of independent loads (no global index -> address chain).
@@ -230,12 +232,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
             for (int i = 0; i < A_PASSES; ++i) rows_n[i] = Is[fi * BM + arow0 + i * A_ROWS_PER_PASS];
         }
     };
-    auto load_a = [&](int i) {
+    auto load_a = [&](int set, int i) {
         if (AVEC) {
             const bool ok = (f_t < p.F) && (rows_n[i] >= 0);
             const unsigned off = ok ? (unsigned)rows_n[i] * lda_b + (unsigned)c_t * 4u : OOB;
             const float4_t v = buffer_load_f32x4(rsrc_a, (int)off, 0, 0);
-            ra[i] = make_float4(v.x, v.y, v.z, v.w);
+            ra[set][i] = make_float4(v.x, v.y, v.z, v.w);
         } else {   // generic path: any C / alignment, element by element
             float e[4];
 #pragma unroll
@@ -245,40 +247,40 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
                 const int row = (f < p.F) ? Is[min(f, F_LDS - 1) * BM + arow0 + i * A_ROWS_PER_PASS] : -1;
                 e[j] = (row >= 0) ? p.A[(int64_t)row * p.lda + c] : 0.f;
             }
-            ra[i] = make_float4(e[0], e[1], e[2], e[3]);
+            ra[set][i] = make_float4(e[0], e[1], e[2], e[3]);
         }
     };
-    auto load_b = [&](int i) {
+    auto load_b = [&](int set, int i) {
         const unsigned off = bvalid ? boff0 + (unsigned)(k0_n + i * B_ROWS_PER_PASS) * ldw_b : OOB;
         const float4_t v = buffer_load_f32x4(rsrc_b, (int)off, 0, 0);
-        rb[i] = make_float4(v.x, v.y, v.z, v.w);
+        rb[set][i] = make_float4(v.x, v.y, v.z, v.w);
     };
-    auto load_regs = [&](int k0) {
+    auto load_regs = [&](int set, int k0) {
         load_begin(k0);
 #pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) load_a(i);
+        for (int i = 0; i < A_PASSES; ++i) load_a(set, i);
 #pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) load_b(i);
+        for (int i = 0; i < B_PASSES; ++i) load_b(set, i);
     };
 
-    auto store_a = [&](int buf, int i) {
+    auto store_a = [&](int set, int buf, int i) {
         float *a = As + buf * BK * LDA_S;
         const int r = arow0 + i * A_ROWS_PER_PASS;
-        a[(kq * 4 + 0) * LDA_S + r] = ra[i].x;
-        a[(kq * 4 + 1) * LDA_S + r] = ra[i].y;
-        a[(kq * 4 + 2) * LDA_S + r] = ra[i].z;
-        a[(kq * 4 + 3) * LDA_S + r] = ra[i].w;
+        a[(kq * 4 + 0) * LDA_S + r] = ra[set][i].x;
+        a[(kq * 4 + 1) * LDA_S + r] = ra[set][i].y;
+        a[(kq * 4 + 2) * LDA_S + r] = ra[set][i].z;
+        a[(kq * 4 + 3) * LDA_S + r] = ra[set][i].w;
     };
-    auto store_b = [&](int buf, int i) {
+    auto store_b = [&](int set, int buf, int i) {
         float *b = Bs + buf * BK * LDB_S;
         const int kr = brow0 + i * B_ROWS_PER_PASS;
-        *reinterpret_cast<float4 *>(b + kr * LDB_S + bn4 * 4) = rb[i];
+        *reinterpret_cast<float4 *>(b + kr * LDB_S + bn4 * 4) = rb[set][i];
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int set, int buf) {
 #pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) store_a(buf, i);
+        for (int i = 0; i < A_PASSES; ++i) store_a(set, buf, i);
 #pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) store_b(buf, i);
+        for (int i = 0; i < B_PASSES; ++i) store_b(set, buf, i);
     };
 
     floatx16 acc[TM][TN];
@@ -315,15 +317,21 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     // split-K (small M): this workgroup handles slices [lo, hi) of the list and writes a partial tile
     const int split = blockIdx.x / (p.tiles_m * p.tiles_n);
     const int lo = (int)((int64_t)nlist * split / p.splits), hi_i = (int)((int64_t)nlist * (split + 1) / p.splits);
-    if (hi_i > lo) {
-        load_regs((int)Ks[lo] * BK);
-        store_lds(0);
+    const int nsl = hi_i - lo;        // slices of this workgroup: list entries lo .. hi_i-1
+    if (nsl > 0) {
+        load_regs(0, (int)Ks[lo] * BK);
+        store_lds(0, 0);
+        if (nsl > 1) load_regs(1, (int)Ks[lo + 1] * BK);      // slice 1 stays in flight in set 1
     }
     __syncthreads();
     int cur = 0;
-    // one contraction step; MORE (compile time) = also prefetch and stage step kt+1
-    auto step = [&](int kt_next, auto more_tag) {
-        constexpr bool more = decltype(more_tag)::value;
+    // One contraction step t (compile-time flags).  P = t & 1.  LOAD: issue the loads of slice t+2
+    // (kt_load) into register set P; STORE: stage slice t+1 (register set 1-P, loaded during step t-1)
+    // into the other LDS buffer.
+    auto step = [&](int kt_load, auto load_tag, auto store_tag, auto parity_tag) {
+        constexpr bool do_load = decltype(load_tag)::value;
+        constexpr bool do_store = decltype(store_tag)::value;
+        constexpr int P = decltype(parity_tag)::value;
         const float *a = As + cur * BK * LDA_S + wm * WTM + li;
         const float *b = Bs + cur * BK * LDB_S + wn * WTN + li;
         // fragments of k-pair kk+1 are fetched from LDS while the MFMAs of kk run
@@ -352,26 +360,45 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (more) {
-                if (kk == 0) load_begin(kt_next * BK);
-                if (kk >= 1 && kk - 1 < A_PASSES) load_a(kk - 1);
-                if (kk >= 5 && kk - 5 < B_PASSES) load_b(kk - 5);
-                if (kk >= 10 && kk - 10 < A_PASSES) store_a(cur ^ 1, kk - 10);
+            if constexpr (do_load) {
+                if (kk == 0) load_begin(kt_load * BK);
+                if (kk >= 1 && kk - 1 < A_PASSES) load_a(P, kk - 1);
+                if (kk >= 5 && kk - 5 < B_PASSES) load_b(P, kk - 5);
+            }
+            if constexpr (do_store) {
+                if (kk >= 10 && kk - 10 < A_PASSES) store_a(1 - P, cur ^ 1, kk - 10);
                 if (kk == 14) {
 #pragma unroll
-                    for (int i = 0; i < B_PASSES; i += 2) store_b(cur ^ 1, i);
+                    for (int i = 0; i < B_PASSES; i += 2) store_b(1 - P, cur ^ 1, i);
                 }
                 if (kk == 15) {
 #pragma unroll
-                    for (int i = 1; i < B_PASSES; i += 2) store_b(cur ^ 1, i);
+                    for (int i = 1; i < B_PASSES; i += 2) store_b(1 - P, cur ^ 1, i);
                 }
             }
         }
         __syncthreads();
         cur ^= 1;
     };
-    for (int i = lo; i + 1 < hi_i; ++i) step((int)Ks[i + 1], std::true_type{});
-    if (hi_i > lo) step(-1, std::false_type{});
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        int t = 0;
+        while (t + 2 < nsl) {                       // steps that both load (slice t+2) and store (slice t+1)
+            step((int)Ks[lo + t + 2], T{}, T{}, P0{});
+            ++t;
+            if (t + 2 >= nsl) break;
+            step((int)Ks[lo + t + 2], T{}, T{}, P1{});
+            ++t;
+        }
+        if (t + 1 < nsl) {                          // last but one: only stage the last slice
+            if (t & 1) step(-1, F{}, T{}, P1{}); else step(-1, F{}, T{}, P0{});
+            ++t;
+        }
+        if (t < nsl) step(-1, F{}, F{}, P0{});
+    }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
