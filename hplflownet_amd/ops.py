@@ -112,7 +112,7 @@ def tap_order(nbr):
     """int32 [F<=15, M] neighbour table -> int32 [M] permutation grouping the rows by tap-presence mask."""
     F, M = nbr.shape
     perm = torch.empty(M, dtype=torch.int32, device=nbr.device)
-    scratch = torch.empty(M + 2 * 32768 + 1026 + 64, dtype=torch.int32, device=nbr.device)
+    scratch = torch.empty(M + 2 * 524288 + 1100, dtype=torch.int32, device=nbr.device)
     check(_lib.load().hpl_tap_order(ptr(nbr), nbr.stride(0), F, M, ptr(perm), ptr(scratch), stream()), 'hpl_tap_order')
     return perm
 

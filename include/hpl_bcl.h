@@ -162,7 +162,7 @@ typedef struct hpl_gconv_desc {
 
 /* Row order for tap skipping: perm = the M vertices grouped by their F-bit tap-presence mask
  * (bit f set iff nbr[f*nbr_stride + m] >= 0; F <= 15).  Order inside a group is unspecified (it
- * does not affect results).  scratch: M + 2 * 32768 + 1026 + 64 int32. */
+ * does not affect results).  scratch: M + 2 * 524288 + 1100 int32. */
 int hpl_tap_order(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *perm,
                   int32_t *scratch, hplStream stream);
 
