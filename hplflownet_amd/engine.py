@@ -99,23 +99,25 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ lattice pipeline
     def _lattices(self, data, order, training):
-        """Yield (index, lattice) for `order`; lattice k+1 is built on the side stream while k is consumed."""
+        """Yield (sample, lattice) for `order`; sample k+1 is fetched (once: readers may sample randomly)
+        and its lattice built on the side stream while k is consumed."""
         main = torch.cuda.current_stream(self.device)
 
         def build(i):
+            sample = data[i]
             with torch.cuda.stream(self._side), torch.no_grad():
-                lat = self.gen.build(data[i][0], data[i][1]).prepare(for_training=training)
+                lat = self.gen.build(sample[0], sample[1]).prepare(for_training=training)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
-            return lat, ev
+            return sample, lat, ev
         keep = collections.deque()
         nxt = build(order[0]) if order else None
         for k, i in enumerate(order):
-            lat, ev = nxt
+            sample, lat, ev = nxt
             main.wait_event(ev)
             if k + 1 < len(order):
                 nxt = build(order[k + 1])
-            yield i, lat
+            yield sample, lat
             fin = torch.cuda.Event()
             fin.record(main)
             keep.append((lat, fin))                 # side-stream memory stays alive until its consumer is done
@@ -129,8 +131,7 @@ class Trainer(object):
         self.model.train()
         order = list(range(len(data))) if order is None else list(order)
         total = torch.zeros((), device=self.device)
-        for i, lat in self._lattices(data, order, True):
-            pc1, pc2, sf = data[i]
+        for (pc1, pc2, sf), lat in self._lattices(data, order, True):
             flow = self.model(pc1[None], pc2[None], lat)
             loss = epe3d_loss(flow, sf[None])
             self.opt.zero_grad(set_to_none=True)
@@ -146,8 +147,7 @@ class Trainer(object):
     def validate(self, data):
         self.model.eval()
         agg = collections.OrderedDict()
-        for i, lat in self._lattices(data, list(range(len(data))), False):
-            pc1, pc2, sf = data[i]
+        for (pc1, pc2, sf), lat in self._lattices(data, list(range(len(data))), False):
             flow = self.model(pc1[None], pc2[None], lat)
             for k, v in flow_metrics(flow[0].t(), sf.t()).items():
                 agg[k] = agg.get(k, 0.0) + v

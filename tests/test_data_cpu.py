@@ -1,0 +1,91 @@
+"""CPU: the data path in front of the lattice build on synthetic directory
+trees laid out like the published datasets; expectations restate the reference's rules
+(transforms.py:494-548, flyingthings3d_subset.py:62-101, kitti.py:62-107)."""
+import os
+
+import numpy as np
+
+from hplflownet_amd.data import KITTI, FlyingThings3DSubset, ProcessData
+
+
+def _write(root, rel, pc1, pc2):
+    d = os.path.join(root, rel)
+    os.makedirs(d)
+    np.save(os.path.join(d, 'pc1.npy'), pc1)
+    np.save(os.path.join(d, 'pc2.npy'), pc2)
+    return d
+
+
+def test_process_data_rules():
+    rng = np.random.RandomState(0)
+    pc1 = rng.uniform(-5, 5, (300, 3)).astype(np.float32)
+    pc1[:, 2] = rng.uniform(1, 60, 300)
+    pc2 = pc1 + rng.normal(0, 0.2, (300, 3)).astype(np.float32)
+    near = (pc1[:, 2] < 35.0) & (pc2[:, 2] < 35.0)
+    t = ProcessData({'DEPTH_THRESHOLD': 35.0, 'NO_CORR': False}, 64, False, seed=1)
+    a, b, sf = t([pc1, pc2])
+    assert a.shape == b.shape == sf.shape == (64, 3)
+    assert (a[:, 2] < 35).all() and (b[:, 2] < 35).all()
+    assert np.array_equal(sf, b - a)                                  # same indices for both clouds (:525)
+    rows = [np.nonzero((pc1 == r).all(1))[0][0] for r in a]
+    assert len(set(rows)) == 64 and near[rows].all()                  # without replacement, inside the mask
+    a2, _, _ = ProcessData({'DEPTH_THRESHOLD': 35.0, 'NO_CORR': False}, 64, False, seed=1)([pc1, pc2])
+    assert np.array_equal(a, a2)                                      # seedable
+    # NO_CORR: independent draws for cloud 2; sf still belongs to cloud 1's draw (:519-523,541-543)
+    a, b, sf = ProcessData({'DEPTH_THRESHOLD': 35.0, 'NO_CORR': True}, 64, False, seed=2)([pc1, pc2])
+    rows = [np.nonzero((pc1 == r).all(1))[0][0] for r in a]
+    assert np.array_equal(sf, (pc2 - pc1)[rows]) and not np.array_equal(sf, b - a)
+    # too few points: rejected, or everything inside the mask with allow_less_points (:526-532)
+    assert ProcessData({'DEPTH_THRESHOLD': 35.0, 'NO_CORR': False}, 1000, False)([pc1, pc2]) == (None, None, None)
+    a, b, sf = ProcessData({'DEPTH_THRESHOLD': 35.0, 'NO_CORR': False}, 1000, True)([pc1, pc2])
+    assert len(a) == int(near.sum()) and np.array_equal(sf, b - a)
+    # no threshold, no sampling: identity
+    a, b, sf = ProcessData({'DEPTH_THRESHOLD': -1, 'NO_CORR': False}, -1, False)([pc1, pc2])
+    assert np.array_equal(a, pc1) and np.array_equal(b, pc2)
+    assert ProcessData({'DEPTH_THRESHOLD': 0.5, 'NO_CORR': False}, 8, True)([pc1, pc2]) == (None, None, None)
+    assert ProcessData({'DEPTH_THRESHOLD': 35.0, 'NO_CORR': False}, 8, True)([None, None]) == (None, None, None)
+
+
+def test_flyingthings_subset_reader(tmp_path):
+    rng = np.random.RandomState(1)
+    root = str(tmp_path)
+    base = os.path.join(root, 'FlyingThings3D_subset_processed_35m')
+    clouds = {}
+    for i in range(9):
+        pc1 = rng.uniform(1, 20, (50, 3)).astype(np.float32)
+        pc2 = (pc1 + 0.1).astype(np.float32)
+        clouds[_write(base, 'val/%07d' % i, pc1, pc2)] = (pc1, pc2)
+    ds = FlyingThings3DSubset(False, None, root, device='cpu')
+    assert len(ds) == 3 and ds.samples == sorted(clouds)[::4]         # every 4th unless full (:79-82)
+    assert len(FlyingThings3DSubset(False, None, root, full=True, device='cpu')) == 9
+    assert 'found 9' in ds.check_counts()                             # canonical 3824: reported, not fatal
+    p1, p2, sf = ds[1]
+    want1, want2 = clouds[ds.samples[1]]
+    flip = np.array([-1, 1, -1], np.float32)
+    assert np.array_equal(p1.numpy().T, want1 * flip) and np.array_equal(p2.numpy().T, want2 * flip)   # (:96-99)
+    assert np.allclose(sf.numpy(), (p2 - p1).numpy())
+    t = ProcessData({'DEPTH_THRESHOLD': 35.0, 'NO_CORR': False}, 16, False, seed=0)
+    p1, p2, sf = FlyingThings3DSubset(False, t, root, device='cpu')[0]
+    assert tuple(p1.shape) == (3, 16)                                  # z was negated -> all "near"
+
+
+def test_kitti_reader(tmp_path):
+    rng = np.random.RandomState(2)
+    root = str(tmp_path)
+    base = os.path.join(root, 'KITTI_processed_occ_final')
+    for i in range(4):
+        pc1 = rng.uniform(-3, 3, (80, 3)).astype(np.float32)
+        pc2 = (pc1 + rng.normal(0, 0.3, (80, 3))).astype(np.float32)
+        _write(base, '%06d' % i, pc1, pc2)
+    mapping = os.path.join(root, 'map.txt')
+    with open(mapping, 'w') as f:
+        f.write('a\n\nb\nc\n')                                       # frame 1 unmapped -> skipped (:76-83)
+    ds = KITTI(None, root, remove_ground=True, mapping_file=mapping, device='cpu')
+    assert [os.path.basename(s) for s in ds.samples] == ['000000', '000002', '000003']
+    raw1 = np.load(os.path.join(ds.samples[0], 'pc1.npy'))
+    raw2 = np.load(os.path.join(ds.samples[0], 'pc2.npy'))
+    keep = ~((raw1[:, 1] < -1.4) & (raw2[:, 1] < -1.4))               # ground only if below in BOTH (:100-105)
+    p1, p2, _ = ds[0]
+    assert np.array_equal(p1.numpy().T, raw1[keep]) and np.array_equal(p2.numpy().T, raw2[keep])
+    assert 0 < keep.sum() < 80
+    assert len(KITTI(None, root, remove_ground=False, device='cpu')) == 4
