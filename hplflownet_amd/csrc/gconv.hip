@@ -143,13 +143,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     // + output row of every tile row [BM] + the tile's tap mask [1])
     // + list of the contraction slices this tile needs [KLIST ushort])
     constexpr int KLIST = 1024;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA_S + 2 * BK * LDB_S + F_LDS * BM + BM + 4 + KLIST / 2];
+    static_assert(NT % BM == 0 && BM / 32 <= 4, "a thread stages indices of one 32-row block only");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA_S + 2 * BK * LDB_S + F_LDS * BM + BM + 8 + KLIST / 2];
     float *As = smem;
     float *Bs = smem + 2 * BK * LDA_S;
     int *Is = reinterpret_cast<int *>(smem + 2 * BK * LDA_S + 2 * BK * LDB_S);
     int *Vs = Is + F_LDS * BM;          // vertex (output row) of tile row r, -1 past M
-    int *tapmask_s = Vs + BM;          // [0] tap mask, [1] number of needed slices
-    unsigned short *Ks = reinterpret_cast<unsigned short *>(tapmask_s + 4);
+    int *tapmask_s = Vs + BM;          // [0] tap mask, [1] number of needed slices, [2..5] masks of the 32-row blocks
+    unsigned short *Ks = reinterpret_cast<unsigned short *>(tapmask_s + 8);
 
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     // With a row permutation (vertices sorted by tap mask, hpl_tap_order) tile row r is vertex
     // row_perm[m0 + r]: rows of one tile then miss the same taps, and a whole 32-wide slice whose
     // taps are absent for all BM rows is skipped (no loads, no MFMAs, no barrier).
-    if (t == 0) *tapmask_s = 0;
+    if (t < 8) tapmask_s[t] = 0;
     for (int r = t; r < BM; r += NT) {
         const int64_t m = m0 + r;
         Vs[r] = (m < p.M) ? (p.row_perm ? p.row_perm[m] : (int)m) : -1;
@@ -196,10 +197,20 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
             Is[i] = row;
             mybits |= (row >= 0) ? (1 << f) : 0;
         }
-        if (mybits) atomicOr(tapmask_s, mybits);
+        if (mybits) {
+            atomicOr(tapmask_s, mybits);
+            atomicOr(tapmask_s + 2 + ((t % BM) >> 5), mybits);      // NT % BM == 0: r = t % BM for every i of this thread
+        }
     }
     __syncthreads();
     const int tapmask = __builtin_amdgcn_readfirstlane(*tapmask_s);
+    // A 32-row block (one MFMA tile of a wave) whose rows all miss the taps of a slice skips the MFMAs
+    // of that slice (the loads, stores and the barrier stay).  Needs <= 2 taps per slice (C >= 32) so
+    // that the list entry can carry them: bits 0..9 slice, 10..13 first tap, 14 "also the next tap".
+    const bool blockskip = p.C >= BK;
+    int bmask[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) bmask[i] = __builtin_amdgcn_readfirstlane(tapmask_s[2 + wm * TM + i]);
     // Buffer descriptors (wave-uniform, built from kernel arguments): 32-bit byte offsets keep the
     // per-load address arithmetic to a multiply-add, and an out-of-range offset returns zeros in
     // hardware -- that is how absent neighbours (-1), taps past F and columns past ldw read as 0.
@@ -307,7 +318,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
                 need = (tapmask & bits) != 0;
             }
             const unsigned long long bal = __ballot(need);
-            if (need) Ks[count + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)kt;
+            if (need) {
+                int e = kt;
+                if (blockskip) {
+                    const int f_lo = (kt * BK) / p.C;
+                    e |= (f_lo << 10) | (((kt * BK + BK - 1) / p.C > f_lo && f_lo + 1 < p.F) ? (1 << 14) : 0);
+                }
+                Ks[count + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
+            }
             count += __popcll(bal);
         }
         if (lane == 0) tapmask_s[1] = count;
@@ -319,19 +337,54 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     const int lo = (int)((int64_t)nlist * split / p.splits), hi_i = (int)((int64_t)nlist * (split + 1) / p.splits);
     const int nsl = hi_i - lo;        // slices of this workgroup: list entries lo .. hi_i-1
     if (nsl > 0) {
-        load_regs(0, (int)Ks[lo] * BK);
+        load_regs(0, (int)(Ks[lo] & 1023) * BK);
         store_lds(0, 0);
-        if (nsl > 1) load_regs(1, (int)Ks[lo + 1] * BK);      // slice 1 stays in flight in set 1
+        if (nsl > 1) load_regs(1, (int)(Ks[lo + 1] & 1023) * BK);      // slice 1 stays in flight in set 1
     }
     __syncthreads();
     int cur = 0;
     // One contraction step t (compile-time flags).  P = t & 1.  LOAD: issue the loads of slice t+2
     // (kt_load) into register set P; STORE: stage slice t+1 (register set 1-P, loaded during step t-1)
     // into the other LDS buffer.
-    auto step = [&](int kt_load, auto load_tag, auto store_tag, auto parity_tag) {
+    auto step = [&](int e_cur, int kt_load, auto load_tag, auto store_tag, auto parity_tag) {
         constexpr bool do_load = decltype(load_tag)::value;
         constexpr bool do_store = decltype(store_tag)::value;
         constexpr int P = decltype(parity_tag)::value;
+        // the prefetch / staging pieces of this step, one call per k-pair
+        auto pieces = [&](int kk) {
+            if constexpr (do_load) {
+                if (kk == 0) load_begin(kt_load * BK);
+                if (kk >= 1 && kk - 1 < A_PASSES) load_a(P, kk - 1);
+                if (kk >= 5 && kk - 5 < B_PASSES) load_b(P, kk - 5);
+            }
+            if constexpr (do_store) {
+                if (kk >= 10 && kk - 10 < A_PASSES) store_a(1 - P, cur ^ 1, kk - 10);
+                if (kk == 14) {
+#pragma unroll
+                    for (int i = 0; i < B_PASSES; i += 2) store_b(1 - P, cur ^ 1, i);
+                }
+                if (kk == 15) {
+#pragma unroll
+                    for (int i = 1; i < B_PASSES; i += 2) store_b(1 - P, cur ^ 1, i);
+                }
+            }
+        };
+        bool need[TM], need_any = false;
+        {
+            const int f_lo = (e_cur >> 10) & 15, two = (e_cur >> 14) & 1;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                need[i] = !blockskip || (((bmask[i] >> f_lo) | (two ? (bmask[i] >> (f_lo + 1)) : 0)) & 1);
+                need_any |= need[i];
+            }
+        }
+        if (!need_any) {          // wave-uniform: none of this wave's row blocks has a tap of this slice
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) pieces(kk);
+            __syncthreads();
+            cur ^= 1;
+            return;
+        }
         const float *a = As + cur * BK * LDA_S + wm * WTM + li;
         const float *b = Bs + cur * BK * LDB_S + wn * WTN + li;
         // fragments of k-pair kk+1 are fetched from LDS while the MFMAs of kk run
@@ -355,27 +408,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
             // the MFMAs and waits lgkmcnt(0) right after: ~50 idle matrix-pipe cycles per k-pair)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                if (TM > 1 && !need[i]) continue;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (do_load) {
-                if (kk == 0) load_begin(kt_load * BK);
-                if (kk >= 1 && kk - 1 < A_PASSES) load_a(P, kk - 1);
-                if (kk >= 5 && kk - 5 < B_PASSES) load_b(P, kk - 5);
-            }
-            if constexpr (do_store) {
-                if (kk >= 10 && kk - 10 < A_PASSES) store_a(1 - P, cur ^ 1, kk - 10);
-                if (kk == 14) {
-#pragma unroll
-                    for (int i = 0; i < B_PASSES; i += 2) store_b(1 - P, cur ^ 1, i);
-                }
-                if (kk == 15) {
-#pragma unroll
-                    for (int i = 1; i < B_PASSES; i += 2) store_b(1 - P, cur ^ 1, i);
-                }
-            }
+            pieces(kk);
         }
         __syncthreads();
         cur ^= 1;
@@ -387,17 +427,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
         using P1 = std::integral_constant<int, 1>;
         int t = 0;
         while (t + 2 < nsl) {                       // steps that both load (slice t+2) and store (slice t+1)
-            step((int)Ks[lo + t + 2], T{}, T{}, P0{});
+            step((int)Ks[lo + t], (int)(Ks[lo + t + 2] & 1023), T{}, T{}, P0{});
             ++t;
             if (t + 2 >= nsl) break;
-            step((int)Ks[lo + t + 2], T{}, T{}, P1{});
+            step((int)Ks[lo + t], (int)(Ks[lo + t + 2] & 1023), T{}, T{}, P1{});
             ++t;
         }
         if (t + 1 < nsl) {                          // last but one: only stage the last slice
-            if (t & 1) step(-1, F{}, T{}, P1{}); else step(-1, F{}, T{}, P0{});
+            if (t & 1) step((int)Ks[lo + t], -1, F{}, T{}, P1{}); else step((int)Ks[lo + t], -1, F{}, T{}, P0{});
             ++t;
         }
-        if (t < nsl) step(-1, F{}, F{}, P0{});
+        if (t < nsl) step((int)Ks[lo + t], -1, F{}, F{}, P0{});
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
