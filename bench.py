@@ -324,6 +324,13 @@ def main():
         parallel.barrier()
         elapsed = parallel.max_over_ranks(elapsed, device=dev)
 
+    # the pipelined loop's last output against a plain single-stream forward of the same pair (inference)
+    pipe_check = None
+    if overlap and not a.train:
+        with torch.no_grad():
+            ref = step(a.warmup + a.steps - 1)
+        torch.cuda.synchronize()
+        pipe_check = {'max_abs_diff': float((y - ref).abs().max()), 'max_abs': float(ref.abs().max())}
     dom = timers.summary(a.steps).get(DOMINANT, {})
     # per-kernel detail: a separate, untimed, non-overlapped pass (an event pair around each of the
     # ~130 launches costs ~1.5 ms of host time per step, which the timed loop does not pay)
@@ -375,7 +382,8 @@ def main():
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,
-                'host_ms_per_step': {k: v / a.steps for k, v in host.items()} if overlap else None}
+                'host_ms_per_step': {k: v / a.steps for k, v in host.items()} if overlap else None,
+                'pipelined_output_check': pipe_check}
         if world == 1 and not a.no_cpu_baseline and not a.train:
             p1, p2, sf = pairs_np[0]
             base, flow_cpu, epe_cpu = cpu_baseline(p1, p2, sf, SCALES_FILTER_MAP, state)

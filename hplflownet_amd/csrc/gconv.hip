@@ -1009,11 +1009,28 @@ __global__ void __launch_bounds__(256) k_mfma_probe(float *out, int iters) {
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+
+// the same number of MFMAs as one dependent chain per wave (one accumulator, as the 32x32-per-wave tiles)
+__global__ void __launch_bounds__(256) k_mfma_probe_chain(float *out, int iters) {
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float a = (float)threadIdx.x * 1e-3f, b = 1.0f + (float)blockIdx.x * 1e-6f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[r];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 }  // namespace
 
 extern "C" int hpl_mfma_probe(float *out, int blocks, int iters, hplStream stream) {
-    HPL_REQUIRE(out && blocks > 0 && iters > 0, "hpl_mfma_probe: bad arguments");
-    k_mfma_probe<<<blocks, 256, 0, to_stream(stream)>>>(out, iters);
+    HPL_REQUIRE(out && blocks > 0 && iters != 0, "hpl_mfma_probe: bad arguments");
+    if (iters < 0) k_mfma_probe_chain<<<blocks, 256, 0, to_stream(stream)>>>(out, -iters);
+    else k_mfma_probe<<<blocks, 256, 0, to_stream(stream)>>>(out, iters);
     HPL_CHECK_LAUNCH("hpl_mfma_probe");
     return HPL_OK;
 }

@@ -190,7 +190,9 @@ int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, const int32_t *
                     int64_t tap_max, float *dbias, hplStream stream);
 
 /* Diagnostic: `blocks` workgroups of 4 waves each issue iters*64 v_mfma_f32_32x32x2_f32 per wave
- * with no memory traffic; out needs blocks*256 floats.  flops = blocks*4*iters*64*4096. */
+ * with no memory traffic; out needs blocks*256 floats.  flops = blocks*4*|iters|*64*4096.
+ * iters > 0: four independent accumulators per wave; iters < 0: ONE accumulator (every MFMA
+ * depends on the previous one, as in the 32x32-per-wave tiles of the gather-GEMM). */
 int hpl_mfma_probe(float *out, int blocks, int iters, hplStream stream);
 
 /* out[n] = sum_m X[m*ld + n]   (bias gradients) */
