@@ -174,8 +174,8 @@ def cpu_baseline(pc1, pc2, sf, sfm, state_dict):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=8192)
     ap.add_argument('--pool', type=int, default=4, help='distinct resident pairs cycled through the steps')
     ap.add_argument('--no-lattice', action='store_true', help='exclude the device lattice build from the step')
