@@ -151,7 +151,7 @@ def needed_slice_fraction(tbl, C, BM=64, BK=32):
     return float(need.float().mean().item())
 
 
-def cpu_baseline(pc1, pc2, sf, sfm, state_dict):
+def cpu_baseline(pc1, pc2, sf, sfm, state_dict, shallow=False):
     """The CPU oracle on one pair of the same workload; returns (dict, flow)."""
     from oracle import bcl_oracle, lattice_oracle
     try:
@@ -162,11 +162,11 @@ def cpu_baseline(pc1, pc2, sf, sfm, state_dict):
     t0 = time.time()
     gd = lattice_oracle.generate_data(pc1, pc2, sfm)
     t1 = time.time()
-    flow = bcl_oracle.hplflownet_forward(state_dict, pc1.T, pc2.T, gd)
+    flow = bcl_oracle.hplflownet_forward(state_dict, pc1.T, pc2.T, gd, shallow=shallow)
     t2 = time.time()
     d = {'value': 1.0 / (t2 - t0), 'unit': 'point-pairs/s', 'cores': int(threads), 'kind': 'port',
-         'sample': '1 pair, N=%d, 7-level lattice build (C oracle, 1 thread) + full HPLFlowNet forward '
-                   '(numpy oracle, BLAS threads = cores)' % pc1.shape[0],
+         'sample': '1 pair, N=%d, %d-level lattice build (C oracle, 1 thread) + %s forward '
+                   '(numpy oracle, BLAS threads = cores)' % (pc1.shape[0], len(sfm), 'HPLFlowNetShallow' if shallow else 'full HPLFlowNet'),
          'lattice_s': t1 - t0, 'forward_s': t2 - t1, 'host_cpus': os.cpu_count()}
     return d, flow, bcl_oracle.epe3d(flow, sf.T)
 
@@ -184,6 +184,8 @@ def main():
                     help='build each lattice on the main stream instead of a second stream overlapping the previous forward')
     ap.add_argument('--streams', type=int, default=3,
                     help='HIP streams the forwards of consecutive pairs alternate over (pairs in flight)')
+    ap.add_argument('--arch', default='HPLFlowNet', choices=['HPLFlowNet', 'HPLFlowNetShallow'],
+                    help='HPLFlowNetShallow + --points 4096 is BASELINE config 2')
     ap.add_argument('--train', action='store_true',
                     help='time a training step (fwd + bwd + gradient all-reduce + Adam) instead of inference')
     a = ap.parse_args()
@@ -204,9 +206,11 @@ def main():
     from hplflownet_amd import ops
     from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_, synthetic_pair
 
-    margs = types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP, evaluate=True, use_leaky=True,
+    full = a.arch == 'HPLFlowNet'
+    sfm = SCALES_FILTER_MAP if full else SCALES_FILTER_MAP[:5]
+    margs = types.SimpleNamespace(dim=3, scales_filter_map=sfm, evaluate=True, use_leaky=True,
                                   bcn_use_bias=True, bcn_use_norm=True, last_relu=False, DEVICE='cuda')
-    model = H.HPLFlowNet(margs)
+    model = getattr(H, a.arch)(margs)
     fill_module_(model, 1.0, 'hash')                      # random-init weights of the named architecture
     state = {k: v.numpy().copy() for k, v in model.state_dict().items()}
     model = model.to(dev).eval()
@@ -301,6 +305,17 @@ def main():
                 keep.popleft()
         return out
 
+    # which gather-GEMM class dominates this model / size: one untimed step with every launch timed
+    dominant = DOMINANT
+    if not full:
+        timers.enabled, timers.only = True, None
+        with torch.set_grad_enabled(a.train):
+            step(0)
+        torch.cuda.synchronize()
+        timers.enabled = False
+        pre = {k: v for k, v in timers.summary(1).items() if k.startswith('gconv')}
+        dominant = max(pre, key=lambda k: pre[k]['ms_per_step'])
+        timers.records = []
     host = {'lattice_build_ms': 0.0, 'forward_enqueue_ms': 0.0}     # host wall time inside the timed loop
     with torch.set_grad_enabled(a.train):
         if overlap:
@@ -310,7 +325,7 @@ def main():
                 step(i)
         sync_all()
         timers.enabled = True
-        timers.only = {DOMINANT}
+        timers.only = {dominant}
         host = dict.fromkeys(host, 0.0)
         t0 = time.perf_counter()
         if overlap:
@@ -331,7 +346,7 @@ def main():
             ref = step(a.warmup + a.steps - 1)
         torch.cuda.synchronize()
         pipe_check = {'max_abs_diff': float((y - ref).abs().max()), 'max_abs': float(ref.abs().max())}
-    dom = timers.summary(a.steps).get(DOMINANT, {})
+    dom = timers.summary(a.steps).get(dominant, {})
     # per-kernel detail: a separate, untimed, non-overlapped pass (an event pair around each of the
     # ~130 launches costs ~1.5 ms of host time per step, which the timed loop does not pay)
     detail_steps = min(a.steps, 10)
@@ -347,17 +362,19 @@ def main():
     if rank == 0:
         roofline = {'bound': 'mfma', 'achieved': dom.get('achieved'), 'peak': MFMA_F32_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': dom.get('frac'), 'traffic': None,
-                    'kernel': 'k_gconv<64,128,2,4,true,15> (fp32-MFMA gather-GEMM, 15-tap stencil: blur convs of bcn1_/bcn2_)',
+                    'kernel': ('k_gconv<64,128,2,4,true,15> (fp32-MFMA gather-GEMM, 15-tap stencil: blur convs of '
+                               'bcn1_/bcn2_)') if full else 'k_gconv, class %s (fp32-MFMA gather-GEMM)' % dominant,
                     'measured_mfma_ceiling': ceiling,
                     'launches_per_step': dom.get('launches_per_step'), 'avg_launch_us': dom.get('avg_launch_us'),
                     'gflop_per_step': dom.get('gflop_per_step')}
         # how much of the algorithmic work the dominant kernel really executes (absent taps are skipped)
         lat0 = gen.build(*pairs[0])
-        fl = [2.0 * lat0.levels[L].H[0] * 15 * c * o for L, c, o in ((0, 580, 1024), (1, 324, 512))]
-        fr = [needed_slice_fraction(lat0.levels[L].blur[0], c, BM=64) for L, c in ((0, 580), (1, 324))]
-        roofline['executed_fraction'] = (fl[0] * fr[0] + fl[1] * fr[1]) / (fl[0] + fl[1])
-        roofline['achieved_executed'] = (roofline['achieved'] or 0.0) * roofline['executed_fraction']
-        ex = kernels.get(DOMINANT, {})
+        if full:
+            fl = [2.0 * lat0.levels[L].H[0] * 15 * c * o for L, c, o in ((0, 580, 1024), (1, 324, 512))]
+            fr = [needed_slice_fraction(lat0.levels[L].blur[0], c, BM=64) for L, c in ((0, 580), (1, 324))]
+            roofline['executed_fraction'] = (fl[0] * fr[0] + fl[1] * fr[1]) / (fl[0] + fl[1])
+            roofline['achieved_executed'] = (roofline['achieved'] or 0.0) * roofline['executed_fraction']
+        ex = kernels.get(dominant, {})
         roofline['exclusive'] = {'achieved': ex.get('achieved'), 'frac': ex.get('frac'),
                                  'avg_launch_us': ex.get('avg_launch_us')}
         roofline['note'] = ('achieved = algorithmic flops (2*H*15*C_in*C_out, what the reference multiplies) / HIP-event '
@@ -365,7 +382,7 @@ def main():
                             'share the GPU; exclusive = the same launches alone on the GPU (separate single-stream '
                             'pass); executed_fraction = share of 32-wide slices not skipped as all-absent taps')
         prof = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(prof):
+        if os.path.exists(prof) and full:
             try:
                 roofline['traffic'] = json.load(open(prof)).get('k_gconv_64x128_bytes_per_launch')
             except Exception:
@@ -374,7 +391,7 @@ def main():
                 'value': world * a.steps / elapsed, 'unit': 'point-pairs/s', 'n_gpus': world, 'steps': a.steps,
                 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': 'full HPLFlowNet %s (7 levels, 19.3M params, random init), ' % ('training step (fwd+bwd+grad all-reduce+Adam)' if a.train else 'inference') +
+                'config': {'workload': ('full HPLFlowNet %s (7 levels, 19.3M params, random init), ' if full else 'HPLFlowNetShallow %s (5 levels, random init), ') % ('training step (fwd+bwd+grad all-reduce+Adam)' if a.train else 'inference') +
                                        'FT3D-like synthetic pair, N=%d, bs=1 per GPU' % a.points,
                            'num_points': a.points, 'step_includes_lattice_build': not a.no_lattice,
                            'lattice_overlapped_on_second_stream': bool(overlap),
@@ -386,7 +403,7 @@ def main():
                 'pipelined_output_check': pipe_check}
         if world == 1 and not a.no_cpu_baseline and not a.train:
             p1, p2, sf = pairs_np[0]
-            base, flow_cpu, epe_cpu = cpu_baseline(p1, p2, sf, SCALES_FILTER_MAP, state)
+            base, flow_cpu, epe_cpu = cpu_baseline(p1, p2, sf, sfm, state, shallow=not full)
             with torch.no_grad():
                 y0 = step(0)
             flow_gpu = y0[0].cpu().numpy()
