@@ -95,7 +95,16 @@ def check(rc, what):
         raise HplError('%s failed (%d): %s' % (what, rc, load().hpl_last_error().decode()))
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_GET_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device, as an integer.  The raw C
+    accessors cost ~0.3 us; torch.cuda.current_stream() builds a Stream object (~6 us, 130 calls per
+    forward)."""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return _RAW_STREAM(_GET_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -249,7 +249,7 @@ _NO_SPLITK = bool(os.environ.get('HPL_NO_SPLITK'))      # A/B switch for benchma
 
 def _splitk_workspace(device):
     """Per-(device, stream) scratch for split-K partial tiles: 16 splits x 1M floats = 64 MB."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, stream())
     ws = _SPLITK_WS.get(key)
     if ws is None:
         ws = _SPLITK_WS[key] = torch.empty(16 << 20, dtype=torch.float32, device=device)

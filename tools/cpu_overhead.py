@@ -29,3 +29,9 @@ with torch.no_grad():
     for _ in range(5): model(t1[None], t2[None], lat)
     pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+pstats.Stats(pr).sort_stats('tottime').print_stats(22)
+with torch.no_grad():
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(5): gen.build(t1, t2).prepare()
+    pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats('tottime').print_stats(22)
