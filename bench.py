@@ -41,7 +41,7 @@ def gconv_class(M, N, K=1 << 20):
         tn = (N + 127) // 128
         return '64x128' if t64 * tn >= 512 else '64x64'
     if N > 32:
-        return '128x64' if t128 >= 512 else '64x64'
+        return '64x64'
     return '128x32' if t128 >= 512 else '64x32'
 
 

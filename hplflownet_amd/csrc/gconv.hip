@@ -615,8 +615,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
         if (t64 * tn >= 512) launch_cfg<64, 128, 2, 4>(p, avec, s);
         else launch_cfg<64, 64, 2, 2>(p, avec, s);
     } else if (p.N > 32) {
-        if (t128 >= 512) launch_cfg<128, 64, 2, 2>(p, avec, s);
-        else launch_cfg<64, 64, 2, 2>(p, avec, s);
+        launch_cfg<64, 64, 2, 2>(p, avec, s);       // 4 workgroups per CU; 128x64 measured 50 % slower at M = 70 k
     } else {
         if (t128 >= 512) launch_cfg<128, 32, 4, 1>(p, avec, s);
         else launch_cfg<64, 32, 2, 1>(p, avec, s);

@@ -19,6 +19,7 @@ shapes = [  # name, level, C_in, C_out, F
     ('bcn3_ blur', 2, 388, 256, 15), ('bcn1 blur', 0, 68, 64, 15), ('bcn2 blur', 1, 68, 64, 15),
     ('conv2', -1, 1024, 1024, 1), ('conv3', -1, 1024, 512, 1),
     ('bcn4_ blur', 3, 260, 256, 15), ('corr1 B-term', -2, 64, 32, 15),
+    ('pair bcn1 blur', -10, 68, 64, 15), ('pair bcn2 blur', -11, 68, 64, 15), ('pair bcn3 blur', -12, 68, 64, 15),
 ]
 only = os.environ.get('SHAPES')          # comma-separated substrings
 if only:
@@ -28,6 +29,9 @@ reps = int(os.environ.get('REPS', '5'))
 for name, lvl, C, O, F in shapes:
     if lvl >= 0:
         tbl = lat.levels[lvl].blur[0].t
+        M = tbl.shape[1]
+    elif lvl <= -10:                     # Down BCL of the stacked pair: level -10 - lvl, pair blur table
+        tbl = lat.levels[-10 - lvl].blur.pair.t
         M = tbl.shape[1]
     elif lvl == -2:                      # corr B-term of level 2: 15*H1 virtual vertices, permuted corr2 table
         tbl = lat.levels[2].corr2.t
