@@ -276,3 +276,45 @@ def test_pair_batched_down_path_equals_per_cloud(cls, nsc, n1, n2):
     assert torch.equal(y_sep, y_ref)
     scale = max(1.0, float(y_sep.abs().max()))
     assert float((y_pair - y_sep).abs().max()) < 1e-5 * scale
+
+
+def test_device_lattice_fuzz_vs_oracle():
+    """Randomised clouds (sizes 1..300, ragged pairs, duplicated points, points on a line / plane, huge and
+    tiny coordinates): every table of the GPU lattice equals the C oracle bit for bit."""
+    import hplflownet_amd as H
+    from hypothesis import given, settings, strategies as st
+    from oracle import lattice_oracle as LO
+    gen = H.GenerateDataUnsymmetric(types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP), device=DEV)
+
+    @settings(max_examples=25, deadline=None, derandomize=True)
+    @given(st.integers(1, 300), st.integers(1, 300), st.integers(0, 2 ** 31 - 1),
+           st.sampled_from(['cloud', 'dup', 'line', 'plane', 'far', 'tiny']))
+    def check(n1, n2, seed, kind):
+        rng = np.random.RandomState(seed)
+        p1 = rng.uniform(-8, 8, (n1, 3)).astype(np.float32)
+        p1[:, 2] = rng.uniform(1.5, 35, n1)
+        p2 = rng.uniform(-8, 8, (n2, 3)).astype(np.float32)
+        p2[:, 2] = rng.uniform(1.5, 35, n2)
+        if kind == 'dup':
+            p1[:] = p1[rng.randint(0, max(1, n1 // 4), n1)]
+            p2[: min(n1, n2)] = p1[: min(n1, n2)]
+        elif kind == 'line':
+            p1[:, :2] = 0.0
+            p2[:, 1:] = p2[0, 1:]
+        elif kind == 'plane':
+            p1[:, 2] = 10.0
+            p2[:, 0] = -1.0
+        elif kind == 'far':
+            p1 *= 40.0
+            p2 *= 40.0
+        elif kind == 'tiny':
+            p1 *= 1e-3
+            p2 *= 1e-3
+        _, _, _, lat = gen([p1, p2, np.zeros_like(p1)])
+        gd = LO.generate_data(p1, p2, SCALES_FILTER_MAP)
+        for l, (x, y) in enumerate(zip(H.to_reference_format(lat), gd)):
+            for k in y:
+                vx = x[k].cpu().numpy() if torch.is_tensor(x[k]) else x[k]
+                assert np.array_equal(np.asarray(vx), np.asarray(y[k])), (n1, n2, seed, kind, l, k)
+
+    check()
