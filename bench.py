@@ -371,12 +371,22 @@ def main():
         lat0 = gen.build(*pairs[0])
         if full:
             fl = [2.0 * lat0.levels[L].H[0] * 15 * c * o for L, c, o in ((0, 580, 1024), (1, 324, 512))]
-            fr = [needed_slice_fraction(lat0.levels[L].blur[0], c, BM=64) for L, c in ((0, 580), (1, 324))]
+            def executed(tbl, c):
+                # share of (tile, slice) pairs executed; with tap groups: one pass per group, own row order
+                groups = tbl.groups()
+                if not groups:
+                    return needed_slice_fraction(tbl, c, BM=64)
+                F = tbl.t.shape[0]
+                return sum((f1 - f0) * needed_slice_fraction(types.SimpleNamespace(t=tbl.t[f0:f1], perm=p), c, BM=64)
+                           for f0, f1, p in groups) / F
+            fr = [executed(lat0.levels[L].blur[0], c) for L, c in ((0, 580), (1, 324))]
             roofline['executed_fraction'] = (fl[0] * fr[0] + fl[1] * fr[1]) / (fl[0] + fl[1])
             roofline['achieved_executed'] = (roofline['achieved'] or 0.0) * roofline['executed_fraction']
         ex = kernels.get(dominant, {})
         roofline['exclusive'] = {'achieved': ex.get('achieved'), 'frac': ex.get('frac'),
                                  'avg_launch_us': ex.get('avg_launch_us')}
+        if full and ex.get('achieved'):
+            roofline['exclusive']['achieved_executed'] = ex['achieved'] * roofline['executed_fraction']
         roofline['note'] = ('achieved = algorithmic flops (2*H*15*C_in*C_out, what the reference multiplies) / HIP-event '
                             'time of the launches inside the timed loop, where kernels of up to forward_streams pairs '
                             'share the GPU; exclusive = the same launches alone on the GPU (separate single-stream '

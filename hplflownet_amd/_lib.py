@@ -27,7 +27,7 @@ class GConvDesc(ctypes.Structure):
                 ('Wt', c_vp), ('ldw', c_i64), ('N', c_i32), ('act', c_i32), ('slope', c_f32),
                 ('bias', c_vp), ('res', c_vp), ('ldres', c_i64), ('res_mod', c_i64),
                 ('Y', c_vp), ('ldy', c_i64),
-                ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('reserved', c_i32),
+                ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('w_rows', c_i32),
                 ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64)]
 
 

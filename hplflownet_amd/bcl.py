@@ -19,6 +19,8 @@ never materialised, so there is nothing to chunk.
 """
 import collections
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -95,6 +97,10 @@ def pointwise_conv(x, conv, act, use_leaky, out=None):
 
 
 # ----------------------------------------------------------------------------- table cache
+#: the multi-pass contraction pays when a pass is still long: C >= 256 -> >= 40 slices per pass and tile
+GROUPS_MIN_CHANNELS = 256
+
+
 class NbrTable(object):
     """int32 neighbour table [F, M] on the device + lazily checked symmetry."""
 
@@ -107,6 +113,11 @@ class NbrTable(object):
         self._sym = None
         self._perm = False      # False = not computed yet, None = not applicable
         self._taps = False
+        self._groups = False
+        #: set by the lattice builder: vertices per input point of this level.  A sparse lattice (few
+        #: points per vertex -> most neighbour slots empty) is where the multi-pass contraction pays
+        #: (bcn1_, 42 % of the taps present: 2.62 -> 2.08 ms; bcn2_, 72 %: no gain)
+        self.vertices_per_point = None
 
     @property
     def perm(self):
@@ -115,6 +126,24 @@ class NbrTable(object):
             F, M = self.t.shape
             self._perm = ops.tap_order(self.t) if (1 < F <= 15 and M >= self.PERM_MIN_ROWS) else None
         return self._perm
+
+    #: number of tap groups of the multi-pass contraction (ops.gconv tap_groups); env for A/B runs
+    TAP_GROUPS = int(os.environ.get('HPL_TAP_GROUPS', '2'))      # swept 1 / 2 / 3 / 5 end to end: 193 / 205 / 204 / 173 pairs/s
+    GROUPS_MIN_SPARSITY = 2.0
+
+    def groups(self):
+        """[(f0, f1, perm)] for TAP_GROUPS groups of consecutive taps, each with its own row order
+        (tap_order of the sub-table); None when the table is not reordered at all."""
+        if self._groups is False:
+            F, M = self.t.shape
+            G = self.TAP_GROUPS
+            sparse = self.vertices_per_point is None or self.vertices_per_point >= self.GROUPS_MIN_SPARSITY
+            if G <= 1 or not sparse or not (1 < F <= 15 and M >= self.PERM_MIN_ROWS):
+                self._groups = None
+            else:
+                cuts = [round(i * F / G) for i in range(G + 1)]
+                self._groups = [(f0, f1, ops.tap_order(self.t[f0:f1])) for f0, f1 in zip(cuts[:-1], cuts[1:])]
+        return self._groups
 
     #: per-tap vertex lists pay for wide layers only (wgrad tap mode needs C >= 128-ish) and big tables
     TAPS_MIN_ROWS = 4096
@@ -272,7 +301,8 @@ def _run_conv_stack(x, stack, table, M, F, use_leaky, out=None):
             x = ops.gconv(x, conv.weight, conv.bias, table.t, M, F, act=act,
                           bwd_mode=table.bwd_mode(x.shape[0]) if torch.is_grad_enabled() else 'scatter',
                           out=o, slope=_slope(use_leaky),
-                          row_perm=table.perm, taps=table.taps if conv.in_channels >= 100 else None)
+                          row_perm=table.perm, taps=table.taps if conv.in_channels >= 100 else None,
+                          tap_groups=table.groups if conv.in_channels >= GROUPS_MIN_CHANNELS else None)
         else:
             x = ops.gconv(x, conv.weight, conv.bias, None, M, 1, act=act, bwd_mode='dense', out=o,
                           slope=_slope(use_leaky))

@@ -548,7 +548,9 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.ws = d->ws; p.ws_bytes = d->ws ? d->ws_bytes : 0; p.splits = 1; p.partial = nullptr;
     p.tiles_m = p.tiles_n = 0;
     p.a_bytes = ((d->rows_a - 1) * d->lda + d->C) * 4;
-    p.w_bytes = cdiv(p.K, 32) * 32 * d->ldw * 4;
+    const int64_t w_rows = d->w_rows ? (int64_t)d->w_rows : cdiv(p.K, 32) * 32;
+    HPL_REQUIRE(w_rows >= p.K, "%s: w_rows=%lld < F*C=%d", who, (long long)w_rows, p.K);
+    p.w_bytes = imin(w_rows, cdiv(p.K, 32) * 32) * d->ldw * 4;
     HPL_REQUIRE(p.a_bytes < (int64_t)INT32_MAX && p.w_bytes < (int64_t)INT32_MAX,
                 "%s: A or Wt spans >= 2 GiB (32-bit buffer offsets)", who);
     return HPL_OK;

@@ -81,6 +81,8 @@ class GenerateDataUnsymmetric(object):
             lv.H = (H[0], H[1])
             lv.clouds = [ops.CloudTables(bary[c], off[c], H[c]) for c in (0, 1)]
             lv.blur = PairBlur(blur_p, H[0]) if blur_p is not None else [None, None]
+            if blur_p is not None:
+                lv.blur[0].vertices_per_point = H[0] / float(n[0])
             lv.emg = emg
             lv.emg_pair = emg_p
             lv.pair = ops.PairTables(lv.clouds[0], lv.clouds[1])

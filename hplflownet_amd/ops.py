@@ -214,9 +214,10 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
     d.M, d.C, d.F = M, C, F
     if C > A.shape[1]:
         raise _lib.HplError('C=%d exceeds the %d channels of A' % (C, A.shape[1]))
-    if Wt.shape[0] < round_up(F * C, 32) or Wt.shape[1] < N or not Wt.is_contiguous():
+    if Wt.shape[0] < F * C or Wt.shape[1] < N or not Wt.is_contiguous():
         raise _lib.HplError('Wt %s too small for K=%d N=%d' % (tuple(Wt.shape), F * C, N))
     d.Wt, d.ldw, d.N = ptr(Wt), Wt.shape[1], N
+    d.w_rows = min(Wt.shape[0], round_up(F * C, 32))     # rows past the image read as zero
     d.act, d.slope = act, slope
     d.bias = ptr(bias)
     if res is not None:
@@ -408,8 +409,14 @@ class GConvFn(torch.autograd.Function):
 
 
 def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_mod=0, bwd_mode='scatter',
-          out=None, slope=LEAKY_RATE, row_perm=None, taps=None):
-    """Autograd-aware gathered convolution; with grad disabled it can write into `out`."""
+          out=None, slope=LEAKY_RATE, row_perm=None, taps=None, tap_groups=None):
+    """Autograd-aware gathered convolution; with grad disabled it can write into `out`.
+
+    tap_groups (inference): [(f0, f1, perm), ...] -- the contraction is run as one pass per group of
+    consecutive taps, each with the rows sorted by the group's own (short) tap mask, the passes
+    accumulating into the output (bias in the first, activation in the last).  A 5-bit mask leaves
+    ~32 row classes, so 64-row tiles are nearly pure and absent taps are skipped almost exactly
+    (43 % instead of 59 % of the slices executed on bcn1_, 72 % instead of 83 % on bcn2_)."""
     O = weight.shape[0]
     Ctot = weight.numel() // (O * F)
     C = Ctot if C is None else C
@@ -422,6 +429,15 @@ def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_
             return out
         return y
     Wt = _cached_relayout(weight, C, O, F, Ctot, c0)
+    groups = tap_groups() if callable(tap_groups) else tap_groups
+    if groups and nbr is not None and len(groups) > 1:
+        y = out
+        for i, (f0, f1, perm) in enumerate(groups):
+            first, last = i == 0, i == len(groups) - 1
+            y = gconv_raw(A, nbr[f0:f1], M, C, f1 - f0, Wt[f0 * C:], O, bias=bias if first else None,
+                          act=act if last else ACT_NONE, res=res if first else y,
+                          res_mod=res_mod if first else 0, out=y, slope=slope, row_perm=perm)
+        return y
     return gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope,
                      row_perm=row_perm)
 

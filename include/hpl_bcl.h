@@ -149,7 +149,10 @@ typedef struct hpl_gconv_desc {
     const int32_t *scat;
     int64_t scat_stride;
     int32_t scat_c;
-    int32_t reserved;
+    /* rows of Wt that exist (0 = roundup(F*C, 32), i.e. a zero-padded image).  A smaller value
+     * (>= F*C) lets Wt be a row range of a bigger image -- one tap group of it: rows past w_rows
+     * read as zero. */
+    int32_t w_rows;
     /* optional permutation of the M output rows (hpl_tap_order): tile row j computes and writes
      * output row row_perm[j]; the result is unchanged, rows of one tile share absent taps so that
      * whole contraction slices can be skipped.  NULL = identity. */

@@ -193,3 +193,35 @@ def test_engine_train_validate_resume(tmp_path):
     # the optimiser state travelled too: the next step is identical
     a, b = tr.train_epoch(data), tr2.train_epoch(data)
     assert abs(a - b) < 1e-5 * max(1.0, abs(a)), (a, b)
+
+
+@pytest.mark.parametrize('G', [2, 3, 5])
+def test_tap_group_passes_equal_single_pass(G):
+    """Inference runs wide stencil convs as one pass per group of consecutive taps (own row order per
+    group, passes accumulate into the output): same result as the single pass up to fp32 summation
+    order, bias / residual / activation applied once."""
+    from hplflownet_amd import ops
+    from hplflownet_amd.bcl import NbrTable
+    from hplflownet_amd.ops import ACT_LEAKY
+    rng = np.random.RandomState(G)
+    M, C, O, F = 20000, 260, 96, 15
+    nbr = np.where(rng.rand(F, M) < 0.45, rng.randint(0, M, size=(F, M)), -1).astype(np.int32)
+    nbr[0] = np.arange(M)
+    tbl = NbrTable(torch.from_numpy(nbr).to(DEV))
+    tbl.TAP_GROUPS = G
+    A = torch.from_numpy(rng.randn(M, C).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rng.randn(O, C, F, 1) / np.sqrt(C * F)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rng.randn(O).astype(np.float32)).to(DEV)
+    res = torch.from_numpy(rng.randn(M, O).astype(np.float32)).to(DEV)
+    groups = tbl.groups()
+    assert len(groups) == G and groups[0][0] == 0 and groups[-1][1] == F
+    for f0, f1, perm in groups:
+        assert sorted(perm.cpu().tolist()) == list(range(M))
+    with torch.no_grad():
+        one = ops.gconv(A, W, b, tbl.t, M, F, act=ACT_LEAKY, res=res, res_mod=M, row_perm=tbl.perm)
+        out = torch.empty(M, O + 8, device=DEV)[:, 4:4 + O]                  # strided destination
+        many = ops.gconv(A, W, b, tbl.t, M, F, act=ACT_LEAKY, res=res, res_mod=M, row_perm=tbl.perm,
+                         tap_groups=groups, out=out)
+    assert many.data_ptr() == out.data_ptr()
+    assert rel_err(many.cpu().numpy(), one.cpu().numpy()) < 2e-6
+    assert float((many - one).abs().max()) < 1e-4
