@@ -87,7 +87,7 @@ class DeviceLattice(object):
             for tbl in tables:
                 if tbl is not None:
                     tbl.perm
-            if not for_training and isinstance(lv.blur, PairBlur):
+            if isinstance(lv.blur, PairBlur):
                 lv.blur[0].groups()             # row orders of the tap groups (wide Up convs, multi-pass)
         if for_training:
             self.resolve_symmetry()

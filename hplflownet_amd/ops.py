@@ -336,6 +336,23 @@ def _mirror_map(F, device):
     return _MIRROR[key]
 
 
+def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
+                 slope=LEAKY_RATE, row_perm=None):
+    """gconv_raw, run as one pass per tap group when `groups` = [(f0, f1, perm), ...] is given: pass i
+    contracts taps [f0, f1) (rows f0*C.. of Wt, rows f0.. of the table) in its own row order and adds
+    to the output of the passes before it; bias / residual enter the first pass, the activation the last."""
+    if not groups or nbr is None or len(groups) < 2:
+        return gconv_raw(A, nbr, M, C, F, Wt, N, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope,
+                         row_perm=row_perm)
+    y = out
+    for i, (f0, f1, perm) in enumerate(groups):
+        first, last = i == 0, i == len(groups) - 1
+        y = gconv_raw(A, nbr[f0:f1], M, C, f1 - f0, Wt[f0 * C:], N, bias=bias if first else None,
+                      act=act if last else ACT_NONE, res=res if first else y, res_mod=res_mod if first else 0,
+                      out=y, slope=slope, row_perm=perm)
+    return y
+
+
 class GConvFn(torch.autograd.Function):
     """Gathered convolution Y = act(b + sum_f W_f . A[nbr[f]]) with the conv weight in its torch
     layout `weight.view(O, Ctot, F)`; channels [c0, c0+C) of the weight are used.
@@ -345,12 +362,13 @@ class GConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm=None,
-                taps=None):
+                taps=None, groups=None):
         O = weight.shape[0]
         Ctot = weight.numel() // (O * F)
         Wt = weight_relayout(weight, C, O, F, F, Ctot * F, 1, base=c0 * F)
-        Y = gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=act, res=res, res_mod=res_mod, slope=slope,
-                      row_perm=row_perm)
+        Y = gconv_passes(A, nbr, M, C, F, Wt, O, groups, bias=bias, act=act, res=res, res_mod=res_mod, slope=slope,
+                         row_perm=row_perm)
+        ctx.groups = groups          # the mirror backward gathers through the same table: same groups
         ctx.slope = slope
         ctx.row_perm = row_perm      # same table in the mirror backward -> same tap masks -> same order
         ctx.taps = taps
@@ -377,7 +395,7 @@ class GConvFn(torch.autograd.Function):
                     raise _lib.HplError('mirror backward needs a table over the same vertex set')
                 WtT = weight_relayout(weight, O, C, F, Ctot * F, F, 1, base=c0 * F,
                                       fmap=_mirror_map(F, weight.device))
-                gA_c = gconv_raw(g, nbr, M, O, F, WtT, C, row_perm=ctx.row_perm)
+                gA_c = gconv_passes(g, nbr, M, O, F, WtT, C, ctx.groups, row_perm=ctx.row_perm)
             else:   # scatter: G[m, (f, c)] = g[m] . W[:, c, f], added into row nbr[f, m]
                 # columns ordered (f, c): source element (o, f*C + c) = W[o, c0 + c, f]
                 Wcols = weight.view(O, Ctot, F)[:, c0:c0 + C, :].permute(0, 2, 1).reshape(O, F * C).contiguous()
@@ -405,14 +423,14 @@ class GConvFn(torch.autograd.Function):
                 gres = g.view(M // res_mod, res_mod, O).sum(dim=0)
             else:
                 gres = g
-        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None, None, None
+        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None, None, None, None
 
 
 def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_mod=0, bwd_mode='scatter',
           out=None, slope=LEAKY_RATE, row_perm=None, taps=None, tap_groups=None):
     """Autograd-aware gathered convolution; with grad disabled it can write into `out`.
 
-    tap_groups (inference): [(f0, f1, perm), ...] -- the contraction is run as one pass per group of
+    tap_groups: [(f0, f1, perm), ...] -- the contraction is run as one pass per group of
     consecutive taps, each with the rows sorted by the group's own (short) tap mask, the passes
     accumulating into the output (bias in the first, activation in the last).  A 5-bit mask leaves
     ~32 row classes, so 64-row tiles are nearly pure and absent taps are skipped almost exactly
@@ -423,23 +441,16 @@ def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_
     if torch.is_grad_enabled() and (A.requires_grad or weight.requires_grad or
                                     (res is not None and res.requires_grad)):
         y = GConvFn.apply(A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm,
-                          taps() if callable(taps) else taps)
+                          taps() if callable(taps) else taps,
+                          tap_groups() if callable(tap_groups) else tap_groups)
         if out is not None:
             out.copy_(y)
             return out
         return y
     Wt = _cached_relayout(weight, C, O, F, Ctot, c0)
     groups = tap_groups() if callable(tap_groups) else tap_groups
-    if groups and nbr is not None and len(groups) > 1:
-        y = out
-        for i, (f0, f1, perm) in enumerate(groups):
-            first, last = i == 0, i == len(groups) - 1
-            y = gconv_raw(A, nbr[f0:f1], M, C, f1 - f0, Wt[f0 * C:], O, bias=bias if first else None,
-                          act=act if last else ACT_NONE, res=res if first else y,
-                          res_mod=res_mod if first else 0, out=y, slope=slope, row_perm=perm)
-        return y
-    return gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope,
-                     row_perm=row_perm)
+    return gconv_passes(A, nbr, M, C, F, Wt, O, groups, bias=bias, act=act, res=res, res_mod=res_mod, out=out,
+                        slope=slope, row_perm=row_perm)
 
 
 _WT_CACHE = collections.OrderedDict()
