@@ -60,6 +60,8 @@ _SIGNATURES = {
     'hpl_transpose': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     'hpl_table_symmetric': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp]),
     'hpl_lattice_keys': (ctypes.c_int, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'hpl_lattice_keys_pair': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_i64, c_i64, c_f32, c_vp, c_vp,
+                                             c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'hpl_lattice_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'hpl_lattice_hash': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'hpl_lattice_neighbors': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, ctypes.c_int,

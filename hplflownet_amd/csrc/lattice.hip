@@ -57,12 +57,10 @@ Elev make_elev() {
 __device__ __forceinline__ int canonical(int i, int j) { return (j < 4 - i) ? j : j - 4; }
 
 // transforms/transforms.py:300-353, same statement order as oracle hpl_keys_and_barycentric
-__global__ void k_lattice_keys(const float *__restrict__ pc, int64_t N, float scale, const Elev E,
-                               int32_t *__restrict__ keys, float *__restrict__ bary,
-                               float *__restrict__ emg, int64_t emg_ld) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float p0 = pc[n] * scale, p1 = pc[N + n] * scale, p2 = pc[2 * N + n] * scale;
+__device__ __forceinline__ void lattice_point(float q0, float q1, float q2, int64_t n, int64_t N, float scale,
+                                              const Elev &E, int32_t *__restrict__ keys, float *__restrict__ bary,
+                                              float *__restrict__ emg, int64_t emg_ld) {
+    const float p0 = q0 * scale, p1 = q1 * scale, p2 = q2 * scale;
     float el[4], gr[4], res[4];
     int rank[4];
 #pragma unroll
@@ -123,6 +121,49 @@ __global__ void k_lattice_keys(const float *__restrict__ pc, int64_t N, float sc
         k.w = g + canonical(rank[j], 3);
         *reinterpret_cast<int4 *>(keys + ((int64_t)j * N + n) * 4) = k;
     }
+}
+
+__global__ void k_lattice_keys(const float *__restrict__ pc, int64_t N, float scale, const Elev E,
+                               int32_t *__restrict__ keys, float *__restrict__ bary,
+                               float *__restrict__ emg, int64_t emg_ld) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    lattice_point(pc[n], pc[N + n], pc[2 * N + n], n, N, scale, E, keys, bary, emg, emg_ld);
+}
+
+// Both clouds in one launch (blockIdx.z).  The points are either given ((3, N) arrays) or are the
+// vertices of the previous level, computed on the fly from their integer keys exactly as
+// hpl_lattice_next_points does (transforms.py:461-467) -- the (3, H) arrays are never written.
+struct KeysPair {
+    const float *pc[2];
+    const int32_t *vk[2];
+    int64_t vstride[2], n[2];
+    int32_t *keys[2];
+    float *bary[2], *emg[2];
+};
+
+__global__ void k_lattice_keys_pair(const KeysPair a, float divisor, float scale, const Elev E, int64_t emg_ld) {
+    const int c = blockIdx.z;
+    const int64_t N = a.n[c];
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float q[3];
+    if (a.pc[c]) {
+        q[0] = a.pc[c][n]; q[1] = a.pc[c][N + n]; q[2] = a.pc[c][2 * N + n];
+    } else {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)a.vk[c][(int64_t)j * a.vstride[c] + n] / divisor;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float acc = E.e[0 * 3 + i] * v[0];
+            acc = fmaf(E.e[1 * 3 + i], v[1], acc);
+            acc = fmaf(E.e[2 * 3 + i], v[2], acc);
+            acc = fmaf(E.e[3 * 3 + i], v[3], acc);
+            q[i] = acc;
+        }
+    }
+    lattice_point(q[0], q[1], q[2], n, N, scale, E, a.keys[c], a.bary[c], a.emg[c], emg_ld);
 }
 
 // ---------------------------------------------------------------- workspace layout
@@ -194,8 +235,16 @@ __global__ void k_init_ws(int32_t *mm, int64_t *tk1, int32_t *tf1, int64_t cap1,
 }
 
 // per-coordinate min/max over keys [4][n][4] of one cloud (transforms.py:384-385)
-__global__ void k_minmax(const int32_t *__restrict__ keys, int64_t n, int32_t *mm) {
+// Both clouds of a level go through every stage in ONE launch: blockIdx.z selects the cloud.
+struct Two {
+    const int32_t *keys[2];
+    int64_t n[2];
+};
+
+__global__ void k_minmax(const Two in, int32_t *mm) {
     const int j = blockIdx.y;   // coordinate
+    const int32_t *keys = in.keys[blockIdx.z];
+    const int64_t n = in.n[blockIdx.z];
     const int4 *p = reinterpret_cast<const int4 *>(keys + (int64_t)j * n * 4);
     int lo = INT32_MAX, hi = INT32_MIN;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -216,10 +265,30 @@ __global__ void k_minmax(const int32_t *__restrict__ keys, int64_t n, int32_t *m
 
 // Hash build with LDS staging.  256 points per workgroup = 1024 entries.
 constexpr int LSLOTS = 2048;
-__global__ void __launch_bounds__(256) k_hash_insert(const int32_t *__restrict__ keys, int64_t n,
-                                                     const int32_t *__restrict__ mm,
-                                                     int64_t *__restrict__ tkeys, int32_t *__restrict__ tfirst,
-                                                     uint64_t mask, int32_t *__restrict__ slot_of) {
+struct HashArgs {
+    const int32_t *keys[2];
+    int64_t n[2];
+    int64_t *tkeys[2];
+    int32_t *tfirst[2];
+    uint64_t mask[2];
+    int32_t *slot[2];
+    int32_t *flag[2];
+    int32_t *scan[2];
+    int32_t *tid[2];
+    int32_t *vkeys[2];
+    int32_t *off[2];
+    int32_t *counts;
+};
+
+__global__ void __launch_bounds__(256) k_hash_insert(const HashArgs a, const int32_t *__restrict__ mm) {
+    const int c = blockIdx.z;
+    const int32_t *__restrict__ keys = a.keys[c];
+    const int64_t n = a.n[c];
+    if ((int64_t)blockIdx.x * 256 >= n) return;          // grid sized for the larger cloud
+    int64_t *__restrict__ tkeys = a.tkeys[c];
+    int32_t *__restrict__ tfirst = a.tfirst[c];
+    const uint64_t mask = a.mask[c];
+    int32_t *__restrict__ slot_of = a.slot[c];
     __shared__ unsigned long long lkeys[LSLOTS];
     __shared__ int lmin[LSLOTS];
     __shared__ int lglob[LSLOTS];
@@ -266,20 +335,25 @@ __global__ void __launch_bounds__(256) k_hash_insert(const int32_t *__restrict__
     }
 }
 
-__global__ void k_flags(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ tfirst, int64_t E,
-                        int32_t *__restrict__ flag) {
+__global__ void k_flags(const HashArgs a) {
+    const int c = blockIdx.z;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < E) flag[j] = (tfirst[slot_of[j]] == (int32_t)j) ? 1 : 0;
+    if (j < 4 * a.n[c]) a.flag[c][j] = (a.tfirst[c][a.slot[c][j]] == (int32_t)j) ? 1 : 0;
 }
 
 // owners publish their id (= rank among owners, i.e. first-appearance order) and vertex key
-__global__ void k_assign_ids(const int32_t *__restrict__ keys, int64_t n, const int32_t *__restrict__ slot_of,
-                             const int32_t *__restrict__ flag, const int32_t *__restrict__ scan,
-                             int32_t *__restrict__ tid, int32_t *__restrict__ vkeys, int64_t vstride,
-                             int32_t *__restrict__ count_out) {
-    const int64_t E = 4 * n;
+__global__ void k_assign_ids(const HashArgs a) {
+    const int c = blockIdx.z;
+    const int32_t *__restrict__ keys = a.keys[c];
+    const int64_t n = a.n[c];
+    const int32_t *__restrict__ slot_of = a.slot[c];
+    const int32_t *__restrict__ flag = a.flag[c];
+    const int32_t *__restrict__ scan = a.scan[c];
+    int32_t *__restrict__ tid = a.tid[c];
+    int32_t *__restrict__ vkeys = a.vkeys[c];
+    const int64_t E = 4 * n, vstride = E;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0) *count_out = scan[E];
+    if (j == 0) a.counts[c] = scan[E];
     if (j >= E || !flag[j]) return;
     const int32_t id = scan[j];
     tid[slot_of[j]] = id;
@@ -289,11 +363,12 @@ __global__ void k_assign_ids(const int32_t *__restrict__ keys, int64_t n, const 
     for (int c = 0; c < 4; ++c) vkeys[(int64_t)c * vstride + id] = keys[((int64_t)c * n + p) * 4 + r];
 }
 
-__global__ void k_offsets(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ tid, int64_t n,
-                          int32_t *__restrict__ off) {
+__global__ void k_offsets(const HashArgs a) {
+    const int c = blockIdx.z;
+    const int64_t n = a.n[c];
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= 4 * n) return;
-    off[(j & 3) * n + (j >> 2)] = tid[slot_of[j]];
+    a.off[c][(j & 3) * n + (j >> 2)] = a.tid[c][a.slot[c][j]];
 }
 
 __device__ __forceinline__ int32_t lookup(const int64_t *__restrict__ tkeys, const int32_t *__restrict__ tid,
@@ -351,6 +426,30 @@ __global__ void k_neighbors(const int32_t *__restrict__ vkeys, int64_t vstride, 
     out[(int64_t)f * ostride + h] = id >= 0 ? id + shift : -1;
 }
 
+// blur tables of both clouds in one launch (blockIdx.z = cloud), each against its own hash table
+struct NbrArgs {
+    const int32_t *vkeys[2];
+    int64_t vstride[2], H[2];
+    const int64_t *tkeys[2];
+    const int32_t *tid[2];
+    uint64_t mask[2];
+    int32_t *out[2];
+    int64_t ostride[2];
+    int32_t shift[2];
+};
+
+__global__ void k_neighbors2(const NbrArgs a, const Offsets offs, const int32_t *__restrict__ mm) {
+    const int c = blockIdx.z;
+    const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (h >= a.H[c]) return;
+    int k[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = a.vkeys[c][(int64_t)j * a.vstride[c] + h] + offs.v[f * 4 + j];
+    const int32_t id = lookup(a.tkeys[c], a.tid[c], a.mask[c], pack_key(k, mm));
+    a.out[c][(int64_t)f * a.ostride[c] + h] = id >= 0 ? id + a.shift[c] : -1;
+}
+
 // corr2p[k][f*H1 + h] = id in table 2 of (key1_h + coff_k + foff_f)   (transforms.py:223-241)
 __global__ void k_neighbors_corr2(const int32_t *__restrict__ vkeys, int64_t vstride, int64_t H1,
                                   const Offsets coff, const Offsets foff, const int32_t *__restrict__ mm,
@@ -394,6 +493,25 @@ extern "C" int hpl_lattice_keys(const float *pc, int64_t N, float scale, int32_t
     return HPL_OK;
 }
 
+extern "C" int hpl_lattice_keys_pair(const float *pc1, const float *pc2, const int32_t *vk1, const int32_t *vk2,
+                                     int64_t vstride1, int64_t vstride2, float divisor, int64_t n1, int64_t n2,
+                                     float scale, int32_t *keys1, int32_t *keys2, float *bary1, float *bary2,
+                                     float *emg1, float *emg2, int64_t emg_ld, hplStream stream) {
+    HPL_REQUIRE((pc1 && pc2) || (vk1 && vk2 && divisor != 0.f && vstride1 >= n1 && vstride2 >= n2),
+                "hpl_lattice_keys_pair: give the points or the previous level's vertex keys");
+    HPL_REQUIRE(keys1 && keys2 && bary1 && bary2 && emg1 && emg2 && n1 > 0 && n2 > 0 && (emg_ld == 0 || emg_ld >= 4),
+                "hpl_lattice_keys_pair: bad arguments");
+    HPL_REQUIRE(aligned16(keys1) && aligned16(keys2), "hpl_lattice_keys_pair: keys must be 16-byte aligned");
+    KeysPair a;
+    a.pc[0] = pc1; a.pc[1] = pc2; a.vk[0] = pc1 ? nullptr : vk1; a.vk[1] = pc2 ? nullptr : vk2;
+    a.vstride[0] = vstride1; a.vstride[1] = vstride2; a.n[0] = n1; a.n[1] = n2;
+    a.keys[0] = keys1; a.keys[1] = keys2; a.bary[0] = bary1; a.bary[1] = bary2; a.emg[0] = emg1; a.emg[1] = emg2;
+    k_lattice_keys_pair<<<dim3((unsigned)cdiv(imax(n1, n2), 256), 1, 2), 256, 0, to_stream(stream)>>>(
+        a, divisor, scale, make_elev(), emg_ld);
+    HPL_CHECK_LAUNCH("hpl_lattice_keys_pair");
+    return HPL_OK;
+}
+
 extern "C" int64_t hpl_lattice_workspace_bytes(int64_t n1, int64_t n2) {
     if (n1 <= 0 || n2 <= 0) return 0;
     return carve(nullptr, n1, n2).bytes;
@@ -413,23 +531,30 @@ extern "C" int hpl_lattice_hash(const int32_t *keys1, int64_t n1, const int32_t 
     const int64_t capmax = imax(w.c[0].cap, w.c[1].cap);
     k_init_ws<<<(int)cdiv(capmax, 256), 256, 0, s>>>(w.mm, w.c[0].tkeys, w.c[0].tfirst, w.c[0].cap, w.c[1].tkeys,
                                                       w.c[1].tfirst, w.c[1].cap);
+    HashArgs a;
     const int32_t *keys[2] = {keys1, keys2};
     int32_t *offs[2] = {off1, off2};
     int32_t *vk[2] = {vkeys1, vkeys2};
     for (int c = 0; c < 2; ++c) {
-        dim3 g((unsigned)imin(cdiv(w.c[c].n, 1024), 16), 4);   // few groups: 8 contended atomics per wave
-        k_minmax<<<g, 256, 0, s>>>(keys[c], w.c[c].n, w.mm);
+        const CloudWS &q = w.c[c];
+        a.keys[c] = keys[c]; a.n[c] = q.n; a.tkeys[c] = q.tkeys; a.tfirst[c] = q.tfirst; a.mask[c] = q.mask;
+        a.slot[c] = q.slot; a.flag[c] = q.flag; a.scan[c] = q.scan; a.tid[c] = q.tid; a.vkeys[c] = vk[c];
+        a.off[c] = offs[c];
     }
+    a.counts = counts;
+    const int64_t nmax = imax(n1, n2), emax = 4 * nmax;
+    Two two;
+    two.keys[0] = keys1; two.keys[1] = keys2; two.n[0] = n1; two.n[1] = n2;
+    k_minmax<<<dim3((unsigned)imin(cdiv(nmax, 1024), 16), 4, 2), 256, 0, s>>>(two, w.mm);   // few groups: 8 contended atomics per wave
+    k_hash_insert<<<dim3((unsigned)cdiv(nmax, 256), 1, 2), 256, 0, s>>>(a, w.mm);
+    k_flags<<<dim3((unsigned)cdiv(emax, 256), 1, 2), 256, 0, s>>>(a);
     for (int c = 0; c < 2; ++c) {
         const CloudWS &q = w.c[c];
-        k_hash_insert<<<(int)cdiv(q.n, 256), 256, 0, s>>>(keys[c], q.n, w.mm, q.tkeys, q.tfirst, q.mask, q.slot);
-        k_flags<<<(int)cdiv(q.E, 256), 256, 0, s>>>(q.slot, q.tfirst, q.E, q.flag);
         int rc = exclusive_scan_i32(q.flag, q.E, q.scan, q.scan_tmp, s);
         if (rc != HPL_OK) return rc;
-        k_assign_ids<<<(int)cdiv(q.E, 256), 256, 0, s>>>(keys[c], q.n, q.slot, q.flag, q.scan, q.tid, vk[c],
-                                                        q.E, counts + c);
-        k_offsets<<<(int)cdiv(q.E, 256), 256, 0, s>>>(q.slot, q.tid, q.n, offs[c]);
     }
+    k_assign_ids<<<dim3((unsigned)cdiv(emax, 256), 1, 2), 256, 0, s>>>(a);
+    k_offsets<<<dim3((unsigned)cdiv(emax, 256), 1, 2), 256, 0, s>>>(a);
     HPL_CHECK_LAUNCH("hpl_lattice_hash");
     return HPL_OK;
 }
@@ -451,19 +576,24 @@ extern "C" int hpl_lattice_neighbors(const void *workspace, int64_t n1, int64_t 
         HPL_REQUIRE(blur_stride == 0 || blur_stride >= imax(H1, H2), "hpl_lattice_neighbors: blur_stride too small");
         HPL_REQUIRE(blur2_shift >= 0 && blur2_shift + H2 < (int64_t)INT32_MAX, "hpl_lattice_neighbors: bad blur2_shift");
         const Offsets o = make_offsets(bcn_radius);
-        k_neighbors<<<dim3((unsigned)cdiv(H1, 256), o.n), 256, 0, s>>>(vkeys1, 4 * n1, H1, o, w.mm, w.c[0].tkeys,
-                                                                       w.c[0].tid, w.c[0].mask, blur1,
-                                                                       blur_stride ? blur_stride : H1, 0);
-        k_neighbors<<<dim3((unsigned)cdiv(H2, 256), o.n), 256, 0, s>>>(vkeys2, 4 * n2, H2, o, w.mm, w.c[1].tkeys,
-                                                                       w.c[1].tid, w.c[1].mask, blur2,
-                                                                       blur_stride ? blur_stride : H2,
-                                                                       (int32_t)blur2_shift);
+        NbrArgs a;
+        const int32_t *vk[2] = {vkeys1, vkeys2};
+        int32_t *outs[2] = {blur1, blur2};
+        const int64_t Hs[2] = {H1, H2}, ns[2] = {n1, n2};
+        for (int c = 0; c < 2; ++c) {
+            a.vkeys[c] = vk[c]; a.vstride[c] = 4 * ns[c]; a.H[c] = Hs[c]; a.tkeys[c] = w.c[c].tkeys;
+            a.tid[c] = w.c[c].tid; a.mask[c] = w.c[c].mask; a.out[c] = outs[c];
+            a.ostride[c] = blur_stride ? blur_stride : Hs[c];
+            a.shift[c] = c ? (int32_t)blur2_shift : 0;
+        }
+        k_neighbors2<<<dim3((unsigned)cdiv(imax(H1, H2), 256), o.n, 2), 256, 0, s>>>(a, o, w.mm);
     }
     if (corr_filter_radius != -1) {
-        HPL_REQUIRE(corr1 && corr2, "hpl_lattice_neighbors: null corr table");
+        HPL_REQUIRE(corr2, "hpl_lattice_neighbors: null corr table");
         const Offsets co = make_offsets(corr_corr_radius), fo = make_offsets(corr_filter_radius);
-        k_neighbors<<<dim3((unsigned)cdiv(H1, 256), co.n), 256, 0, s>>>(vkeys1, 4 * n1, H1, co, w.mm, w.c[0].tkeys,
-                                                                        w.c[0].tid, w.c[0].mask, corr1, H1, 0);
+        if (corr1)      // NULL: the caller reuses blur1 (same radius, same table)
+            k_neighbors<<<dim3((unsigned)cdiv(H1, 256), co.n), 256, 0, s>>>(vkeys1, 4 * n1, H1, co, w.mm, w.c[0].tkeys,
+                                                                            w.c[0].tid, w.c[0].mask, corr1, H1, 0);
         k_neighbors_corr2<<<dim3((unsigned)cdiv(H1, 256), co.n * fo.n), 256, 0, s>>>(
             vkeys1, 4 * n1, H1, co, fo, w.mm, w.c[1].tkeys, w.c[1].tid, w.c[1].mask, corr2);
     }

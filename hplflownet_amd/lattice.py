@@ -41,20 +41,26 @@ class GenerateDataUnsymmetric(object):
         """pc1, pc2: (3, N) float32 device tensors -> DeviceLattice."""
         L = _lib.load()
         dev = pc1.device
-        last = [pc1.contiguous().float(), pc2.contiguous().float()]
+        pts = [pc1.contiguous().float(), pc2.contiguous().float()]     # level 0: the clouds themselves
+        n = [int(pts[0].shape[1]), int(pts[1].shape[1])]
+        prev = None           # deeper levels: (vertex keys of the level above, their column stride, divisor)
         levels = []
         nlev = len(self.scales_filter_map)
         for idx, (scale, bcn_r, cf_r, cc_r) in enumerate(self.scales_filter_map):
-            n = [int(last[0].shape[1]), int(last[1].shape[1])]
-            keys, bary = [], []
             emg_p = torch.empty((n[0] + n[1], 4), dtype=torch.float32, device=dev)     # both clouds, point-major
             emg = [emg_p[:n[0]], emg_p[n[0]:]]
-            for c in (0, 1):
-                k = torch.empty((4, n[c], 4), dtype=torch.int32, device=dev)
-                b = torch.empty((4, n[c]), dtype=torch.float32, device=dev)
-                check(L.hpl_lattice_keys(ptr(last[c]), n[c], float(scale), ptr(k), ptr(b), ptr(emg[c]), 4, stream()),
-                      'hpl_lattice_keys')
-                keys.append(k); bary.append(b)
+            keys = [torch.empty((4, n[c], 4), dtype=torch.int32, device=dev) for c in (0, 1)]
+            bary = [torch.empty((4, n[c]), dtype=torch.float32, device=dev) for c in (0, 1)]
+            if prev is None:
+                check(L.hpl_lattice_keys_pair(ptr(pts[0]), ptr(pts[1]), None, None, 0, 0, 1.0, n[0], n[1], float(scale),
+                                              ptr(keys[0]), ptr(keys[1]), ptr(bary[0]), ptr(bary[1]), ptr(emg[0]),
+                                              ptr(emg[1]), 4, stream()), 'hpl_lattice_keys_pair')
+            else:       # the points are the vertices of the level above (transforms.py:461-467), never materialised
+                pvk, pstride, div = prev
+                check(L.hpl_lattice_keys_pair(None, None, ptr(pvk[0]), ptr(pvk[1]), pstride[0], pstride[1], div, n[0],
+                                              n[1], float(scale), ptr(keys[0]), ptr(keys[1]), ptr(bary[0]),
+                                              ptr(bary[1]), ptr(emg[0]), ptr(emg[1]), 4, stream()),
+                      'hpl_lattice_keys_pair')
             wsb = int(L.hpl_lattice_workspace_bytes(n[0], n[1]))
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             off = [torch.empty((4, n[c]), dtype=torch.int32, device=dev) for c in (0, 1)]
@@ -72,7 +78,8 @@ class GenerateDataUnsymmetric(object):
                 blur_p = torch.empty((F, H[0] + H[1]), dtype=torch.int32, device=dev)
                 blur_ptr = [ptr(blur_p), blur_p.data_ptr() + 4 * H[0]]
             if cf_r != -1:
-                corr1 = torch.empty((_filter_size(cc_r), H[0]), dtype=torch.int32, device=dev)
+                if cc_r != bcn_r:           # equal radii: corr1 is the blur table of cloud 1
+                    corr1 = torch.empty((_filter_size(cc_r), H[0]), dtype=torch.int32, device=dev)
                 corr2 = torch.empty((_filter_size(cc_r), _filter_size(cf_r) * H[0]), dtype=torch.int32, device=dev)
             check(L.hpl_lattice_neighbors(ptr(ws), n[0], n[1], ptr(vk[0]), ptr(vk[1]), H[0], H[1], int(bcn_r),
                                           int(cf_r), int(cc_r), blur_ptr[0], blur_ptr[1], H[0] + H[1], H[0],
@@ -87,7 +94,7 @@ class GenerateDataUnsymmetric(object):
             lv.emg_pair = emg_p
             lv.pair = ops.PairTables(lv.clouds[0], lv.clouds[1])
             lv.corr1 = NbrTable(corr1) if corr1 is not None else None
-            if lv.corr1 is not None and cc_r == bcn_r:
+            if cf_r != -1 and cc_r == bcn_r:
                 lv.corr1 = lv.blur[0]          # same offsets, same table: share it
             lv.corr2 = NbrTable(corr2) if corr2 is not None else None
             if lv.corr2 is not None:
@@ -95,13 +102,8 @@ class GenerateDataUnsymmetric(object):
             levels.append(lv)
             if idx != nlev - 1:
                 div = float(np.float32(self.expected_std * scale))         # transforms.py:462-463
-                nxt = []
-                for c in (0, 1):
-                    o = torch.empty((3, H[c]), dtype=torch.float32, device=dev)
-                    check(L.hpl_lattice_next_points(ptr(vk[c]), 4 * n[c], H[c], div, ptr(o), stream()),
-                          'hpl_lattice_next_points')
-                    nxt.append(o)
-                last = nxt
+                prev = (vk, [4 * n[0], 4 * n[1]], div)
+                n = [H[0], H[1]]
         return DeviceLattice(levels)
 
     def __call__(self, data):

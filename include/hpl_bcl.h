@@ -235,6 +235,15 @@ int hpl_transpose(const float *src, int64_t lds, float *dst, int64_t ldd, int64_
 int hpl_lattice_keys(const float *pc, int64_t N, float scale, int32_t *keys, float *bary,
                      float *emg, int64_t emg_ld, hplStream stream);
 
+/* The same for both clouds of a level in one launch.  Points: (3, n) arrays pc1 / pc2, or -- when
+ * pc1 == pc2 == NULL -- the vertices of the previous level given by their integer keys vk1 / vk2
+ * ([4][vstride], first n columns) and `divisor`, computed on the fly exactly as
+ * hpl_lattice_next_points does (the (3, H) arrays of transforms.py:461-467 are never written). */
+int hpl_lattice_keys_pair(const float *pc1, const float *pc2, const int32_t *vk1, const int32_t *vk2,
+                          int64_t vstride1, int64_t vstride2, float divisor, int64_t n1, int64_t n2,
+                          float scale, int32_t *keys1, int32_t *keys2, float *bary1, float *bary2,
+                          float *emg1, float *emg2, int64_t emg_ld, hplStream stream);
+
 /* Integer part, stage 1 (transforms/transforms.py:171-207 and :384-391): per-coordinate
  * key range over both clouds, mixed-radix packing (key2int, :70-86), one open-addressing
  * 64-bit table per cloud -- each workgroup first deduplicates its 1024 keys in an LDS
@@ -251,7 +260,8 @@ int hpl_lattice_hash(const int32_t *keys1, int64_t n1, const int32_t *keys2, int
 
 /* Integer part, stage 2 (transforms/transforms.py:209-255): neighbour tables by hash lookup.
  * Radius -1 skips a table (pointer may be NULL).  H1, H2 are the counts read back from
- * stage 1.  blur1 [F][H1], blur2 [F][H2], corr1 [K][H1]; corr2 is written directly in the
+ * stage 1.  blur1 [F][H1], blur2 [F][H2], corr1 [K][H1] (may be NULL with corr2 given: the caller
+ * reuses blur1 when the radii are equal); corr2 is written directly in the
  * kernel-ready permuted layout [K][F*H1] (see hpl_corr2_permute).  Misses are -1; like the
  * reference, neighbour keys are packed without a range check.
  * blur_stride == 0: both blur tables are dense ([F][H1], [F][H2]).  Otherwise both have row
