@@ -318,3 +318,49 @@ def test_device_lattice_fuzz_vs_oracle():
                 assert np.array_equal(np.asarray(vx), np.asarray(y[k])), (n1, n2, seed, kind, l, k)
 
     check()
+
+
+def test_single_cloud_lattice_entries_match_pair_entry():
+    """hpl_lattice_keys / hpl_lattice_next_points (one cloud, (3, N) points materialised) give the same
+    keys / barycentric / el_minus_gr as hpl_lattice_keys_pair, which the builder uses (both clouds per
+    launch, next level's points computed from the vertex keys inside the kernel)."""
+    from hplflownet_amd import _lib
+    from hplflownet_amd._lib import check, ptr, stream
+    L = _lib.load()
+    rng = np.random.RandomState(4)
+    n = (700, 513)
+    pts = [torch.from_numpy(rng.uniform(-6, 6, (3, m)).astype(np.float32)).to(DEV) for m in n]
+    scale = 1.5
+
+    def alloc(m):
+        return (torch.empty((4, m, 4), dtype=torch.int32, device=DEV), torch.empty((4, m), device=DEV),
+                torch.empty((m, 4), device=DEV))
+    single = [alloc(m) for m in n]
+    for c in (0, 1):
+        check(L.hpl_lattice_keys(ptr(pts[c]), n[c], scale, ptr(single[c][0]), ptr(single[c][1]), ptr(single[c][2]), 4,
+                                 stream()), 'keys')
+    pair = [alloc(m) for m in n]
+    check(L.hpl_lattice_keys_pair(ptr(pts[0]), ptr(pts[1]), None, None, 0, 0, 1.0, n[0], n[1], scale, ptr(pair[0][0]),
+                                  ptr(pair[1][0]), ptr(pair[0][1]), ptr(pair[1][1]), ptr(pair[0][2]), ptr(pair[1][2]), 4,
+                                  stream()), 'keys_pair')
+    for c in (0, 1):
+        for a, b in zip(single[c], pair[c]):
+            assert torch.equal(a, b)
+    # vertex-key mode == next_points followed by the point mode
+    vk = [torch.from_numpy(rng.randint(-40, 40, (4, 4 * m)).astype(np.int32)).to(DEV) for m in n]
+    Hn = (300, 250)
+    div = 3.25
+    nxt = [torch.empty((3, h), device=DEV) for h in Hn]
+    for c in (0, 1):
+        check(L.hpl_lattice_next_points(ptr(vk[c]), 4 * n[c], Hn[c], div, ptr(nxt[c]), stream()), 'next_points')
+    ref = [alloc(h) for h in Hn]
+    check(L.hpl_lattice_keys_pair(ptr(nxt[0]), ptr(nxt[1]), None, None, 0, 0, 1.0, Hn[0], Hn[1], scale, ptr(ref[0][0]),
+                                  ptr(ref[1][0]), ptr(ref[0][1]), ptr(ref[1][1]), ptr(ref[0][2]), ptr(ref[1][2]), 4,
+                                  stream()), 'keys_pair')
+    got = [alloc(h) for h in Hn]
+    check(L.hpl_lattice_keys_pair(None, None, ptr(vk[0]), ptr(vk[1]), 4 * n[0], 4 * n[1], div, Hn[0], Hn[1], scale,
+                                  ptr(got[0][0]), ptr(got[1][0]), ptr(got[0][1]), ptr(got[1][1]), ptr(got[0][2]),
+                                  ptr(got[1][2]), 4, stream()), 'keys_pair')
+    for c in (0, 1):
+        for a, b in zip(ref[c], got[c]):
+            assert torch.equal(a, b)
