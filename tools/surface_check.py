@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""GPU: robustness check on a surface-like pair (points on a few smooth patches instead of the
+uniform frustum of the benchmark): lattice sizes, device lattice == oracle, forward time, EPE vs oracle."""
+import os, sys, time, types
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import hplflownet_amd as H
+from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_
+
+def surfaces(n, seed):
+    rng = np.random.RandomState(seed)
+    pts = []
+    per = n // 8
+    for k in range(8):
+        c = rng.uniform([-8, -3, 5], [8, 3, 30])
+        u, v = rng.uniform(-3, 3, per), rng.uniform(-2, 2, per)
+        a, b = rng.uniform(-0.5, 0.5, 2)
+        z = c[2] + a * u + b * v + 0.3 * np.sin(u) + rng.normal(0, 0.01, per)
+        pts.append(np.stack([c[0] + u, c[1] + v, z], 1))
+    pc1 = np.concatenate(pts)[:n].astype(np.float32)
+    pc2 = (pc1 + np.array([0.3, 0.0, 0.2], np.float32) + rng.normal(0, 0.02, pc1.shape)).astype(np.float32)
+    return pc1, pc2, pc2 - pc1
+
+dev = 'cuda'
+a = types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP, evaluate=True, use_leaky=True, bcn_use_bias=True,
+                          bcn_use_norm=True, last_relu=False, DEVICE='cuda')
+model = H.HPLFlowNet(a); fill_module_(model, 1.0, 'hash'); sd = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+model = model.to(dev).eval()
+gen = H.GenerateDataUnsymmetric(a, device=dev)
+pc1, pc2, sf = surfaces(8192, 0)
+t1, t2, _, lat = gen([pc1, pc2, sf]); lat.prepare()
+print('vertices per level (pc1, pc2):', [lv.H for lv in lat.levels])
+from oracle import lattice_oracle as LO, bcl_oracle as BO
+gd = LO.generate_data(pc1, pc2, SCALES_FILTER_MAP)
+ok = all(np.array_equal(np.asarray(x[k].cpu().numpy() if torch.is_tensor(x[k]) else x[k]), np.asarray(y[k]))
+         for x, y in zip(H.to_reference_format(lat), gd) for k in y)
+print('device lattice == oracle:', ok)
+with torch.no_grad():
+    for _ in range(3): y = model(t1[None], t2[None], lat)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): y = model(t1[None], t2[None], lat)
+    torch.cuda.synchronize(); fwd = (time.perf_counter() - t0) / 10
+    t0 = time.perf_counter()
+    for _ in range(10): gen.build(t1, t2).prepare()
+    torch.cuda.synchronize(); lt = (time.perf_counter() - t0) / 10
+print('forward %.2f ms, lattice build %.2f ms (single stream, no overlap)' % (fwd * 1e3, lt * 1e3))
+ref = BO.hplflownet_forward(sd, pc1.T, pc2.T, gd)
+got = y.cpu().numpy()[0]
+print('EPE3D gpu %.6f oracle %.6f  max|diff| %.2e' % (BO.epe3d(got, sf.T), BO.epe3d(ref, sf.T), np.abs(got - ref).max()))
