@@ -73,12 +73,11 @@ class DeviceLattice(object):
         current stream, so that a lattice built on a side stream is complete before it is handed to
         the forward.  for_training: the tables of the per-cloud path + the symmetry read-back."""
         for L, lv in enumerate(self.levels):
+            if lv.pair is not None:
+                lv.pair.csr()       # one build; the per-cloud CSRs are views / offset copies of it
             if lv.pair is not None and not for_training:
                 # inference path: the Down layers run once per pair; cloud 1 alone is splatted only by the
                 # correlation layers that take a previous correlation (levels >= 3)
-                lv.pair.csr()
-                if lv.corr1 is not None and L >= 3:
-                    lv.clouds[0].csr()
                 tables = [lv.blur.pair, lv.blur[0], lv.corr1] if isinstance(lv.blur, PairBlur) else [lv.corr1]
             else:
                 for c in lv.clouds:

@@ -67,6 +67,10 @@ class CloudTables(object):
         self._sym = {}
 
     def csr(self):
+        if self._csr is None and getattr(self, '_csr_src', None) is not None:
+            pair, n0, h0 = self._csr_src
+            p_ptr, p_pt, p_w, p_norm = pair.csr()
+            self._csr = (p_ptr[h0:] - 4 * n0, p_pt[4 * n0:] - n0, p_w[4 * n0:], p_norm[h0:])
         if self._csr is None:
             dev = self.bary.device
             csr_ptr = torch.empty(self.H + 1, dtype=torch.int32, device=dev)
@@ -105,6 +109,12 @@ class PairTables(object):
                                                  c1.N, c1.H, ptr(csr_ptr), ptr(csr_pt), ptr(csr_w), ptr(norm),
                                                  ptr(scratch), stream()), 'hpl_csr_build_pair')
             self._csr = (csr_ptr, csr_pt, csr_w, norm)
+            # the pair CSR is the two per-cloud CSRs laid end to end: cloud 1's is a set of views
+            # (no launch), cloud 2's needs its offsets removed (built on first use)
+            if c0._csr is None:
+                c0._csr = (csr_ptr[:c0.H + 1], csr_pt[:4 * c0.N], csr_w[:4 * c0.N], norm[:c0.H])
+            if c1._csr is None:
+                c1._csr_src = (self, c0.N, c0.H)
         return self._csr
 
 

@@ -261,7 +261,10 @@ def test_pair_batched_down_path_equals_per_cloud(cls, nsc, n1, n2):
     t1, t2, _, lat = gen([pc1, pc2, pc1])
     # pair CSR == per-cloud CSRs laid end to end
     for lv in lat.levels:
-        p, q0, q1 = lv.pair.csr(), lv.clouds[0].csr(), lv.clouds[1].csr()
+        fresh = [ops.CloudTables(c.bary, c.off, c.H) for c in lv.clouds]          # independent per-cloud builds
+        p, q0, q1 = lv.pair.csr(), fresh[0].csr(), fresh[1].csr()
+        for c, q in zip(lv.clouds, (q0, q1)):                                      # derived from the pair CSR
+            assert all(torch.equal(x, y) for x, y in zip(c.csr(), q))
         assert torch.equal(p[0][:lv.H[0] + 1], q0[0]) and torch.equal(p[0][lv.H[0]:] - p[0][lv.H[0]], q1[0])
         assert torch.equal(p[1], torch.cat([q0[1], q1[1] + lv.clouds[0].N]))
         assert torch.equal(p[2], torch.cat([q0[2], q1[2]])) and torch.equal(p[3], torch.cat([q0[3], q1[3]]))
