@@ -19,6 +19,7 @@ shapes = [  # name, level, C_in, C_out, F
     ('bcn3_ blur', 2, 388, 256, 15), ('bcn1 blur', 0, 68, 64, 15), ('bcn2 blur', 1, 68, 64, 15),
     ('conv2', -1, 1024, 1024, 1), ('conv3', -1, 1024, 512, 1),
     ('bcn4_ blur', 3, 260, 256, 15), ('corr1 B-term', -2, 64, 32, 15),
+    ('dense longK', -1, 8704, 1024, 1),          # uniform tiles, no skipping: the loop's own efficiency
     ('pair bcn1 blur', -10, 68, 64, 15), ('pair bcn2 blur', -11, 68, 64, 15), ('pair bcn3 blur', -12, 68, 64, 15),
 ]
 only = os.environ.get('SHAPES')          # comma-separated substrings
@@ -36,6 +37,8 @@ for name, lvl, C, O, F in shapes:
     elif lvl == -2:                      # corr B-term of level 2: 15*H1 virtual vertices, permuted corr2 table
         tbl = lat.levels[2].corr2.t
         M = tbl.shape[1]
+    elif lvl == -1 and C > 4096:
+        tbl, M = None, 25841
     else:
         tbl, M = None, 8192
     A = torch.randn(M if lvl != -2 else lat.levels[2].H[1], C, device=dev)
