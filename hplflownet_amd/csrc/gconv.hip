@@ -171,10 +171,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     const int bn4 = t % B_F4_PER_ROW;
     const int brow0 = t / B_F4_PER_ROW;
 
-    // two register sets: the global loads of slice t+2 are issued while slice t is multiplied and slice
-    // t+1 (loaded one step earlier) is stored to LDS -- every load has more than a whole step to land
+    // gathered rows (A): two register sets -- the global loads of slice t+2 are issued while slice t is
+    // multiplied and slice t+1 (loaded one step earlier) is stored to LDS
     float4 ra[2][A_PASSES];
-    float4 rb[2][B_PASSES];
 
     // Stage the tile's source-row indices once: every later step reads them from LDS, so the
     // gather of step t+1 is a burst of independent loads (no global index -> address chain).
@@ -261,17 +260,26 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
             ra[set][i] = make_float4(e[0], e[1], e[2], e[3]);
         }
     };
-    auto load_b = [&](int set, int i) {
-        const unsigned off = bvalid ? boff0 + (unsigned)(k0_n + i * B_ROWS_PER_PASS) * ldw_b : OOB;
-        const float4_t v = buffer_load_f32x4(rsrc_b, (int)off, 0, 0);
-        rb[set][i] = make_float4(v.x, v.y, v.z, v.w);
+    // Weight rows go straight into LDS (buffer_load_dwordx4 ... lds): the 64 x 16 bytes of a wave are
+    // whole rows of the k-major B tile, contiguous in LDS in lane order -- no staging registers, no
+    // ds_write for B (measured: 3 % on the big launches).  The same for the gathered rows needs a
+    // row-major, XOR-swizzled A tile whose fragment reads are 2-way bank conflicts: measured 4 %
+    // *slower*, so A keeps the register path and the transposing store.
+    const __amdgpu_buffer_rsrc_t lrsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.Wt), (short)0,
+                                                                           (int)p.w_bytes, 0x00020000);
+    (void)rsrc_b;
+    const int wave_brow0 = (wave * 64) / B_F4_PER_ROW;         // first tile row of this wave's 64 lanes
+    auto load_b_lds = [&](int buf, int k0, int i) {
+        const unsigned off = bvalid ? boff0 + (unsigned)(k0 + i * B_ROWS_PER_PASS) * ldw_b : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            lrsrc_b,
+            (__attribute__((address_space(3))) void *)(Bs + buf * BK * LDB_S + (wave_brow0 + i * B_ROWS_PER_PASS) * LDB_S),
+            16, (int)off, 0, 0, 0);
     };
     auto load_regs = [&](int set, int k0) {
         load_begin(k0);
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) load_a(set, i);
-#pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) load_b(set, i);
     };
 
     auto store_a = [&](int set, int buf, int i) {
@@ -282,16 +290,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
         a[(kq * 4 + 2) * LDA_S + r] = ra[set][i].z;
         a[(kq * 4 + 3) * LDA_S + r] = ra[set][i].w;
     };
-    auto store_b = [&](int set, int buf, int i) {
-        float *b = Bs + buf * BK * LDB_S;
-        const int kr = brow0 + i * B_ROWS_PER_PASS;
-        *reinterpret_cast<float4 *>(b + kr * LDB_S + bn4 * 4) = rb[set][i];
-    };
     auto store_lds = [&](int set, int buf) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) store_a(set, buf, i);
-#pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) store_b(set, buf, i);
     };
 
     floatx16 acc[TM][TN];
@@ -337,36 +338,39 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     const int lo = (int)((int64_t)nlist * split / p.splits), hi_i = (int)((int64_t)nlist * (split + 1) / p.splits);
     const int nsl = hi_i - lo;        // slices of this workgroup: list entries lo .. hi_i-1
     if (nsl > 0) {
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) load_b_lds(0, (int)(Ks[lo] & 1023) * BK, i);
         load_regs(0, (int)(Ks[lo] & 1023) * BK);
         store_lds(0, 0);
         if (nsl > 1) load_regs(1, (int)(Ks[lo + 1] & 1023) * BK);      // slice 1 stays in flight in set 1
     }
+    __builtin_amdgcn_s_waitcnt(0);          // everything landed, including the LDS-direct weight rows
     __syncthreads();
     int cur = 0;
     // One contraction step t (compile-time flags).  P = t & 1.  LOAD: issue the loads of slice t+2
     // (kt_load) into register set P; STORE: stage slice t+1 (register set 1-P, loaded during step t-1)
     // into the other LDS buffer.
-    auto step = [&](int e_cur, int kt_load, auto load_tag, auto store_tag, auto parity_tag) {
+    auto step = [&](int e_cur, int kt_load, int kt_b, auto load_tag, auto store_tag, auto parity_tag) {
         constexpr bool do_load = decltype(load_tag)::value;
         constexpr bool do_store = decltype(store_tag)::value;
         constexpr int P = decltype(parity_tag)::value;
         // the prefetch / staging pieces of this step, one call per k-pair
         auto pieces = [&](int kk) {
+            // weights of slice t+1 (kt_b) straight into the free LDS buffer, first in the queue so that
+            // the end-of-step wait can leave the register loads of slice t+2 in flight
+            if constexpr (do_store) {
+                if (kk >= 1 && kk - 1 < B_PASSES) load_b_lds(cur ^ 1, kt_b * BK, kk - 1);
+            }
             if constexpr (do_load) {
                 if (kk == 0) load_begin(kt_load * BK);
-                if (kk >= 1 && kk - 1 < A_PASSES) load_a(P, kk - 1);
-                if (kk >= 5 && kk - 5 < B_PASSES) load_b(P, kk - 5);
+                if (kk >= 6 && kk - 6 < A_PASSES) load_a(P, kk - 6);
             }
             if constexpr (do_store) {
                 if (kk >= 10 && kk - 10 < A_PASSES) store_a(1 - P, cur ^ 1, kk - 10);
-                if (kk == 14) {
-#pragma unroll
-                    for (int i = 0; i < B_PASSES; i += 2) store_b(1 - P, cur ^ 1, i);
-                }
-                if (kk == 15) {
-#pragma unroll
-                    for (int i = 1; i < B_PASSES; i += 2) store_b(1 - P, cur ^ 1, i);
-                }
+            }
+            if (kk == BK / 2 - 1) {
+                constexpr int inflight = do_load ? A_PASSES : 0;      // vmcnt <= inflight: the LDS-direct rows landed
+                __builtin_amdgcn_s_waitcnt((inflight & 0xF) | ((inflight >> 4) << 14) | (0x7 << 4) | (0xF << 8));
             }
         };
         bool need[TM], need_any = false;
@@ -427,17 +431,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
         using P1 = std::integral_constant<int, 1>;
         int t = 0;
         while (t + 2 < nsl) {                       // steps that both load (slice t+2) and store (slice t+1)
-            step((int)Ks[lo + t], (int)(Ks[lo + t + 2] & 1023), T{}, T{}, P0{});
+            step((int)Ks[lo + t], (int)(Ks[lo + t + 2] & 1023), (int)(Ks[lo + t + 1] & 1023), T{}, T{}, P0{});
             ++t;
             if (t + 2 >= nsl) break;
-            step((int)Ks[lo + t], (int)(Ks[lo + t + 2] & 1023), T{}, T{}, P1{});
+            step((int)Ks[lo + t], (int)(Ks[lo + t + 2] & 1023), (int)(Ks[lo + t + 1] & 1023), T{}, T{}, P1{});
             ++t;
         }
         if (t + 1 < nsl) {                          // last but one: only stage the last slice
-            if (t & 1) step((int)Ks[lo + t], -1, F{}, T{}, P1{}); else step((int)Ks[lo + t], -1, F{}, T{}, P0{});
+            if (t & 1) step((int)Ks[lo + t], -1, (int)(Ks[lo + t + 1] & 1023), F{}, T{}, P1{});
+            else step((int)Ks[lo + t], -1, (int)(Ks[lo + t + 1] & 1023), F{}, T{}, P0{});
             ++t;
         }
-        if (t < nsl) step((int)Ks[lo + t], -1, F{}, F{}, P0{});
+        if (t < nsl) step((int)Ks[lo + t], -1, -1, F{}, F{}, P0{});
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
