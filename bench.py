@@ -235,6 +235,7 @@ def main():
         # BASELINE config 4: one pair per GPU, identical weights, mean loss over ranks ==
         # all-reduce(mean) of the gradients (77.2 MB fp32 over xGMI), Adam lr 1e-4 (main.py:138-140)
         model.train()
+        ops.enable_weight_bank(not os.environ.get('HPL_NO_BANK'))     # one batched weight re-layout per step
         parallel.broadcast_parameters(model)
         reducer = parallel.GradAllReducer(model.parameters())
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)

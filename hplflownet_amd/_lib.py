@@ -19,6 +19,13 @@ class HplError(RuntimeError):
     pass
 
 
+class RelayoutJob(ctypes.Structure):
+    """Mirror of `hpl_relayout_job` (include/hpl_bcl.h)."""
+    _fields_ = [('W', ctypes.c_void_p), ('base', ctypes.c_int64), ('sr', ctypes.c_int64), ('sq', ctypes.c_int64),
+                ('sf', ctypes.c_int64), ('R', ctypes.c_int32), ('Q', ctypes.c_int32), ('F', ctypes.c_int32),
+                ('mirror', ctypes.c_int32), ('ldw', ctypes.c_int64)]
+
+
 class GConvDesc(ctypes.Structure):
     """Mirror of `struct hpl_gconv_desc` (include/hpl_bcl.h)."""
     _fields_ = [('A', c_vp), ('lda', c_i64), ('rows_a', c_i64),
@@ -46,6 +53,7 @@ _SIGNATURES = {
     'hpl_slice': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'hpl_weight_relayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i64, c_i64,
                                            c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    'hpl_weight_relayout_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp, c_vp]),
     'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,
                                            c_i64, c_i64, c_i64, ctypes.c_int, c_vp]),
     'hpl_tap_order': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),

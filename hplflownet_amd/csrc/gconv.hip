@@ -676,6 +676,35 @@ __global__ void k_weight_relayout(const float *__restrict__ W, int64_t base, int
     }
 }
 
+// One launch for many re-layouts (all conv weights of a model, both directions): job j owns
+// destination elements [prefix[j], prefix[j+1]) of one buffer; mirror = taps stored in the order
+// (F - f) % F (the mirrored-gather data gradient).
+__global__ void k_weight_relayout_batch(const hpl_relayout_job *__restrict__ jobs, int njobs,
+                                        const int64_t *__restrict__ prefix, float *__restrict__ dst) {
+    const int64_t total = prefix[njobs];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        int lo = 0, hi = njobs - 1;               // last job with prefix[job] <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (prefix[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const hpl_relayout_job jb = jobs[lo];
+        const int64_t e = i - prefix[lo];
+        const int64_t k = e / jb.ldw;
+        const int q = (int)(e - k * jb.ldw);
+        float v = 0.f;
+        if (q < jb.Q && k < (int64_t)jb.F * jb.R) {
+            const int fdst = (int)(k / jb.R);
+            const int r = (int)(k - (int64_t)fdst * jb.R);
+            const int f = jb.mirror ? (jb.F - fdst) % jb.F : fdst;
+            v = jb.W[jb.base + r * jb.sr + q * jb.sq + f * jb.sf];
+        }
+        dst[i] = v;
+    }
+}
+
 __global__ void k_weight_unlayout(const float *__restrict__ Wt, int64_t ldw, int R, int Q, int F,
                                   float *__restrict__ W, int64_t base, int64_t sr, int64_t sq, int64_t sf,
                                   int accumulate) {
@@ -702,6 +731,15 @@ extern "C" int hpl_weight_relayout(const float *W, int64_t base, int R, int Q, i
     const int grid = (int)imin(cdiv(k_rows * ldw, 256), 8192);
     k_weight_relayout<<<grid, 256, 0, to_stream(stream)>>>(W, base, R, Q, F, sr, sq, sf, fmap, Wt, k_rows, ldw);
     HPL_CHECK_LAUNCH("hpl_weight_relayout");
+    return HPL_OK;
+}
+
+extern "C" int hpl_weight_relayout_batch(const hpl_relayout_job *jobs, int njobs, const int64_t *prefix,
+                                         int64_t total, float *dst, hplStream stream) {
+    HPL_REQUIRE(jobs && prefix && dst && njobs > 0 && total > 0, "hpl_weight_relayout_batch: bad arguments");
+    const int grid = (int)imin(cdiv(total, 256), 16384);
+    k_weight_relayout_batch<<<grid, 256, 0, to_stream(stream)>>>(jobs, njobs, prefix, dst);
+    HPL_CHECK_LAUNCH("hpl_weight_relayout_batch");
     return HPL_OK;
 }
 

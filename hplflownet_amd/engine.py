@@ -32,7 +32,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-from . import parallel
+from . import ops, parallel
 from .flownet import HPLFlowNet, HPLFlowNetShallow, load_reference_checkpoint
 from .lattice import GenerateDataUnsymmetric
 from .synthetic import SCALES_FILTER_MAP, fill_module_, synthetic_pair
@@ -88,6 +88,8 @@ class Trainer(object):
         fill_module_(self.model, 1.0, 'hash')           # deterministic He-uniform start (no dataset, no RNG state)
         self.model.to(self.device)
         self.gen = GenerateDataUnsymmetric(self.args, device=self.device)
+        if self.device.type == 'cuda':
+            ops.enable_weight_bank()          # one batched weight re-layout per training step
         self.opt = torch.optim.Adam([p for p in self.model.parameters() if p.requires_grad], lr=lr, weight_decay=0)
         self.reducer = None
         if distributed:

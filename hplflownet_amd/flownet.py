@@ -262,6 +262,8 @@ class _FlowNetBase(nn.Module):
         nlev = self.NLEV
         if torch.is_grad_enabled():
             lat.resolve_symmetry()
+            if ops.BANK is not None:
+                ops.BANK.refresh()          # all weight images of this step in one launch
         pair = (not torch.is_grad_enabled()) and self.pair_batched and \
             all(lv.pair is not None and isinstance(lv.blur, PairBlur) for lv in lat.levels[:nlev])
         down = [[], []]

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import GConvDesc, check, ptr, stream
+from ._lib import GConvDesc, RelayoutJob, check, ptr, stream
 
 ACT_NONE, ACT_LEAKY = 0, 1
 LEAKY_RATE = 0.1   # reference: models/module_utils.py:6
@@ -346,6 +346,81 @@ def _mirror_map(F, device):
     return _MIRROR[key]
 
 
+class WeightBank(object):
+    """Training re-lays every conv weight after each optimiser step, once for the forward and once for
+    the data gradient: ~160 small launches per step.  The bank records those requests during the
+    first step and from then on refreshes ALL images with one launch (`hpl_weight_relayout_batch`)
+    at the start of a step; a lookup is served from the bank while the parameter's version still is
+    the one the refresh saw, otherwise the caller re-lays that weight on its own."""
+
+    def __init__(self):
+        self.jobs = collections.OrderedDict()     # key -> [weight, args, offset, elems, version]
+        self.buf = None
+        self.dev_jobs = self.dev_prefix = None
+        self.total = 0
+        self.dirty = False                        # jobs added since the device tables were built
+
+    @staticmethod
+    def _key(weight, R, Q, F, sr, sq, sf, base, mirror):
+        return (weight.data_ptr(), tuple(weight.shape), R, Q, F, sr, sq, sf, base, mirror)
+
+    def get(self, weight, R, Q, F, sr, sq, sf, base=0, mirror=False):
+        """The [roundup(F*R,32), roundup(Q,4)] image of `weight`, from the bank when fresh."""
+        key = self._key(weight, R, Q, F, sr, sq, sf, base, mirror)
+        job = self.jobs.get(key)
+        k_rows, ldw = round_up(F * R, 32), round_up(Q, 4)
+        if job is not None and not self.dirty and job[4] == weight._version and job[0] is weight:
+            return self.buf[job[2]:job[2] + job[3]].view(k_rows, ldw)
+        if job is None:
+            self.jobs[key] = [weight, (R, Q, F, sr, sq, sf, base, mirror), None, k_rows * ldw, -1]
+            self.dirty = True
+        fmap = _mirror_map(F, weight.device) if mirror else None
+        return weight_relayout(weight, R, Q, F, sr, sq, sf, base=base, fmap=fmap)
+
+    def refresh(self):
+        """One launch: every recorded image from the current parameter values."""
+        if not self.jobs:
+            return
+        dev = next(iter(self.jobs.values()))[0].device
+        if self.dirty or self.buf is None:
+            arr = (RelayoutJob * len(self.jobs))()
+            prefix = [0]
+            for i, job in enumerate(self.jobs.values()):
+                w, (R, Q, F, sr, sq, sf, base, mirror) = job[0], job[1]
+                arr[i].W, arr[i].base, arr[i].sr, arr[i].sq, arr[i].sf = w.data_ptr(), base, sr, sq, sf
+                arr[i].R, arr[i].Q, arr[i].F, arr[i].mirror, arr[i].ldw = R, Q, F, int(mirror), round_up(Q, 4)
+                job[2] = prefix[-1]
+                prefix.append(prefix[-1] + job[3])
+            self.total = prefix[-1]
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.dev_jobs = raw.to(dev)
+            self.dev_prefix = torch.tensor(prefix, dtype=torch.int64, device=dev)
+            self.buf = torch.empty(self.total, dtype=torch.float32, device=dev)
+            self.dirty = False
+        check(_lib.load().hpl_weight_relayout_batch(ptr(self.dev_jobs), len(self.jobs), ptr(self.dev_prefix),
+                                                    self.total, ptr(self.buf), stream()), 'hpl_weight_relayout_batch')
+        for job in self.jobs.values():
+            job[4] = job[0]._version
+
+
+#: bank used by the autograd path when a training loop calls BANK.refresh() at the start of its steps
+BANK = None
+
+
+def enable_weight_bank(on=True):
+    """Switch the batched weight re-layout of the training path on / off (off: one launch per use)."""
+    global BANK
+    BANK = WeightBank() if on else None
+    return BANK
+
+
+def _train_relayout(weight, R, Q, F, sr, sq, sf, base=0, mirror=False):
+    if BANK is not None:
+        return BANK.get(weight, R, Q, F, sr, sq, sf, base, mirror)
+    fmap = _mirror_map(F, weight.device) if mirror else None
+    return weight_relayout(weight, R, Q, F, sr, sq, sf, base=base, fmap=fmap)
+
+
 def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
                  slope=LEAKY_RATE, row_perm=None):
     """gconv_raw, run as one pass per tap group when `groups` = [(f0, f1, perm), ...] is given: pass i
@@ -375,7 +450,7 @@ class GConvFn(torch.autograd.Function):
                 taps=None, groups=None):
         O = weight.shape[0]
         Ctot = weight.numel() // (O * F)
-        Wt = weight_relayout(weight, C, O, F, F, Ctot * F, 1, base=c0 * F)
+        Wt = _train_relayout(weight, C, O, F, F, Ctot * F, 1, base=c0 * F)
         Y = gconv_passes(A, nbr, M, C, F, Wt, O, groups, bias=bias, act=act, res=res, res_mod=res_mod, slope=slope,
                          row_perm=row_perm)
         ctx.groups = groups          # the mirror backward gathers through the same table: same groups
@@ -398,13 +473,12 @@ class GConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             rows = A.shape[0]
             if bwd_mode == 'dense':
-                WtT = weight_relayout(weight, O, C, 1, Ctot * F, F, 1, base=c0 * F)
+                WtT = _train_relayout(weight, O, C, 1, Ctot * F, F, 1, base=c0 * F)
                 gA_c = gconv_raw(g, None, M, O, 1, WtT, C)
             elif bwd_mode == 'mirror':
                 if rows != M:
                     raise _lib.HplError('mirror backward needs a table over the same vertex set')
-                WtT = weight_relayout(weight, O, C, F, Ctot * F, F, 1, base=c0 * F,
-                                      fmap=_mirror_map(F, weight.device))
+                WtT = _train_relayout(weight, O, C, F, Ctot * F, F, 1, base=c0 * F, mirror=True)
                 gA_c = gconv_passes(g, nbr, M, O, F, WtT, C, ctx.groups, row_perm=ctx.row_perm)
             else:   # scatter: G[m, (f, c)] = g[m] . W[:, c, f], added into row nbr[f, m]
                 # columns ordered (f, c): source element (o, f*C + c) = W[o, c0 + c, f]

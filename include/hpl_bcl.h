@@ -115,6 +115,20 @@ int hpl_slice(const float *Y, int64_t ldy, int C, const float *bary, const int32
 int hpl_weight_relayout(const float *W, int64_t base, int R, int Q, int F, int64_t sr, int64_t sq,
                         int64_t sf, const int32_t *fmap, float *Wt, int64_t k_rows, int64_t ldw,
                         hplStream stream);
+/* Many re-layouts in one launch (training re-lays every conv weight after each optimiser step, in
+ * the forward and in the data-gradient direction).  jobs / prefix live in DEVICE memory; job j writes
+ * destination elements [prefix[j], prefix[j+1]) of dst as an image [k_rows][ldw] with the meaning of
+ * hpl_weight_relayout; mirror != 0 stores tap f at position (F - f) % F.  total = prefix[njobs]. */
+typedef struct hpl_relayout_job {
+    const float *W;         /* source parameter */
+    int64_t base, sr, sq, sf;
+    int32_t R, Q, F, mirror;
+    int64_t ldw;            /* row length of the destination image (multiple of 4) */
+} hpl_relayout_job;
+int hpl_weight_relayout_batch(const hpl_relayout_job *jobs /* DEVICE */, int njobs,
+                              const int64_t *prefix /* DEVICE, njobs + 1 */, int64_t total, float *dst,
+                              hplStream stream);
+
 /* inverse scatter for weight gradients: W[base + r*sr + q*sq + f*sf] (+)= Wt[(f*R + r)*ldw + q] */
 int hpl_weight_unlayout(const float *Wt, int64_t ldw, int R, int Q, int F, float *W, int64_t base,
                         int64_t sr, int64_t sq, int64_t sf, int accumulate, hplStream stream);

@@ -36,6 +36,17 @@ def test_gconv_desc_layout_matches_header():
                                              + 8 + 8 + 4 + 4 + 8 + 8 + 8)
 
 
+def test_relayout_job_layout_matches_header():
+    hdr = header_text()
+    struct = hdr[hdr.index('typedef struct hpl_relayout_job {'):hdr.index('} hpl_relayout_job;')]
+    struct = re.sub(r'/\*.*?\*/', '', struct, flags=re.S)
+    names = []
+    for decl in re.findall(r'(?:const\s+)?(?:float|int32_t|int64_t)\s*\*?\s*([\w\s,]+);', struct):
+        names += [n.strip() for n in decl.split(',')]
+    assert names == [f[0] for f in _lib.RelayoutJob._fields_]
+    assert ctypes.sizeof(_lib.RelayoutJob) == 8 + 4 * 8 + 4 * 4 + 8
+
+
 def test_no_cpu_fallback():
     import hplflownet_amd as H
     m = H.BilateralConvFlex(3, 1, 8, [8], 'cpu', True, True, True, False, False, False)

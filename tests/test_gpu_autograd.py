@@ -225,3 +225,32 @@ def test_tap_group_passes_equal_single_pass(G):
     assert many.data_ptr() == out.data_ptr()
     assert rel_err(many.cpu().numpy(), one.cpu().numpy()) < 2e-6
     assert float((many - one).abs().max()) < 1e-4
+
+
+def test_weight_bank_matches_individual_relayouts():
+    """Batched re-layout (one launch for all recorded images, forward and mirrored direction): identical
+    images; stale entries (parameter changed since the refresh) fall back to the individual launch."""
+    from hplflownet_amd import ops
+    rng = np.random.RandomState(5)
+    bank = ops.WeightBank()
+    ws = [torch.from_numpy(rng.randn(o, c, f, 1).astype(np.float32)).to(DEV).requires_grad_(True)
+          for o, c, f in ((64, 68, 15), (33, 7, 1), (128, 260, 15), (512, 1024, 1))]
+    reqs = []
+    for w in ws:
+        O, C, F = w.shape[0], w.shape[1], w.shape[2]
+        reqs.append((w, (C, O, F, F, C * F, 1), dict(base=0, mirror=False)))
+        reqs.append((w, (O, C, F, C * F, F, 1), dict(base=0, mirror=(F > 1))))
+    reqs.append((ws[0], (20, 64, 15, 15, 68 * 15, 1), dict(base=5 * 15, mirror=False)))       # channel sub-range
+    first = [bank.get(w, *a, **k).clone() for w, a, k in reqs]            # recorded, served individually
+    bank.refresh()
+    for (w, a, k), ref in zip(reqs, first):
+        got = bank.get(w, *a, **k)
+        assert got.data_ptr() >= bank.buf.data_ptr() and torch.equal(got, ref)
+    with torch.no_grad():
+        ws[2].mul_(2.0)                                                    # version bump -> entry is stale
+    w, a, k = reqs[4]
+    stale = bank.get(w, *a, **k)
+    assert not (bank.buf.data_ptr() <= stale.data_ptr() < bank.buf.data_ptr() + 4 * bank.total)
+    assert torch.equal(stale, 2.0 * first[4])
+    bank.refresh()
+    assert torch.equal(bank.get(w, *a, **k), 2.0 * first[4])
