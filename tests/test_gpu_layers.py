@@ -160,7 +160,7 @@ def test_whole_model_golden_F5(tag, cls, n, nsc):
     assert float((y2 - y.detach()).abs().max()) < 2e-5 * max(1.0, float(y.detach().abs().max()))
 
 
-@pytest.mark.parametrize('n,seed', [(256, 0), (1024, 0), (1024, 3), (8192, 0)])
+@pytest.mark.parametrize('n,seed', [(256, 0), (1024, 0), (1024, 3), (8192, 0), (32768, 1)])
 def test_device_lattice_bit_exact(n, seed):
     """GPU lattice == C oracle (== reference, tests/test_oracle_lattice.py) on every table."""
     import hplflownet_amd as H
