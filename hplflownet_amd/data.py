@@ -8,6 +8,13 @@ Own restatement of what feeds the hot path in the reference:
   `allow_less_points` fallback (:526-532).  Differences: the RNG is an explicit, seedable
   `numpy.random.RandomState` instead of the global one, and failure returns `(None, None, None)`
   without printing.
+* `Augmentation` (/root/reference/transforms/transforms.py:551-640), the training-time transform:
+  both clouds get one random per-axis scale x rotation about y, one shift and a clipped per-point
+  jitter (:565-590); cloud 2 then gets its own rotation about y and shift (:592-606), `sf` is
+  taken BEFORE cloud 2's own jitter (:607-613); depth cut and sampling as in ProcessData.  The
+  draws are made in the reference's order from the seedable RandomState, so `seed=s` reproduces
+  the reference under `np.random.seed(s)` bit for bit (tests/golden/transforms.npz).  Unlike the
+  reference the caller's arrays are not modified in place.
 * `FlyingThings3DSubset` (/root/reference/datasets/flyingthings3d_subset.py:22-101): leaf
   directories below `<root>/FlyingThings3D_subset_processed_35m/{train,val}` holding `pc1.npy` /
   `pc2.npy`; x and z are negated on load (:96-99); every 4th sample unless `full` (:79-82).
@@ -28,7 +35,7 @@ import os
 import numpy as np
 import torch
 
-__all__ = ['ProcessData', 'FlyingThings3DSubset', 'KITTI']
+__all__ = ['ProcessData', 'Augmentation', 'FlyingThings3DSubset', 'KITTI']
 
 
 class ProcessData(object):
@@ -43,7 +50,10 @@ class ProcessData(object):
         pc1, pc2 = data
         if pc1 is None:
             return None, None, None
-        sf = pc2[:, :3] - pc1[:, :3]
+        return self._select(pc1, pc2, pc2[:, :3] - pc1[:, :3])
+
+    def _select(self, pc1, pc2, sf):
+        """Depth cut + sampling; `sf` rows follow cloud 1's draw."""
         if self.DEPTH_THRESHOLD > 0:
             near = (pc1[:, 2] < self.DEPTH_THRESHOLD) & (pc2[:, 2] < self.DEPTH_THRESHOLD)
         else:
@@ -64,6 +74,55 @@ class ProcessData(object):
         return ('%s\n(data_process_args: \n\tDEPTH_THRESHOLD: %s\n\tNO_CORR: %s\n\tallow_less_points: %s\n'
                 '\tnum_points: %s\n)' % (self.__class__.__name__, self.DEPTH_THRESHOLD, self.no_corr,
                                          self.allow_less_points, self.num_points))
+
+
+def _rot_y(angle, dtype):
+    c, s = np.cos(angle), np.sin(angle)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=dtype)
+
+
+class Augmentation(object):
+    def __init__(self, aug_together_args, aug_pc2_args, data_process_args, num_points, allow_less_points=False,
+                 seed=None):
+        self.together_args = aug_together_args
+        self.pc2_args = aug_pc2_args
+        self.sampler = ProcessData(data_process_args, num_points, allow_less_points)
+        self.rng = self.sampler.rng = np.random.RandomState(seed)
+        self.no_corr = self.sampler.no_corr
+
+    def _jitter(self, a, n):
+        return np.clip(a['jitter_sigma'] * self.rng.randn(n, 3), -a['jitter_clip'], a['jitter_clip']).astype(np.float32)
+
+    def __call__(self, data):
+        pc1, pc2 = data
+        if pc1 is None:
+            return None, None, None
+        tg, p2, rng = self.together_args, self.pc2_args, self.rng
+        n = pc1.shape[0]
+        # common motion of the scene: per-axis scale, rotation about y, shift, per-point jitter (in this draw order)
+        scale = np.diag(rng.uniform(tg['scale_low'], tg['scale_high'], 3).astype(np.float32))
+        m = scale.dot(_rot_y(rng.uniform(-tg['degree_range'], tg['degree_range']), np.float32).T)
+        shift = rng.uniform(-tg['shift_range'], tg['shift_range'], (1, 3)).astype(np.float32)
+        bias = shift + self._jitter(tg, n)
+        a = pc1.copy()
+        b = pc2.copy()
+        a[:, :3] = pc1[:, :3].dot(m) + bias
+        b[:, :3] = pc2[:, :3].dot(m) + bias
+        # extra motion of cloud 2: rotation about y, shift; the flow is read off before its jitter
+        m2 = _rot_y(rng.uniform(-p2['degree_range'], p2['degree_range']), pc1.dtype)
+        shift2 = rng.uniform(-p2['shift_range'], p2['shift_range'], (1, 3)).astype(np.float32)
+        b[:, :3] = b[:, :3].dot(m2.T) + shift2
+        sf = b[:, :3] - a[:, :3]
+        if not self.no_corr:
+            b[:, :3] += self._jitter(p2, n)
+        return self.sampler._select(a, b, sf)
+
+    def __repr__(self):
+        fmt = lambda d: ''.join('\t%-10s %s\n' % (k, d[k]) for k in sorted(d))      # noqa: E731
+        return ('%s\n(together_args: \n%s\npc2_args: \n%s\ndata_process_args: \n\tDEPTH_THRESHOLD: %s\n'
+                '\tNO_CORR: %s\n\tallow_less_points: %s\n\tnum_points: %s\n)' % (
+                    self.__class__.__name__, fmt(self.together_args), fmt(self.pc2_args), self.sampler.DEPTH_THRESHOLD,
+                    self.no_corr, self.sampler.allow_less_points, self.sampler.num_points))
 
 
 def _leaf_dirs(root):

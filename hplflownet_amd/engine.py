@@ -20,6 +20,12 @@ processes on the CPU), and with world_size > 1 every rank trains its own pair an
 are averaged with one bucketed all-reduce over RCCL (parallel.GradAllReducer) -- mean loss over
 the global batch, as `.mean()` over a batch would give.
 
+On real data (`--dataset FlyingThings3DSubset|KITTI --data-root DIR`) the training set goes through
+`data.Augmentation` with the published settings (configs/train_ours.yaml:40-57, main.py:56-63) and is
+visited in a fresh random order every epoch (DataLoader shuffle=True, main.py:67); validation goes
+through `data.ProcessData` in order (main.py:76-90).  `--init xavier` gives the reference's start
+(xavier-normal weights, zero biases: main_utils.py:33-47, main.py:100-101).
+
     python -m hplflownet_amd.engine --arch HPLFlowNet --points 8192 --pairs 8 --epochs 1 --ckpt-dir /tmp/ck
     python -m hplflownet_amd.engine --evaluate --resume /tmp/ck/model_best.pth.tar --pairs 4
 """
@@ -32,6 +38,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
+from . import data as data_mod
 from . import ops, parallel
 from .flownet import HPLFlowNet, HPLFlowNetShallow, load_reference_checkpoint
 from .lattice import GenerateDataUnsymmetric
@@ -53,6 +60,30 @@ def flow_metrics(pred, gt):
             'Acc3DS': float(((err < 0.05) | (rel < 0.05)).float().mean()),
             'Acc3DR': float(((err < 0.1) | (rel < 0.1)).float().mean()),
             'Outliers': float(((err > 0.3) | (rel > 0.1)).float().mean())}
+
+
+# configs/train_ours.yaml:40-57
+DATA_PROCESS = {'DEPTH_THRESHOLD': 35., 'NO_CORR': True}
+AUG_TOGETHER = {'degree_range': 0.1745329252, 'shift_range': 1., 'scale_low': 0.95, 'scale_high': 1.05,
+                'jitter_sigma': 0.01, 'jitter_clip': 0.00}
+AUG_PC2 = {'degree_range': 0., 'shift_range': 0.3, 'jitter_sigma': 0.01, 'jitter_clip': 0.00}
+
+
+def init_weights_(model, init_type='xavier', gain=1.0):
+    """Every Conv*/Linear weight drawn as the reference does, biases zeroed (main_utils.py:33-47)."""
+    fn = {'normal': lambda w: torch.nn.init.normal_(w, 0.0, gain),
+          'xavier': lambda w: torch.nn.init.xavier_normal_(w, gain=gain),
+          'kaiming': lambda w: torch.nn.init.kaiming_normal_(w, a=0, mode='fan_in'),
+          'orthogonal': lambda w: torch.nn.init.orthogonal_(w, gain=gain)}
+    if init_type not in fn:
+        raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+    for m in model.modules():
+        name = m.__class__.__name__
+        if hasattr(m, 'weight') and ('Conv' in name or 'Linear' in name):
+            fn[init_type](m.weight.data)
+            if getattr(m, 'bias', None) is not None:
+                m.bias.data.zero_()
+    return model
 
 
 def model_args(nscales, device='cuda', evaluate=False):
@@ -78,14 +109,18 @@ class SyntheticPairs(object):
 
 
 class Trainer(object):
-    def __init__(self, arch='HPLFlowNet', device='cuda', lr=1e-4, seed=0, distributed=False, rank=0):
+    def __init__(self, arch='HPLFlowNet', device='cuda', lr=1e-4, seed=0, distributed=False, rank=0, init='hash'):
         cls, nsc = ARCHS[arch]
         self.rank = rank
         self.arch, self.device = arch, torch.device(device)
         self.args = model_args(nsc, evaluate=False)
         torch.manual_seed(seed)
         self.model = cls(self.args)
-        fill_module_(self.model, 1.0, 'hash')           # deterministic He-uniform start (no dataset, no RNG state)
+        if init == 'hash':
+            fill_module_(self.model, 1.0, 'hash')       # deterministic He-uniform start (no dataset, no RNG state)
+        else:
+            init_weights_(self.model, init)
+        self.shuffle = np.random.RandomState(seed + 7919 * rank)
         self.model.to(self.device)
         self.gen = GenerateDataUnsymmetric(self.args, device=self.device)
         if self.device.type == 'cuda':
@@ -182,9 +217,9 @@ class Trainer(object):
                 self.opt.load_state_dict(ck['optimizer'])
         return ck
 
-    def fit(self, train_data, val_data, epochs, ckpt_dir=None, log=print):
+    def fit(self, train_data, val_data, epochs, ckpt_dir=None, log=print, shuffle=False):
         for _ in range(self.epoch, epochs):
-            tr = self.train_epoch(train_data)
+            tr = self.train_epoch(train_data, self.shuffle.permutation(len(train_data)) if shuffle else None)
             val = self.validate(val_data)['EPE3D'] if val_data is not None and len(val_data) else tr
             best = self.min_loss is None or val < self.min_loss
             if best:
@@ -206,13 +241,18 @@ def main(argv=None):
     ap.add_argument('--ckpt-dir', default=None)
     ap.add_argument('--resume', default=None)
     ap.add_argument('--evaluate', action='store_true')
+    ap.add_argument('--dataset', default='synthetic', choices=['synthetic', 'FlyingThings3DSubset', 'KITTI'])
+    ap.add_argument('--data-root', default=None)
+    ap.add_argument('--init', default='hash', choices=['hash', 'xavier', 'normal', 'kaiming', 'orthogonal'])
     a = ap.parse_args(argv)
     rank, world, local_rank = parallel.init_distributed()
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
-    tr = Trainer(a.arch, dev, lr=a.lr, distributed=world > 1, rank=rank)
+    tr = Trainer(a.arch, dev, lr=a.lr, distributed=world > 1, rank=rank, init=a.init)
     if a.resume:
         tr.resume(a.resume, load_optimizer=not a.evaluate)
+    if a.dataset != 'synthetic':
+        return _real_data(a, tr, dev, rank, world)
     if a.evaluate:
         res = tr.validate(SyntheticPairs(a.pairs, a.points, dev, first_seed=1000 + rank * a.pairs))
         if rank == 0:
@@ -221,6 +261,46 @@ def main(argv=None):
     train = SyntheticPairs(a.pairs, a.points, dev, first_seed=rank * a.pairs)
     val = SyntheticPairs(a.val_pairs, a.points, dev, first_seed=1000)
     return tr.fit(train, val, a.epochs, a.ckpt_dir, log=print if rank == 0 else (lambda *_: None))
+
+
+class _Shard(object):
+    """Every world-th sample of a reader, starting at rank (independent pairs per GPU)."""
+
+    def __init__(self, reader, rank, world, limit=0):
+        self.reader = reader
+        self.ids = list(range(rank, len(reader), world))
+        if limit > 0:
+            self.ids = self.ids[:limit]
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, i):
+        return self.reader[self.ids[i]]
+
+
+def _real_data(a, tr, dev, rank, world):
+    log = print if rank == 0 else (lambda *_: None)
+    if a.dataset == 'KITTI':                        # evaluation only in the reference (configs/test_ours_KITTI.yaml)
+        val = data_mod.KITTI(data_mod.ProcessData(dict(DATA_PROCESS, NO_CORR=False), a.points, True, seed=0),
+                             a.data_root, device=dev)
+        train = None
+    else:
+        val = data_mod.FlyingThings3DSubset(False, data_mod.ProcessData(DATA_PROCESS, a.points, False, seed=0),
+                                            a.data_root, device=dev)
+        train = None if a.evaluate else data_mod.FlyingThings3DSubset(
+            True, data_mod.Augmentation(AUG_TOGETHER, AUG_PC2, DATA_PROCESS, a.points, False, seed=1 + rank),
+            a.data_root, device=dev)
+    for ds in (train, val):
+        msg = ds.check_counts() if ds is not None else None
+        if msg:
+            log('warning: ' + msg)
+    val = _Shard(val, rank, world, a.val_pairs if train is not None else a.pairs)
+    if train is None:
+        res = tr.validate(val)
+        log(' '.join('%s %.4f' % kv for kv in res.items()))
+        return res
+    return tr.fit(_Shard(train, rank, world, a.pairs), val, a.epochs, a.ckpt_dir, log=log, shuffle=True)
 
 
 if __name__ == '__main__':

@@ -89,3 +89,25 @@ def test_kitti_reader(tmp_path):
     assert np.array_equal(p1.numpy().T, raw1[keep]) and np.array_equal(p2.numpy().T, raw2[keep])
     assert 0 < keep.sum() < 80
     assert len(KITTI(None, root, remove_ground=False, device='cpu')) == 4
+
+
+def test_transforms_match_reference_vectors():
+    """ProcessData / Augmentation with seed=s reproduce the reference run under np.random.seed(s), bit for bit
+    (fixture: tools/make_transform_fixture.py -> tests/golden/transforms.npz), two consecutive calls each."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), 'tools'))
+    import make_transform_fixture as F
+    from hplflownet_amd import data
+    gold = np.load(os.path.join(here, 'golden', 'transforms.npz'))
+    for tag, kind, kw, seed in F.CASES:
+        pc1, pc2 = F.cloud_pair(seed)
+        keep1, keep2 = pc1.copy(), pc2.copy()
+        t = F.make(data, kind, kw, seed=seed)
+        for suffix in ('', '_b'):
+            a, b, sf = t([pc1, pc2])
+            for name, got in (('pc1', a), ('pc2', b), ('sf', sf)):
+                want = gold['%s_%s%s' % (tag, name, suffix)]
+                assert got.dtype == want.dtype and np.array_equal(got, want), (tag, name, suffix)
+        assert np.array_equal(pc1, keep1) and np.array_equal(pc2, keep2)      # inputs are left alone
+    assert 'together_args' in repr(F.make(data, 'Augmentation', F.CASES[3][3 - 1]))

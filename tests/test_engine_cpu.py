@@ -47,3 +47,21 @@ def test_checkpoint_layout_round_trip(tmp_path):
     tr2.model, tr2.opt = other, torch.optim.Adam(other.parameters(), lr=1e-4)
     tr2.resume(path)
     assert tr2.epoch == 11 and tr2.min_loss == 0.25
+
+
+def test_init_weights_and_shards():
+    m = HPLFlowNetShallow(engine.model_args(5, device='cpu'))
+    torch.manual_seed(0)
+    engine.init_weights_(m, 'xavier')
+    w = m.bcn1.blur_conv[0].weight                                    # (64, 68, 15, 1): fan_in 68*15, fan_out 64*15
+    want = (2.0 / ((68 + 64) * 15)) ** 0.5
+    assert abs(float(w.std()) - want) < 0.05 * want
+    assert all(float(p.abs().max()) == 0.0 for n, p in m.named_parameters() if n.endswith('bias') and 'conv' in n)
+    try:
+        engine.init_weights_(m, 'nope')
+        assert False
+    except NotImplementedError:
+        pass
+    sh = [engine._Shard(list(range(10)), r, 4) for r in range(4)]
+    assert sorted(x for s in sh for x in (s[i] for i in range(len(s)))) == list(range(10))
+    assert [s[0] for s in sh] == [0, 1, 2, 3] and len(engine._Shard(list(range(10)), 1, 4, limit=2)) == 2
