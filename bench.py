@@ -187,6 +187,9 @@ def main():
                     help='build each lattice on the main stream instead of a second stream overlapping the previous forward')
     ap.add_argument('--streams', type=int, default=3,
                     help='HIP streams the forwards of consecutive pairs alternate over (pairs in flight)')
+    ap.add_argument('--lattice-depth', type=int, default=2,
+                    help='pairs whose lattice is under construction at once on the lattice stream (1: block on every '
+                         'read-back of vertex counts)')
     ap.add_argument('--arch', default='HPLFlowNet', choices=['HPLFlowNet', 'HPLFlowNetShallow'],
                     help='HPLFlowNetShallow + --points 4096 is BASELINE config 2')
     ap.add_argument('--train', action='store_true',
@@ -275,24 +278,26 @@ def main():
         if overlap else None
 
     def run_pipelined(first, count):
-        """count steps; the lattice of pair i+1 is built on a second HIP stream while the forward of
-        pair i runs on the main stream (the reference overlaps the same two stages with DataLoader
-        worker processes, main.py:85-92).  Exactly `count` lattice builds and `count` forwards."""
+        """count steps; the lattices of the next pairs are built on a second HIP stream while the forward
+        of pair i runs on the main streams (the reference overlaps the same two stages with DataLoader
+        worker processes, main.py:85-92); up to --lattice-depth pairs are under construction at once so
+        that the host never blocks on the per-level vertex counts.  Exactly `count` lattice builds and
+        `count` forwards, the first build starting inside this call."""
         import collections
+        from hplflownet_amd.lattice import LatticePipeline
 
-        def build(i):
+        pipe = LatticePipeline(gen, lambda i: pairs[i % a.pool], first, count, depth=a.lattice_depth, stream=side,
+                               for_training=a.train)
+
+        def build():
             t = time.perf_counter()
-            with torch.cuda.stream(side), torch.no_grad():
-                lat = gen.build(*pairs[i % a.pool]).prepare(for_training=a.train)
-                ev = torch.cuda.Event()
-                ev.record(side)
+            (i, _), lat, ev = pipe.get()
             host['lattice_build_ms'] += (time.perf_counter() - t) * 1e3
-            return lat, ev
+            return i, lat, ev
         keep = collections.deque()
-        nxt = build(first)
         out = None
-        for i in range(first, first + count):
-            lat, ev = nxt
+        for _ in range(count):
+            i, lat, ev = build()
             main = fwd_streams[i % n_fwd]
             main.wait_event(ev)
             t = time.perf_counter()
@@ -302,8 +307,6 @@ def main():
             fin = torch.cuda.Event()
             fin.record(main)
             keep.append((lat, out, fin))          # side-stream allocations stay alive until their forward is done
-            if i + 1 < first + count:
-                nxt = build(i + 1)
             while len(keep) > 1 + n_fwd:
                 keep[0][2].synchronize()
                 keep.popleft()
@@ -427,6 +430,7 @@ def main():
                                        'FT3D-like synthetic pair, N=%d, bs=1 per GPU' % a.points,
                            'num_points': a.points, 'step_includes_lattice_build': not a.no_lattice,
                            'lattice_overlapped_on_second_stream': bool(overlap),
+                           'lattices_under_construction': a.lattice_depth if overlap else 1,
                            'forward_streams': n_fwd if overlap else 1,
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},

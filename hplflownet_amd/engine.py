@@ -41,7 +41,7 @@ import torch
 from . import data as data_mod
 from . import ops, parallel
 from .flownet import HPLFlowNet, HPLFlowNetShallow, load_reference_checkpoint
-from .lattice import GenerateDataUnsymmetric
+from .lattice import GenerateDataUnsymmetric, LatticePipeline
 from .synthetic import SCALES_FILTER_MAP, fill_module_, synthetic_pair
 
 ARCHS = {'HPLFlowNet': (HPLFlowNet, 7), 'HPLFlowNetShallow': (HPLFlowNetShallow, 5)}
@@ -135,32 +135,24 @@ class Trainer(object):
         self._side = torch.cuda.Stream(device=self.device, priority=-1) if self.device.type == 'cuda' else None
 
     # ------------------------------------------------------------------ lattice pipeline
-    def _lattices(self, data, order, training):
-        """Yield (sample, lattice) for `order`; sample k+1 is fetched (once: readers may sample randomly)
-        and its lattice built on the side stream while k is consumed."""
+    def _lattices(self, data, order, training, depth=2):
+        """Yield (sample, lattice) for `order`.  Each sample is fetched once (readers may sample randomly);
+        the lattices of the next `depth` samples are under construction on the side stream while the
+        current one is consumed, and the host never blocks on their vertex-count read-backs."""
         main = torch.cuda.current_stream(self.device)
-
-        def build(i):
-            sample = data[i]
-            with torch.cuda.stream(self._side), torch.no_grad():
-                lat = self.gen.build(sample[0], sample[1]).prepare(for_training=training)
-                ev = torch.cuda.Event()
-                ev.record(self._side)
-            return sample, lat, ev
+        pipe = LatticePipeline(self.gen, lambda k: data[order[k]], 0, len(order), depth=depth, stream=self._side,
+                               for_training=training)
         keep = collections.deque()
-        nxt = build(order[0]) if order else None
-        for k, i in enumerate(order):
-            sample, lat, ev = nxt
+        for _ in range(len(order)):
+            (_, sample), lat, ev = pipe.get()
             main.wait_event(ev)
-            if k + 1 < len(order):
-                nxt = build(order[k + 1])
             yield sample, lat
             fin = torch.cuda.Event()
             fin.record(main)
-            keep.append((lat, fin))                 # side-stream memory stays alive until its consumer is done
+            keep.append((lat, sample, fin))         # side-stream memory stays alive until its consumer is done
             while len(keep) > 2:
-                keep.popleft()[1].synchronize()
-        for _, fin in keep:
+                keep.popleft()[2].synchronize()
+        for _, _, fin in keep:
             fin.synchronize()
 
     # ------------------------------------------------------------------ loops

@@ -72,6 +72,13 @@ class DeviceLattice(object):
         """Build every lazily constructed table (CSRs, tap orders, symmetry verdicts) now, on the
         current stream, so that a lattice built on a side stream is complete before it is handed to
         the forward.  for_training: the tables of the per-cloud path + the symmetry read-back."""
+        self.prepare_tables(for_training)
+        if for_training:
+            self.resolve_symmetry()
+        return self
+
+    def prepare_tables(self, for_training=False):
+        """The launches of prepare() without its read-back (lattice.LatticeBuild overlaps that one)."""
         for L, lv in enumerate(self.levels):
             if lv.pair is not None:
                 lv.pair.csr()       # one build; the per-cloud CSRs are views / offset copies of it
@@ -88,13 +95,11 @@ class DeviceLattice(object):
                     tbl.perm
             if isinstance(lv.blur, PairBlur):
                 lv.blur[0].groups()             # row orders of the tap groups (wide Up convs, multi-pass)
-        if for_training:
-            self.resolve_symmetry()
         return self
 
-    def resolve_symmetry(self):
-        """Decide `symmetric` of every blur / corr1 table that has not been checked yet with ONE host
-        read-back (the backward picks the mirrored-gather or the atomic-scatter form from it)."""
+    def symmetry_begin(self):
+        """Launch the symmetry checks of every blur / corr1 table not decided yet and start the copy of
+        their flags to pinned memory -> (todo, event or None); symmetry_finish(todo) after the event."""
         todo = []
         for lv in self.levels:
             tables = [lv.corr1]
@@ -105,9 +110,19 @@ class DeviceLattice(object):
             for t in tables:
                 if t is not None and t._sym is None and t.t.shape[0] == 15 and all(t is not u for u, _ in todo):
                     todo.append((t, ops.table_symmetry_flag(t.t)))
+        if not todo:
+            return (todo, None), None
+        flags = torch.cat([f for _, f in todo])
+        host = torch.empty(flags.shape, dtype=flags.dtype, pin_memory=True)
+        host.copy_(flags, non_blocking=True)
+        landed = torch.cuda.Event()
+        landed.record()
+        return (todo, host), landed
+
+    def symmetry_finish(self, begun):
+        todo, host = begun
         if todo:
-            flags = torch.cat([f for _, f in todo]).tolist()
-            for (t, _), v in zip(todo, flags):
+            for (t, _), v in zip(todo, host.tolist()):
                 t._sym = bool(v)
         for lv in self.levels:
             if isinstance(lv.blur, PairBlur):            # the per-cloud views inherit the pair's verdict
@@ -115,6 +130,14 @@ class DeviceLattice(object):
                     if lv.blur._own[i] is not None and lv.blur._own[i]._sym is None:
                         lv.blur._own[i]._sym = lv.blur.pair._sym
         return self
+
+    def resolve_symmetry(self):
+        """Decide `symmetric` of every blur / corr1 table that has not been checked yet with ONE host
+        read-back (the backward picks the mirrored-gather or the atomic-scatter form from it)."""
+        begun, landed = self.symmetry_begin()
+        if landed is not None:
+            landed.synchronize()
+        return self.symmetry_finish(begun)
 
     @staticmethod
     def from_generated_data(gd, device):

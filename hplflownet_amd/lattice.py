@@ -9,9 +9,13 @@ hplflownet_amd.flownet consume directly; `to_reference_format()` gives the refer
 list-of-dicts wire format (int64) for anything else.
 
 The float part is bit-identical to the reference's torch-CPU arithmetic as measured in the
-build container (see oracle/lattice_oracle.c); the integer part is exact.  One host
-synchronisation per level remains: the vertex counts size the next level's arrays.
+build container (see oracle/lattice_oracle.c); the integer part is exact.  One host read-back
+per level remains: the vertex counts size the next level's arrays.  `build()` waits for each;
+`LatticeBuild` / `LatticePipeline` keep several pairs under construction on one stream and only
+resume a pair once its counts have landed in pinned memory, so the host thread never blocks on
+them in steady state (bench.py and engine.Trainer feed the forward this way).
 """
+import collections
 import math
 
 import numpy as np
@@ -38,7 +42,19 @@ class GenerateDataUnsymmetric(object):
         self.device = torch.device(device)
 
     def build(self, pc1, pc2):
-        """pc1, pc2: (3, N) float32 device tensors -> DeviceLattice."""
+        """pc1, pc2: (3, N) float32 device tensors -> DeviceLattice (blocks on every read-back)."""
+        steps = self.build_steps(pc1, pc2)
+        try:
+            while True:
+                next(steps).synchronize()
+        except StopIteration as fin:
+            return fin.value
+
+    def build_steps(self, pc1, pc2):
+        """Generator form of build(): launches everything up to the next read-back of vertex counts
+        (an asynchronous copy into pinned memory), yields the event that marks its arrival and must be
+        resumed -- on the same stream -- only after that event has completed; returns the DeviceLattice
+        (StopIteration.value)."""
         L = _lib.load()
         dev = pc1.device
         pts = [pc1.contiguous().float(), pc2.contiguous().float()]     # level 0: the clouds themselves
@@ -46,6 +62,7 @@ class GenerateDataUnsymmetric(object):
         prev = None           # deeper levels: (vertex keys of the level above, their column stride, divisor)
         levels = []
         nlev = len(self.scales_filter_map)
+        counts_host = torch.empty((nlev, 2), dtype=torch.int32, pin_memory=True)
         for idx, (scale, bcn_r, cf_r, cc_r) in enumerate(self.scales_filter_map):
             emg_p = torch.empty((n[0] + n[1], 4), dtype=torch.float32, device=dev)     # both clouds, point-major
             emg = [emg_p[:n[0]], emg_p[n[0]:]]
@@ -68,7 +85,11 @@ class GenerateDataUnsymmetric(object):
             counts = torch.empty(2, dtype=torch.int32, device=dev)
             check(L.hpl_lattice_hash(ptr(keys[0]), n[0], ptr(keys[1]), n[1], ptr(off[0]), ptr(off[1]), ptr(vk[0]),
                                      ptr(vk[1]), ptr(counts), ptr(ws), wsb, stream()), 'hpl_lattice_hash')
-            H = [int(v) for v in counts.tolist()]                  # host sync: sizes of the next arrays
+            counts_host[idx].copy_(counts, non_blocking=True)      # sizes of the next arrays
+            landed = torch.cuda.Event()
+            landed.record()
+            yield landed
+            H = [int(v) for v in counts_host[idx].tolist()]
             blur_p = None
             blur_ptr = [None, None]
             corr1 = corr2 = None
@@ -118,6 +139,100 @@ class GenerateDataUnsymmetric(object):
 
     def __repr__(self):
         return '%s\n(scales_filter_map: %s\n)' % (self.__class__.__name__, self.scales_filter_map)
+
+
+class LatticeBuild(object):
+    """One pair's lattice under construction on `stream`: advance() launches up to the next read-back
+    and returns; `done` / `result` / `event` (recorded on `stream` after the last launch, incl.
+    prepare()) once finished."""
+
+    def __init__(self, gen, pc1, pc2, stream=None, for_training=False, prepare=True, tag=None):
+        self.stream = stream if stream is not None else torch.cuda.current_stream(pc1.device)
+        self.tag = tag
+        self.done = False
+        self.result = self.event = None
+        self._pending = None
+        self._steps = self._run(gen, pc1, pc2, for_training, prepare)
+
+    def _run(self, gen, pc1, pc2, for_training, prepare):
+        lat = yield from gen.build_steps(pc1, pc2)
+        if prepare:
+            lat.prepare_tables(for_training)
+            if for_training:
+                begun, landed = lat.symmetry_begin()
+                if landed is not None:
+                    yield landed
+                lat.symmetry_finish(begun)
+        return lat
+
+    def ready(self):
+        """True if advance() would not block."""
+        return self.done or self._pending is None or self._pending.query()
+
+    def advance(self):
+        if self.done:
+            return True
+        if self._pending is not None:
+            self._pending.synchronize()
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            try:
+                self._pending = next(self._steps)
+            except StopIteration as fin:
+                self.result, self.done, self._pending = fin.value, True, None
+                self.event = torch.cuda.Event()
+                self.event.record(self.stream)
+        return self.done
+
+    def finish(self):
+        while not self.advance():
+            pass
+        return self.result
+
+
+class LatticePipeline(object):
+    """Lattices of consecutive pairs, up to `depth` under construction at once on one stream.
+
+    `source(i)` -> (pc1, pc2) device tensors (3, N) of pair i; pairs first .. first+count-1 are built,
+    each exactly once, and handed out in order by get() as ((i, source(i)), DeviceLattice, event); the
+    consumer's stream must wait for `event`, and must keep the pair and the lattice referenced until its
+    own work on them is done (they were allocated on the lattice stream).  get() resumes, round robin, each
+    pair whose counts have already landed until the oldest is complete, and blocks only when no pair can
+    move."""
+
+    def __init__(self, gen, source, first, count, depth=2, stream=None, for_training=False):
+        self.gen, self.source, self.depth = gen, source, max(1, int(depth))
+        self.stream, self.for_training = stream, for_training
+        self._next, self._end = first, first + count
+        self._inflight = collections.deque()
+
+    def _top_up(self):
+        while len(self._inflight) < self.depth and self._next < self._end:
+            with torch.cuda.stream(self.stream):        # a reader's host-to-device copies belong to this stream too
+                item = self.source(self._next)
+            b = LatticeBuild(self.gen, item[0], item[1], self.stream, self.for_training, tag=(self._next, item))
+            b.advance()
+            self._inflight.append(b)
+            self._next += 1
+
+    def get(self):
+        self._top_up()
+        if not self._inflight:
+            raise StopIteration('all %d lattices were handed out' % self._end)
+        head = self._inflight[0]
+        while not head.done:
+            # resume whoever has its counts, oldest first; launching those stages takes about as long as the
+            # read-backs of the others, so the blocking advance of the head below is the rare case
+            moved = False
+            for b in self._inflight:
+                if not b.done and b.ready():
+                    b.advance()
+                    moved = True
+            if not moved:
+                head.advance()
+        self._inflight.popleft()
+        self._top_up()
+        return head.tag, head.result, head.event
+
 
 
 def to_reference_format(lat):

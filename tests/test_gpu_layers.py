@@ -367,3 +367,44 @@ def test_single_cloud_lattice_entries_match_pair_entry():
     for c in (0, 1):
         for a, b in zip(ref[c], got[c]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('depth,training', [(1, False), (4, False), (3, True)])
+def test_lattice_pipeline_equals_blocking_build(depth, training):
+    """Several pairs under construction at once on a side stream (asynchronous read-backs of the vertex
+    counts) give, pair by pair and in order, exactly the tables of the blocking build; each pair is
+    fetched once; symmetry verdicts are resolved when the lattice is built for training."""
+    import hplflownet_amd as H
+    from hplflownet_amd.lattice import LatticeBuild, LatticePipeline
+    gen = H.GenerateDataUnsymmetric(types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP), device=DEV)
+    sizes = [300, 64, 1000, 17, 512, 128]
+    pairs, fetched = [], []
+    for s, n in enumerate(sizes):
+        p1, p2, _ = synthetic_pair(n, 20 + s)
+        pairs.append((torch.from_numpy(p1.T.copy()).to(DEV), torch.from_numpy(p2[: max(1, n - s)].T.copy()).to(DEV)))
+
+    def source(i):
+        fetched.append(i)
+        return pairs[i]
+    side = torch.cuda.Stream()
+    pipe = LatticePipeline(gen, source, 1, 5, depth=depth, stream=side, for_training=training)
+    for want in range(1, 6):
+        (i, item), lat, ev = pipe.get()
+        assert i == want and item is pairs[i]
+        ev.synchronize()
+        ref = H.to_reference_format(gen.build(*pairs[i]))
+        for l, (x, y) in enumerate(zip(H.to_reference_format(lat), ref)):
+            for k in y:
+                same = torch.equal(x[k], y[k]) if torch.is_tensor(y[k]) else x[k] == y[k]
+                assert same, (i, l, k)
+        if training:
+            assert all(lv.blur.pair._sym is not None for lv in lat.levels)
+    assert fetched == [1, 2, 3, 4, 5]
+    with pytest.raises(StopIteration):
+        pipe.get()
+    # a single build driven by hand: ready() / advance() / finish()
+    b = LatticeBuild(gen, pairs[0][0], pairs[0][1], stream=side, prepare=False)
+    steps = 0
+    while not b.advance():
+        steps += 1
+    assert steps == len(SCALES_FILTER_MAP) and b.ready() and b.finish() is b.result
