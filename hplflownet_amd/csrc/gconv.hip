@@ -775,7 +775,7 @@ struct WParams {
     float *dbias;        // optional: dbias[n] += sum_m dY[m, n] (by the k-tile-0 workgroups; not in tap mode)
 };
 
-template <int BN, bool VEC, bool TAP, int NT = 256>
+template <int BN, bool VEC, bool TAP, int NT = 256, bool DEEP = false>
 __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
     constexpr int BKR = 128;                 // rows of dWt per tile (flat k)
     constexpr int BMS = 32;                  // vertices per step
@@ -804,8 +804,10 @@ __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
     const int32_t *vm = TAP ? p.tap_m + p.tap_ptr[tap] : nullptr;
     const int32_t *vrow = TAP ? p.tap_row + p.tap_ptr[tap] : nullptr;
     const int64_t m_total = TAP ? (int64_t)(p.tap_ptr[tap + 1] - p.tap_ptr[tap]) : p.M;
-    const int64_t mb = (int64_t)blockIdx.y * p.m_per_split;
-    const int64_t me = imin(m_total, mb + p.m_per_split);
+    // the vertex loop is cut into gridDim.y slabs; a tap's own list is cut evenly (lists differ in length)
+    const int64_t per = TAP ? ((m_total + gridDim.y - 1) / gridDim.y + BMS - 1) / BMS * BMS : p.m_per_split;
+    const int64_t mb = (int64_t)blockIdx.y * per;
+    const int64_t me = imin(m_total, mb + per);
     if (mb >= me) return;
 
     const int t = threadIdx.x, lane = t & 63;
@@ -819,7 +821,9 @@ __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
     const bool k_ok = TAP ? (c_t < p.C) : (kk < p.K);
     const int bn4 = t % B_F4, brow0 = t / B_F4;
 
-    float4 ra[A_PASSES], rb[B_PASSES];
+    // Two register sets: the rows of step s+2 are being fetched while those of step s+1 wait in the
+    // other set for their turn in LDS (DEEP; tap mode, whose rows come from L2 misses more often).
+    float4 ra0[A_PASSES], rb0[B_PASSES], ra1[DEEP ? A_PASSES : 1], rb1[DEEP ? B_PASSES : 1];
     // Indices of a step are fetched one step before its data (source row of every gathered A row,
     // vertex of every dY row): the data loads of step s+1 and the index loads of step s+2 are in
     // flight while step s is multiplied.
@@ -845,7 +849,7 @@ __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
             mi[i] = (r < BMS && j < me) ? (TAP ? vm[j] : (int)j) : -1;
         }
     };
-    auto load_data = [&](int64_t ms) {
+    auto load_data = [&](int64_t ms, float4 *ra, float4 *rb) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -888,7 +892,7 @@ __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
             if (!TAP && do_bias) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const float4 *ra, const float4 *rb) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i)
             *reinterpret_cast<float4 *>(As + buf * BMS * BKR + (arow0 + i * A_ROWS_PER_PASS) * BKR + ak4 * 4) = ra[i];
@@ -908,16 +912,7 @@ __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int64_t nsteps = (me - mb + BMS - 1) / BMS;
-    load_idx(mb);
-    load_data(mb);
-    if (nsteps > 1) load_idx(mb + BMS);
-    store_lds(0);
-    __syncthreads();
-    int cur = 0;
-    for (int64_t st = 0; st < nsteps; ++st) {
-        const bool more = st + 1 < nsteps;
-        if (more) load_data(mb + (st + 1) * BMS);
-        if (st + 2 < nsteps) load_idx(mb + (st + 2) * BMS);
+    auto multiply = [&](int cur) {
         const float *a = As + cur * BMS * BKR + wm * WTM + li;
         const float *b = Bs + cur * BMS * BN + wn * WTN + li;
 #pragma unroll
@@ -933,9 +928,43 @@ __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_lds(cur ^ 1);
+    };
+    if (DEEP) {
+        // step st: LDS buffer `cur` holds st, register set (st+1)&1 holds st+1, set st&1 is free for st+2,
+        // the index registers hold st+2 and are refilled for st+3 once its loads are issued
+        load_idx(mb);
+        load_data(mb, ra0, rb0);
+        if (nsteps > 1) { load_idx(mb + BMS); load_data(mb + BMS, ra1, rb1); }
+        if (nsteps > 2) load_idx(mb + 2 * BMS);
+        store_lds(0, ra0, rb0);
         __syncthreads();
-        cur ^= 1;
+        auto body = [&](int64_t st, int cur, float4 *fa, float4 *fb, float4 *na, float4 *nb) {
+            if (st + 2 < nsteps) load_data(mb + (st + 2) * BMS, fa, fb);
+            if (st + 3 < nsteps) load_idx(mb + (st + 3) * BMS);
+            multiply(cur);
+            if (st + 1 < nsteps) store_lds(cur ^ 1, na, nb);
+            __syncthreads();
+        };
+        for (int64_t st = 0; st < nsteps; st += 2) {
+            body(st, 0, ra0, rb0, ra1, rb1);
+            if (st + 1 < nsteps) body(st + 1, 1, ra1, rb1, ra0, rb0);
+        }
+    } else {
+        load_idx(mb);
+        load_data(mb, ra0, rb0);
+        if (nsteps > 1) load_idx(mb + BMS);
+        store_lds(0, ra0, rb0);
+        __syncthreads();
+        int cur = 0;
+        for (int64_t st = 0; st < nsteps; ++st) {
+            const bool more = st + 1 < nsteps;
+            if (more) load_data(mb + (st + 1) * BMS, ra0, rb0);
+            if (st + 2 < nsteps) load_idx(mb + (st + 2) * BMS);
+            multiply(cur);
+            if (more) store_lds(cur ^ 1, ra0, rb0);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
     if (!TAP && do_bias) {
         // column sums of this workgroup's dY slab: threads with the same float4 column combine in LDS
@@ -1005,9 +1034,24 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
     p.tiles_n = (int)cdiv(N, bn);
     const int tiles = tiles_k * p.tiles_n;
     // split the vertex axis so that ~4 workgroups per CU exist, each with >= 256 vertices
-    int64_t splits = imax(1, imin(cdiv(1024, tiles), cdiv(m_len, 256)));
+    // Slabs of the vertex loop per tile: workgroups run 2 per CU (512 at a time); pick the count that
+    // minimises rounds x (slab length + the cost of the atomic epilogue, ~256 vertices' worth).  In tap
+    // mode the lists are ~half of M and unequal; finer slabs even them out (~16 workgroups per slot).
+    static const int force_splits = getenv("HPL_WGRAD_SPLITS") ? atoi(getenv("HPL_WGRAD_SPLITS")) : 0;
+    int64_t splits = 1;
+    {
+        const int64_t len = tap ? imax(1, m_len / 2) : m_len;
+        const int64_t smax = imax(1, imin(64, cdiv(len, 256)));
+        int64_t best = INT64_MAX;
+        for (int64_t sp = 1; sp <= smax; ++sp) {
+            const int64_t cost = cdiv((int64_t)tiles * sp, 512) * (cdiv(cdiv(len, sp), 32) * 32 + 256);
+            if (cost < best) { best = cost; splits = sp; }
+        }
+        if (tap) splits = imax(1, imin(cdiv(8192, tiles), cdiv(len, 512)));      // measured: finer is better
+        if (force_splits > 0) splits = force_splits;
+    }
     p.m_per_split = cdiv(cdiv(m_len, splits), 32) * 32;
-    splits = cdiv(m_len, p.m_per_split);
+    if (!tap) splits = cdiv(m_len, p.m_per_split);
     dim3 grid(tiles, (unsigned)splits);
     hipStream_t s = to_stream(stream);
 #define LAUNCH(BN_)                                                          \
@@ -1017,7 +1061,10 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
         else k_wgrad<BN_, false, false><<<grid, 256, 0, s>>>(p);             \
     } while (0)
     if (bn == 128 && vec) {     // 8 waves (2x4): 4 waves per SIMD, 2-5 % over 4 waves
-        if (tap) k_wgrad<128, true, true, 512><<<grid, 512, 0, s>>>(p);
+        static const bool deep = getenv("HPL_WGRAD_DEEP") ? atoi(getenv("HPL_WGRAD_DEEP")) != 0 : true;
+        if (tap && deep) k_wgrad<128, true, true, 512, true><<<grid, 512, 0, s>>>(p);
+        else if (tap) k_wgrad<128, true, true, 512><<<grid, 512, 0, s>>>(p);
+        else if (deep) k_wgrad<128, true, false, 512, true><<<grid, 512, 0, s>>>(p);
         else k_wgrad<128, true, false, 512><<<grid, 512, 0, s>>>(p);
     } else
     if (bn == 128) LAUNCH(128); else if (bn == 64) LAUNCH(64); else LAUNCH(32);
