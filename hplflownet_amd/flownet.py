@@ -82,10 +82,12 @@ class DeviceLattice(object):
         for L, lv in enumerate(self.levels):
             if lv.pair is not None:
                 lv.pair.csr()       # one build; the per-cloud CSRs are views / offset copies of it
-            if lv.pair is not None and not for_training:
-                # inference path: the Down layers run once per pair; cloud 1 alone is splatted only by the
-                # correlation layers that take a previous correlation (levels >= 3)
-                tables = [lv.blur.pair, lv.blur[0], lv.corr1] if isinstance(lv.blur, PairBlur) else [lv.corr1]
+            if lv.pair is not None and isinstance(lv.blur, PairBlur):
+                # the Down layers run once per pair; cloud 1 alone is splatted only by the correlation
+                # layers that take a previous correlation (levels >= 3) and sliced by the Up layers
+                tables = [lv.blur.pair, lv.blur[0], lv.corr1]
+                if for_training:
+                    lv.clouds[0].csr()
             else:
                 for c in lv.clouds:
                     c.csr()
@@ -205,8 +207,8 @@ class _FlowNetBase(nn.Module):
     UP = None            # per level L: num_output of bcn{L+1}_
     REFINE = False       # corr{j}_refine Conv1d stacks (shallow model)
     HEAD_IN = None
-    #: inference on a device-built lattice runs the Down path once per PAIR (both clouds stacked);
-    #: False forces the per-cloud path (what training and reference-format lattices use)
+    #: on a device-built lattice the Down path runs once per PAIR (both clouds stacked), in inference and
+    #: in training; False forces the per-cloud path (what reference-format lattices use)
     pair_batched = not os.environ.get('HPL_NO_PAIR')      # env: A/B switch for benchmarking
 
     def __init__(self, args):
@@ -287,12 +289,27 @@ class _FlowNetBase(nn.Module):
             lat.resolve_symmetry()
             if ops.BANK is not None:
                 ops.BANK.refresh()          # all weight images of this step in one launch
-        pair = (not torch.is_grad_enabled()) and self.pair_batched and \
+        pair = self.pair_batched and \
             all(lv.pair is not None and isinstance(lv.blur, PairBlur) for lv in lat.levels[:nlev])
         down = [[], []]
         corrs = {}
         prev = None
-        if pair:
+        if pair and torch.is_grad_enabled():
+            # the same stacked Down path written with autograd-visible ops (cat instead of in-place columns)
+            y = self._stack(torch.cat([to_channel_last(pc1), to_channel_last(pc2)], dim=0), self.conv1)
+            for L in range(nlev):
+                lv = lat.levels[L]
+                layer = getattr(self, 'bcn%d' % (L + 1))
+                if L == 0 and (lv.clouds[0].N != pc1.shape[2] or lv.clouds[1].N != pc2.shape[2]):
+                    raise _lib.HplError('lattice was built for %d / %d points, got %d / %d'
+                                        % (lv.clouds[0].N, lv.clouds[1].N, pc1.shape[2], pc2.shape[2]))
+                y = layer.forward_cl(torch.cat([lv.emg_pair, y], dim=1), lv.pair, lv.blur.pair, None)
+                feats = [y[:lv.H[0]], y[lv.H[0]:]]
+                down[0].append(feats[0])
+                down[1].append(feats[1])
+                if L >= 2:
+                    prev = self._corr(L, lat, feats, prev, corrs, dev)
+        elif pair:
             # Both clouds go through conv1 and the Down BCLs as ONE stacked matrix (cloud 2's points and
             # vertices behind cloud 1's; pair CSR, pair blur table): half the launches, and the output
             # of level L is written straight into columns [4, 4+C) of level L+1's input.

@@ -84,6 +84,10 @@ class CloudTables(object):
             self._csr = (csr_ptr, csr_pt, csr_w, norm)
         return self._csr
 
+    def slice_back(self, g, use_norm):
+        """Backward of the splat: g [H, C] -> [N, C] = sum_r bary[r, n] * norm[v] * g[v = off[r, n]]."""
+        return slice_raw(g, self.bary, self.off, self.N, vscale=self.csr()[3] if use_norm else None)
+
 
 class PairTables(object):
     """Both clouds of one lattice level treated as one cloud: points [0,N0) + [N0,N0+N1), vertices
@@ -116,6 +120,16 @@ class PairTables(object):
             if c1._csr is None:
                 c1._csr_src = (self, c0.N, c0.H)
         return self._csr
+
+    def slice_back(self, g, use_norm):
+        """Backward of the pair splat: each cloud's rows from its own vertices (one launch per cloud
+        into the two halves of one [N0+N1, C] matrix)."""
+        c0, c1 = self.c0, self.c1
+        norm = self.csr()[3] if use_norm else None
+        out = torch.empty((self.N, g.shape[1]), dtype=torch.float32, device=g.device)
+        slice_raw(g[:c0.H], c0.bary, c0.off, c0.N, vscale=norm[:c0.H] if use_norm else None, out=out[:c0.N])
+        slice_raw(g[c0.H:], c1.bary, c1.off, c1.N, vscale=norm[c0.H:] if use_norm else None, out=out[c0.N:])
+        return out
 
 
 def tap_order(nbr):
@@ -311,10 +325,8 @@ class SplatFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        c = ctx.cloud
         g = g if g.stride(1) == 1 else g.contiguous()
-        norm = c.csr()[3] if ctx.use_norm else None
-        return slice_raw(g, c.bary, c.off, c.N, vscale=norm), None, None
+        return ctx.cloud.slice_back(g, ctx.use_norm), None, None
 
 
 class SliceFn(torch.autograd.Function):

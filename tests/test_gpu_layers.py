@@ -153,6 +153,15 @@ def test_whole_model_golden_F5(tag, cls, n, nsc):
     scale = max(want.values())
     for k in want:
         assert abs(got[k] - want[k]) < 2e-3 * max(want[k], 1e-3 * scale), (k, got[k], want[k])
+    # the device-built lattice takes the pair-batched Down path under autograd: same bar against the reference
+    gen = H.GenerateDataUnsymmetric(model_args(nsc), device=DEV)
+    lat = gen.build(p1[0], p2[0]).prepare(for_training=True)
+    m.zero_grad(set_to_none=True)
+    lossp = torch.norm(m(p1, p2, lat) - T(sf.T)[None], p=2, dim=1).mean()
+    assert abs(float(lossp.item()) - float(z[tag + '_loss'])) < 1e-4
+    lossp.backward()
+    for k, p in m.named_parameters():
+        assert abs(float(p.grad.norm()) - want[k]) < 2e-3 * max(want[k], 1e-3 * scale), (k, 'pair path')
     # inference path (no autograd, in-place channel-block writes) gives the same flow
     with torch.no_grad():
         y2 = m(p1, p2, gd_batched_device(gd[:nsc]))
@@ -279,6 +288,25 @@ def test_pair_batched_down_path_equals_per_cloud(cls, nsc, n1, n2):
     assert torch.equal(y_sep, y_ref)
     scale = max(1.0, float(y_sep.abs().max()))
     assert float((y_pair - y_sep).abs().max()) < 1e-5 * scale
+    # training: the same stacked Down path under autograd -- loss and every parameter gradient agree
+    sf = torch.from_numpy(np.ascontiguousarray((pc2[:n1] - pc1[:n1]).T if n2 >= n1 else pc1.T * 0.1)).to(DEV)
+    grads = []
+    for pair_mode in (True, False):
+        m.pair_batched = pair_mode
+        m.zero_grad(set_to_none=True)
+        lat_t = gen.build(t1, t2).prepare(for_training=True)
+        loss = torch.norm(m(t1[None], t2[None], lat_t) - sf[None], p=2, dim=1).mean()
+        loss.backward()
+        grads.append((float(loss.detach()), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    (la, ga), (lb, gb) = grads
+    assert abs(la - lb) < 1e-5 * max(1.0, abs(lb)) and set(ga) == set(gb)
+    scale = max(float(g.norm()) for g in gb.values())
+    # Same sums in another order + LeakyReLU kinks deep in the chain.  Noise floor measured on the per-cloud path
+    # alone by scaling all weights by (1 + 1e-7): worst entry moves by 4.1e-3 of the largest entry of its tensor
+    # (bcn3_ weight, few vertices per entry), worst norm by 5.4e-4 -- the pair path differs by exactly as much.
+    for k in gb:
+        assert abs(float(ga[k].norm()) - float(gb[k].norm())) <= 2e-3 * max(float(gb[k].norm()), 1e-3 * scale), k
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-2 * float(gb[k].abs().max()) + 1e-7, k
 
 
 def test_device_lattice_fuzz_vs_oracle():
