@@ -161,25 +161,11 @@ __global__ void __launch_bounds__(256) k_scan_sums(const int32_t *__restrict__ i
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// in-place exclusive scan of nb <= 1024 block sums; block_sums[nb] = grand total
-__global__ void __launch_bounds__(256) k_scan_top(int32_t *__restrict__ block_sums, int nb) {
-    const int i0 = threadIdx.x * 4;
-    int v[4], s = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = (i0 + j < nb) ? block_sums[i0 + j] : 0; s += v[j]; }
-    int total;
-    int run = block_exclusive_scan_256(s, &total);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (i0 + j < nb) block_sums[i0 + j] = run;
-        run += v[j];
-    }
-    if (threadIdx.x == 0) block_sums[nb] = total;
-}
-
+// base: where the running total of the chunks before this one stands (nullptr: 0).  It is the
+// previous chunk's out[n], i.e. this chunk's out[0], which is rewritten with the same value.
 __global__ void __launch_bounds__(256) k_scan_final(const int32_t *__restrict__ in, int64_t n,
                                                     const int32_t *__restrict__ block_sums, int nb,
-                                                    int32_t *__restrict__ out) {
+                                                    int32_t *out, const int32_t *base) {
     const int64_t i0 = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
     int v[4], s = 0;
 #pragma unroll
@@ -192,7 +178,7 @@ __global__ void __launch_bounds__(256) k_scan_final(const int32_t *__restrict__ 
         for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_sums[b];
         int tot;
         block_exclusive_scan_256(part, &tot);
-        if (threadIdx.x == 0) boff_s = tot;
+        if (threadIdx.x == 0) boff_s = tot + (base ? *base : 0);
         __syncthreads();
     }
     int run = block_exclusive_scan_256(s, nullptr) + boff_s;
@@ -389,10 +375,16 @@ extern "C" int hpl_leaky_bwd(const float *dY, int64_t lddy, const float *Y, int6
 // shared with lattice.hip.  tmp: cdiv(n, 1024) + 1 ints.
 namespace hpl {
 int exclusive_scan_i32(const int32_t *cnt, int64_t n, int32_t *ptr, int32_t *tmp, hipStream_t s) {
-    const int64_t nb = cdiv(n, SCAN_BLOCK);
-    HPL_REQUIRE(nb >= 1 && nb <= 1024, "exclusive_scan_i32: n=%lld out of range", (long long)n);
-    k_scan_sums<<<(int)nb, 256, 0, s>>>(cnt, n, tmp);
-    k_scan_final<<<(int)nb, 256, 0, s>>>(cnt, n, tmp, (int)nb, ptr);
+    HPL_REQUIRE(n >= 1 && n < (int64_t)INT32_MAX, "exclusive_scan_i32: n=%lld out of range", (long long)n);
+    // chunks of 1024 blocks x 1024 elements; a chunk continues from the total the previous one left in
+    // ptr[chunk start] (same stream, so it is there)
+    constexpr int64_t CHUNK = (int64_t)1024 * SCAN_BLOCK;
+    for (int64_t c0 = 0; c0 < n; c0 += CHUNK) {
+        const int64_t len = imin(CHUNK, n - c0);
+        const int nb = (int)cdiv(len, SCAN_BLOCK);
+        k_scan_sums<<<nb, 256, 0, s>>>(cnt + c0, len, tmp);
+        k_scan_final<<<nb, 256, 0, s>>>(cnt + c0, len, tmp, nb, ptr + c0, c0 ? ptr + c0 : nullptr);
+    }
     HPL_CHECK_LAUNCH("exclusive_scan_i32");
     return HPL_OK;
 }

@@ -62,6 +62,20 @@ def test_csr_build(ops, n, level):
     assert rel_err(norm, 1.0 / (w + 1e-5)) < 1e-6
 
 
+def test_csr_build_beyond_one_scan_chunk(ops):
+    """More than 2^20 vertices: the exclusive scan runs in chunks that continue from each other's totals."""
+    rng = np.random.RandomState(3)
+    N, H = 450000, (1 << 20) + 300001
+    off = rng.randint(0, H, (4, N)).astype(np.int32)
+    off[0, :5] = [0, H - 1, (1 << 20) - 1, 1 << 20, (1 << 20) + 1]          # both sides of the chunk seam
+    bary = rng.uniform(0.05, 1.0, (4, N)).astype(np.float32)
+    csr_ptr, csr_pt, csr_w, _ = [t.cpu().numpy() for t in ops.CloudTables(dev(bary), dev(off), H).csr()]
+    flat = off.reshape(-1)
+    order = np.argsort(flat, kind='stable')
+    assert np.array_equal(csr_ptr, np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=H))]).astype(np.int32))
+    assert np.array_equal(csr_pt, (order % N).astype(np.int32)) and np.array_equal(csr_w, bary.reshape(-1)[order])
+
+
 @pytest.mark.parametrize('C', [68, 64, 4, 12, 5, 33, 128, 1024])
 def test_splat_and_slice(ops, C):
     from oracle import bcl_oracle as BO
