@@ -2,7 +2,7 @@
 ops under the SAME model code, vs the golden fixture."""
 import os, sys, types
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import hplflownet_amd as H
 from hplflownet_amd import ops

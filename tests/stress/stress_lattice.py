@@ -2,12 +2,12 @@
 """GPU box: randomised stress of the device lattice against the C oracle -- many sizes (1 .. 60 000 points,
 ragged pairs), distributions (uniform frustum, surface patches, tight clusters, duplicated points, lines,
 huge / tiny coordinates) and scale maps; every table of every level must match bit for bit.
-    python tools/stress_lattice.py [--cases 200] [--seed 0]
+    python tests/stress/stress_lattice.py [--cases 200] [--seed 0]
 """
 import argparse, os, sys, time, types
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import hplflownet_amd as H
 from hplflownet_amd.synthetic import SCALES_FILTER_MAP

@@ -3,7 +3,7 @@
 uniform frustum of the benchmark): lattice sizes, device lattice == oracle, forward time, EPE vs oracle."""
 import os, sys, time, types
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import hplflownet_amd as H
 from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_
