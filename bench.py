@@ -154,24 +154,32 @@ def needed_slice_fraction(tbl, C, BM=64, BK=32):
     return float(need.float().mean().item())
 
 
-def cpu_baseline(pc1, pc2, sf, sfm, state_dict, shallow=False):
-    """The CPU oracle on one pair of the same workload; returns (dict, flow)."""
+def cpu_baseline(samples, sfm, state_dict, shallow=False):
+    """The CPU oracle on a bounded sample of the same workload (`samples`: [(pc1, pc2, sf)], about 10-30 s of CPU
+    work); returns (dict, flow of the first pair, its EPE3D)."""
     from oracle import bcl_oracle, lattice_oracle
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
     except Exception:
         threads = os.cpu_count()
-    t0 = time.time()
-    gd = lattice_oracle.generate_data(pc1, pc2, sfm)
-    t1 = time.time()
-    flow = bcl_oracle.hplflownet_forward(state_dict, pc1.T, pc2.T, gd, shallow=shallow)
-    t2 = time.time()
-    d = {'value': 1.0 / (t2 - t0), 'unit': 'point-pairs/s', 'cores': int(threads), 'kind': 'port',
-         'sample': '1 pair, N=%d, %d-level lattice build (C oracle, 1 thread) + %s forward '
-                   '(numpy oracle, BLAS threads = cores)' % (pc1.shape[0], len(sfm), 'HPLFlowNetShallow' if shallow else 'full HPLFlowNet'),
-         'lattice_s': t1 - t0, 'forward_s': t2 - t1, 'host_cpus': os.cpu_count()}
-    return d, flow, bcl_oracle.epe3d(flow, sf.T)
+    t_lat = t_fwd = 0.0
+    flow0 = None
+    for pc1, pc2, _ in samples:
+        t0 = time.time()
+        gd = lattice_oracle.generate_data(pc1, pc2, sfm)
+        t1 = time.time()
+        flow = bcl_oracle.hplflownet_forward(state_dict, pc1.T, pc2.T, gd, shallow=shallow)
+        t2 = time.time()
+        t_lat, t_fwd = t_lat + (t1 - t0), t_fwd + (t2 - t1)
+        flow0 = flow if flow0 is None else flow0
+    n = len(samples)
+    d = {'value': n / (t_lat + t_fwd), 'unit': 'point-pairs/s', 'cores': int(threads), 'kind': 'port',
+         'sample': '%d pairs, N=%d, %d-level lattice build (C oracle, 1 thread) + %s forward '
+                   '(numpy oracle, BLAS threads = cores)' % (n, samples[0][0].shape[0], len(sfm),
+                                                             'HPLFlowNetShallow' if shallow else 'full HPLFlowNet'),
+         'lattice_s': t_lat / n, 'forward_s': t_fwd / n, 'host_cpus': os.cpu_count()}
+    return d, flow0, bcl_oracle.epe3d(flow0, samples[0][2].T)
 
 
 def main():
@@ -439,7 +447,7 @@ def main():
                 'pipelined_output_check': pipe_check}
         if world == 1 and not a.no_cpu_baseline and not a.train:
             p1, p2, sf = pairs_np[0]
-            base, flow_cpu, epe_cpu = cpu_baseline(p1, p2, sf, sfm, state, shallow=not full)
+            base, flow_cpu, epe_cpu = cpu_baseline(pairs_np[:2], sfm, state, shallow=not full)
             with torch.no_grad():
                 y0 = step(0)
             flow_gpu = y0[0].cpu().numpy()
