@@ -211,6 +211,10 @@ def main():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if world > 1:
+        # N ranks share the node's cores: the host side of a step is one Python thread per rank, keep the
+        # CPU thread pools (torch intra-op, BLAS) from claiming every core N times over
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
     from hplflownet_amd import parallel
     parallel.init_distributed(backend='nccl', device=dev)      # RCCL; inference uses it for barrier/max only
     if a.gpus != world and rank == 0 and world > 1:
