@@ -10,8 +10,8 @@ required by BASELINE config 4.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce pushes 2*(7/8)*77.2 MB
 through one link per GPU (~0.9 ms), far below a training step, so gradients are reduced in a few
-large flat buckets (default 32 MB -> 3 collectives) launched as soon as backward has finished,
-rather than many small per-tensor calls.
+large flat buckets (default 32 MB -> 3 collectives) rather than many small per-tensor calls; a bucket's
+all-reduce starts from a gradient hook as soon as its last gradient exists, under the rest of backward.
 """
 import os
 
@@ -57,13 +57,19 @@ def barrier():
 
 
 class GradAllReducer(object):
-    """Bucketed flat all-reduce (mean) of parameter gradients.
+    """Bucketed flat all-reduce (mean) of parameter gradients, overlapped with the backward pass.
 
-    Parameters are packed in reverse registration order (the order backward produces them) into
-    flat buckets of at most `bucket_bytes`; each bucket is one asynchronous all-reduce.  Missing
-    gradients count as zeros so that all ranks issue identical collectives."""
+    Parameters are packed in reverse registration order (the order backward produces them) into flat
+    buckets of at most `bucket_bytes`.  With `overlap` every parameter carries a post-accumulate hook;
+    the bucket whose last gradient has just been accumulated is packed (one multi-tensor copy) and its
+    asynchronous all-reduce starts while backward is still computing the earlier layers.  Calling the
+    reducer after `backward()` launches whatever is left (buckets holding parameters that received no
+    gradient: those count as zeros, so all ranks issue identical collectives in identical order), waits,
+    divides by the world size and writes the means back into `.grad`.  Buckets always go out in index
+    order -- a bucket that completes early waits for its predecessors -- so ranks cannot interleave them
+    differently."""
 
-    def __init__(self, params, bucket_bytes=32 << 20):
+    def __init__(self, params, bucket_bytes=32 << 20, overlap=True):
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []
         cur, size = [], 0
@@ -77,37 +83,67 @@ class GradAllReducer(object):
         if cur:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
+        self._views = [None] * len(self.buckets)
+        self._ready = [0] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._next = 0                                  # first bucket not launched yet
+        self._bucket_of = {}
+        self.overlap = bool(overlap) and hasattr(torch.Tensor, 'register_post_accumulate_grad_hook')
+        if self.overlap:
+            for b, bucket in enumerate(self.buckets):
+                for p in bucket:
+                    self._bucket_of[id(p)] = b
+                    p.register_post_accumulate_grad_hook(self._on_grad)
+
+    @staticmethod
+    def _active():
+        return dist.is_initialized() and dist.get_world_size() > 1
+
+    def _on_grad(self, p):
+        if not self._active():
+            return
+        b = self._bucket_of[id(p)]
+        self._ready[b] += 1
+        while self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next]):
+            self._launch(self._next)
+
+    def _launch(self, b):
+        bucket = self.buckets[b]
+        flat = self._flat[b]
+        if flat is None or flat.device != bucket[0].device:
+            n = sum(p.numel() for p in bucket)
+            flat = self._flat[b] = torch.empty(n, dtype=bucket[0].dtype, device=bucket[0].device)
+            views, o = [], 0
+            for p in bucket:
+                views.append(flat[o:o + p.numel()].view(p.shape))
+                o += p.numel()
+            self._views[b] = views
+        have = [(v, p.grad) for v, p in zip(self._views[b], bucket) if p.grad is not None]
+        if len(have) < len(bucket):
+            flat.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._next = b + 1
 
     def __call__(self):
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not self._active():
             return
+        while self._next < len(self.buckets):           # no overlap, or parameters without a gradient
+            self._launch(self._next)
         world = dist.get_world_size()
-        work = []
-        for i, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
-            flat = self._flat[i]
-            if flat is None or flat.device != bucket[0].device:
-                flat = self._flat[i] = torch.empty(n, dtype=bucket[0].dtype, device=bucket[0].device)
-            o = 0
-            for p in bucket:
-                k = p.numel()
-                if p.grad is None:
-                    flat[o:o + k].zero_()
-                else:
-                    flat[o:o + k].copy_(p.grad.reshape(-1))
-                o += k
-            work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
-        for w, flat, bucket in work:
-            w.wait()
-            flat.div_(world)
-            o = 0
-            for p in bucket:
-                k = p.numel()
-                if p.grad is None:
-                    p.grad = flat[o:o + k].reshape(p.shape).clone()
-                else:
-                    p.grad.copy_(flat[o:o + k].reshape(p.shape))
-                o += k
+        for b, bucket in enumerate(self.buckets):
+            self._work[b].wait()
+            self._flat[b].div_(world)
+            missing = [(p, v) for p, v in zip(bucket, self._views[b]) if p.grad is None]
+            have = [(p.grad, v) for p, v in zip(bucket, self._views[b]) if p.grad is not None]
+            if have:
+                torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
+            for p, v in missing:
+                p.grad = v.clone()
+            self._work[b] = None
+            self._ready[b] = 0
+        self._next = 0
 
 
 def broadcast_parameters(module, src=0):

@@ -42,14 +42,40 @@ def _worker(rank, world, port, out_dir):
     model = _make_model(seed=rank)                 # deliberately different per rank ...
     P.broadcast_parameters(model, src=0)           # ... until broadcast
     red = P.GradAllReducer(model.parameters(), bucket_bytes=1024)   # small buckets -> several collectives
-    assert len(red.buckets) > 1
+    assert len(red.buckets) > 1 and red.overlap
     x, t = _sample(seeds[0])
     loss = torch.norm(model(x) - t, p=2, dim=1).mean()
     loss.backward()
+    launched_in_backward = red._next                # buckets whose all-reduce started from the gradient hooks
+    red()
+    # the same step without overlap (everything launched after backward) and with a parameter that gets no
+    # gradient on this rank only (counts as zeros; collectives stay aligned): identical means
+    twin = _make_model(seed=rank)
+    twin.load_state_dict(model.state_dict())
+    extra = torch.nn.Parameter(torch.ones(5))
+    red2 = P.GradAllReducer(list(twin.parameters()) + [extra], bucket_bytes=1024, overlap=False)
+    lt = torch.norm(twin(x) - t, p=2, dim=1).mean() + (extra.sum() * 0.5 if rank == 0 else 0.0)
+    lt.backward()
+    red2()
+    same = all(torch.equal(a.grad, b.grad) for a, b in zip(model.parameters(), twin.parameters()))
+    # second step through the hooks: counters were reset
+    for q in model.parameters():
+        q.grad = None
+    x2, t2 = _sample(seeds[1])
+    torch.norm(model(x2) - t2, p=2, dim=1).mean().backward()
+    second_launched = red._next
+    red()
+    grads2 = [q.grad.clone() for q in model.parameters()]
+    for q in model.parameters():
+        q.grad = None
+    x, t = _sample(seeds[0])
+    torch.norm(model(x) - t, p=2, dim=1).mean().backward()
     red()
     P.barrier()
     tmax = P.max_over_ranks(1.0 + rank)
-    torch.save({'seeds': seeds, 'grads': [p.grad.clone() for p in model.parameters()],
+    torch.save({'seeds': seeds, 'grads': [p.grad.clone() for p in model.parameters()], 'same': same,
+                'extra': extra.grad.clone(), 'launched': (launched_in_backward, second_launched, len(red.buckets)),
+                'grads2': grads2,
                 'params': [p.detach().clone() for p in model.parameters()], 'tmax': tmax},
                os.path.join(out_dir, 'r%d.pt' % rank))
     torch.distributed.destroy_process_group()
@@ -66,6 +92,12 @@ def test_two_rank_gloo():
         assert torch.equal(a, b)                                                     # broadcast
     for a, b in zip(res[0]['grads'], res[1]['grads']):
         assert torch.equal(a, b)                                                     # identical after all-reduce
+    for r in res:
+        assert r['same']                                                             # overlap == no overlap
+        assert torch.equal(r['extra'], torch.full((5,), 0.25))                      # (0.5 + missing -> 0) / 2
+        assert r['launched'][0] == r['launched'][1] == r['launched'][2]              # all started inside backward
+    for a, b in zip(res[0]['grads2'], res[1]['grads2']):
+        assert torch.equal(a, b)
     # reference: one process, mean of the two per-sample losses
     model = _make_model(seed=0)
     loss = sum(torch.norm(model(_sample(s)[0]) - _sample(s)[1], p=2, dim=1).mean() for s in (0, 1)) / 2
