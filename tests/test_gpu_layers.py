@@ -1,7 +1,6 @@
 """GPU: the drop-in layers, the models and the device lattice against the reference-generated
 golden vectors (tests/golden) and the CPU oracle.  These tests read like the reference would
 test itself: same constructors, same forward calls, (1, C, N) tensors, int64 index tensors."""
-import json
 import os
 import types
 

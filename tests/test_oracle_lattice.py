@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from common import GOLD, INT_KEYS, ROOT, load_golden_lattice, oracle_lattice, sha
+from common import GOLD, ROOT, load_golden_lattice, oracle_lattice, sha
 from hplflownet_amd.synthetic import SCALES_FILTER_MAP, synthetic_pair
 from oracle import lattice_oracle as LO
 

@@ -2,7 +2,7 @@
 """GPU micro-benchmark of the gather-GEMM on the Up-BCL shapes of the full model at N=8192
 (real level tables from the device lattice).  Prints TFLOP/s per shape."""
 import os, sys, types
-import numpy as np, torch
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import hplflownet_amd as H

@@ -32,7 +32,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
 from ref_import import import_reference  # noqa: E402
-from hplflownet_amd.synthetic import (MODEL_GAIN, SCALES_FILTER_MAP, closed_form_fill,  # noqa: E402
+from hplflownet_amd.synthetic import (SCALES_FILTER_MAP, closed_form_fill,  # noqa: E402
                                       fill_module_, subsample, synthetic_pair)
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
