@@ -129,7 +129,9 @@ class NbrTable(object):
 
     #: number of tap groups of the multi-pass contraction (ops.gconv tap_groups); env for A/B runs
     TAP_GROUPS = int(os.environ.get('HPL_TAP_GROUPS', '2'))      # swept 1 / 2 / 3 / 5 end to end: 193 / 205 / 204 / 173 pairs/s
-    GROUPS_MIN_SPARSITY = 2.0
+    #: levels with at least this many lattice vertices per input point get the passes (level 0: 3.2, level 1:
+    #: 1.34 -- bcn1_ and bcn2_; measured end to end 2.0 -> 1.2: 212.5 -> 218.5 pairs/s)
+    GROUPS_MIN_SPARSITY = float(os.environ.get('HPL_GROUPS_MIN_SPARSITY', '1.2'))
 
     def groups(self):
         """[(f0, f1, perm)] for TAP_GROUPS groups of consecutive taps, each with its own row order

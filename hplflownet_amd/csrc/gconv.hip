@@ -61,6 +61,8 @@ struct GParams {
     int64_t a_bytes; int64_t w_bytes;   // extents of A and Wt for the buffer descriptors
     const int32_t *row_perm;            // optional permutation of the output rows (tile row -> vertex)
     int perm_chunk;                     // tile-rows per XCD chunk in permuted launches
+    int col_share;                      // > 0: column-major XCD order, XCDs per column tile (see tile_coords)
+    int col_rows;                       // tile-rows per virtual column in that order
     int splits; float *partial;         // split-K over the slice list: partial[split][M][N]
     float *ws; int64_t ws_bytes;
 };
@@ -81,6 +83,21 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
     const int q = nwg / 8, r = nwg % 8;
     const int xcd = bid % 8, pos = bid / 8;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // bijective
+    if (p.row_perm && p.col_share > 0) {
+        // Column-major order: an XCD works through ONE column tile at a time (its weight panel stays in that
+        // L2), heaviest tile-rows first.  Column tiles shared by col_share XCDs deal their tile-rows round
+        // robin.  The grid is rounded up to 8 equal runs; surplus workgroups get tm = -1.
+        const int gsz = p.tiles_n * p.col_share * p.col_rows;
+        const int q2 = gsz / 8, r2 = gsz % 8;
+        const int b2 = blockIdx.x;
+        const int x2 = b2 % 8, pos2 = b2 / 8;
+        const int id2 = (x2 < r2 ? x2 * (q2 + 1) : r2 * (q2 + 1) + (x2 - r2) * q2) + pos2;
+        const int v = id2 / p.col_rows, pos = id2 - v * p.col_rows;
+        tn = v / p.col_share;
+        const int row = pos * p.col_share + (v - tn * p.col_share);
+        tm = row < p.tiles_m ? p.tiles_m - 1 - row : -1;
+        return;
+    }
     if (p.row_perm) {
         // Rows are sorted by tap mask: tile-rows differ in work (few taps ... all taps) and have no
         // spatial coherence.  Tile-rows are dealt to the 8 XCDs in chunks of PERM_CHUNK consecutive
@@ -154,6 +171,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
 
     int tile_m, tile_n;
     tile_coords(p, tile_m, tile_n);
+    if (tile_m < 0) return;             // surplus workgroup of a rounded-up grid (uniform: no barrier passed yet)
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -334,7 +352,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     __syncthreads();
     const int nlist = __builtin_amdgcn_readfirstlane(tapmask_s[1]);
     // split-K (small M): this workgroup handles slices [lo, hi) of the list and writes a partial tile
-    const int split = blockIdx.x / (p.tiles_m * p.tiles_n);
+    const int split = p.splits > 1 ? blockIdx.x / (p.tiles_m * p.tiles_n) : 0;    // (a rounded-up grid has splits == 1)
     const int lo = (int)((int64_t)nlist * split / p.splits), hi_i = (int)((int64_t)nlist * (split + 1) / p.splits);
     const int nsl = hi_i - lo;        // slices of this workgroup: list entries lo .. hi_i-1
     if (nsl > 0) {
@@ -551,6 +569,7 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
         if (p.perm_chunk < 1) p.perm_chunk = 1;
     }
     p.ws = d->ws; p.ws_bytes = d->ws ? d->ws_bytes : 0; p.splits = 1; p.partial = nullptr;
+    p.col_share = 0; p.col_rows = 0;
     p.tiles_m = p.tiles_n = 0;
     p.a_bytes = ((d->rows_a - 1) * d->lda + d->C) * 4;
     const int64_t w_rows = d->w_rows ? (int64_t)d->w_rows : cdiv(p.K, 32) * 32;
@@ -577,7 +596,14 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
         p.splits = sp;
         p.partial = p.ws;
     }
-    const int grid = tiles * p.splits;
+    int grid = tiles * p.splits;
+    p.col_share = 0; p.col_rows = 0;
+    static const int col_order = getenv("HPL_TILE_ORDER") ? atoi(getenv("HPL_TILE_ORDER")) : 1;
+    if (col_order && p.row_perm && p.splits == 1 && (p.tiles_n % 8 == 0 || 8 % p.tiles_n == 0)) {
+        p.col_share = p.tiles_n >= 8 ? 1 : 8 / p.tiles_n;
+        p.col_rows = (int)cdiv(p.tiles_m, p.col_share);
+        grid = p.tiles_n * p.col_share * p.col_rows;
+    }
     // F_LDS = taps whose indices are staged in LDS: 1 for dense GEMMs, 15 for the radius-1 stencil
     if (p.F == 1) {
         if (avec) k_gconv<BM, BN, WGM, WGN, true, 1><<<grid, 64 * WGM * WGN, 0, s>>>(p);
