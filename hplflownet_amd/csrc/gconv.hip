@@ -599,8 +599,13 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
     int grid = tiles * p.splits;
     p.col_share = 0; p.col_rows = 0;
     static const int col_order = getenv("HPL_TILE_ORDER") ? atoi(getenv("HPL_TILE_ORDER")) : 1;
-    if (col_order && p.row_perm && p.splits == 1 && (p.tiles_n % 8 == 0 || 8 % p.tiles_n == 0)) {
-        p.col_share = p.tiles_n >= 8 ? 1 : 8 / p.tiles_n;
+    if (col_order && p.row_perm && p.splits == 1) {
+        // every column tile is cut into 8 / gcd(8, tiles_n) interleaved runs of tile-rows, so that the runs
+        // divide evenly among the 8 XCDs (tiles_n = 8: one whole column per XCD; 4: two XCDs per column;
+        // 5: 40 runs, five per XCD, each XCD inside at most two columns)
+        int g = 8, b = p.tiles_n % 8;
+        while (b) { const int t = g % b; g = b; b = t; }
+        p.col_share = 8 / g;
         p.col_rows = (int)cdiv(p.tiles_m, p.col_share);
         grid = p.tiles_n * p.col_share * p.col_rows;
     }
