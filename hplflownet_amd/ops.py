@@ -433,11 +433,18 @@ def _train_relayout(weight, R, Q, F, sr, sq, sf, base=0, mirror=False):
     return weight_relayout(weight, R, Q, F, sr, sq, sf, base=base, fmap=fmap)
 
 
+MAX_TAPS_PER_PASS = 15      # hpl_gconv_forward: F <= 15 (LDS-staged index table of a tile)
+
+
 def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
                  slope=LEAKY_RATE, row_perm=None):
     """gconv_raw, run as one pass per tap group when `groups` = [(f0, f1, perm), ...] is given: pass i
     contracts taps [f0, f1) (rows f0*C.. of Wt, rows f0.. of the table) in its own row order and adds
     to the output of the passes before it; bias / residual enter the first pass, the activation the last."""
+    if not groups and nbr is not None and F > MAX_TAPS_PER_PASS:
+        # radius-2 stencils (65 taps): the kernel stages the indices of at most 15 taps per tile, so the
+        # contraction runs as ceil(F / 15) accumulating passes over consecutive tap ranges
+        groups = [(f0, min(F, f0 + MAX_TAPS_PER_PASS), None) for f0 in range(0, F, MAX_TAPS_PER_PASS)]
     if not groups or nbr is None or len(groups) < 2:
         return gconv_raw(A, nbr, M, C, F, Wt, N, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope,
                          row_perm=row_perm)

@@ -435,3 +435,72 @@ def test_lattice_pipeline_equals_blocking_build(depth, training):
     while not b.advance():
         steps += 1
     assert steps == len(SCALES_FILTER_MAP) and b.ready() and b.finish() is b.result
+
+
+def test_radius2_layers_vs_oracle():
+    """neighborhood_size / corr radii 2 (65 taps; the reference supports any radius, its configs use 1): the
+    contraction runs as ceil(65 / 15) accumulating passes of the same kernel.  BilateralConvFlex forward and
+    every gradient, BilateralCorrelationFlex forward, against the numpy oracle on a device-built lattice."""
+    import hplflownet_amd as H
+    from oracle import bcl_oracle as BO
+    sfm = [[2.0, 2, -1, -1], [1.0, 2, 2, 2]]
+    pc1, pc2, _ = synthetic_pair(160, 11)
+    gen = H.GenerateDataUnsymmetric(types.SimpleNamespace(dim=3, scales_filter_map=sfm), device=DEV)
+    _, _, _, lat = gen([pc1, pc2[:150], pc1])
+    gd = [{k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in d.items()} for d in H.to_reference_format(lat)]
+    g = gd[0]
+    assert g['pc1_blur_neighbors'].shape[0] == 65
+    rng = np.random.RandomState(0)
+    for cin, couts, do_splat, do_slice in ((20, [24, 16], True, True), (33, [40], False, False)):
+        m = H.BilateralConvFlex(3, 2, cin, couts, 'cuda', True, True, True, do_splat, do_slice, False, chunk_size=-1).to(DEV)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.from_numpy(rng.randn(*p.shape).astype(np.float32)) * (0.5 if p.dim() == 1 else 0.05))
+        n_in = g['pc1_barycentric'].shape[1] if do_splat else g['pc1_hash_cnt']
+        x = T(rng.randn(1, cin, n_in).astype(np.float32)).requires_grad_(True)
+        y = m(x, T(g['pc1_barycentric'])[None] if do_splat else None, T(g['pc1_lattice_offset'])[None] if do_splat else None,
+              T(g['pc1_blur_neighbors'])[None], T(g['pc1_barycentric'])[None] if do_slice else None,
+              T(g['pc1_lattice_offset'])[None] if do_slice else None)
+        convs = []
+        for mod in m.blur_conv:
+            conv = mod.conv if hasattr(mod, 'conv') else mod
+            W = conv.weight.detach().cpu().numpy()
+            convs.append((W.reshape(W.shape[0], W.shape[1], -1), conv.bias.detach().cpu().numpy()))
+        bias = m.bias.detach().cpu().numpy() if do_slice else None
+        yo, cache = BO.bilateral_conv_forward(x.detach().cpu().numpy()[0], convs, bias, g['pc1_barycentric'],
+                                              g['pc1_lattice_offset'], g['pc1_blur_neighbors'], g['pc1_barycentric'],
+                                              g['pc1_lattice_offset'], do_splat, do_slice)
+        assert rel_err(y.detach().cpu().numpy()[0], yo) < 1e-5
+        go = T(rng.randn(*y.shape).astype(np.float32))
+        (y * go).sum().backward()
+        gr = BO.bilateral_conv_backward(go.cpu().numpy()[0], cache, x.detach().cpu().numpy()[0], convs, bias,
+                                        g['pc1_barycentric'], g['pc1_lattice_offset'], g['pc1_blur_neighbors'],
+                                        g['pc1_barycentric'], g['pc1_lattice_offset'], do_splat, do_slice)
+        assert rel_err(x.grad.cpu().numpy()[0], gr['features']) < 1e-4
+        for mod, (gW, gb) in zip(m.blur_conv, gr['convs']):
+            conv = mod.conv if hasattr(mod, 'conv') else mod
+            assert rel_err(conv.weight.grad.cpu().numpy().reshape(gW.shape), gW) < 1e-4
+            assert rel_err(conv.bias.grad.cpu().numpy(), gb) < 1e-4
+    # correlation layer with 65 x 65 patch taps on the second level
+    g = gd[1]
+    H1, H2 = g['pc1_hash_cnt'], g['pc2_hash_cnt']
+    assert g['pc2_corr_indices'].shape[:2] == (65, 65)
+    mc = H.BilateralCorrelationFlex(3, 2, 2, 8, [8, 8], [16, 16], 'cuda', True, True, True, 0, False, chunk_size=-1).to(DEV)
+    with torch.no_grad():
+        for p in mc.parameters():
+            p.copy_(torch.from_numpy(rng.randn(*p.shape).astype(np.float32)) * (0.5 if p.dim() == 1 else 0.05))
+    f1, f2 = T(rng.randn(1, 8, H1).astype(np.float32)), T(rng.randn(1, 8, H2).astype(np.float32))
+    with torch.no_grad():
+        yc = mc(f1, f2, None, None, None, T(g['pc1_corr_indices'])[None], T(g['pc2_corr_indices'])[None], H1, H2)
+    cc = []
+    for mod in mc.corr_conv:
+        W = mod.conv.weight.detach().cpu().numpy()
+        cc.append((W.reshape(W.shape[0], W.shape[1], -1), mod.conv.bias.detach().cpu().numpy()))
+    bc = []
+    for mod in mc.blur_conv:
+        conv = mod.conv if hasattr(mod, 'conv') else mod
+        W = conv.weight.detach().cpu().numpy()
+        bc.append((W.reshape(W.shape[0], W.shape[1], -1), conv.bias.detach().cpu().numpy()))
+    yco = BO.bilateral_corr_forward(f1.cpu().numpy()[0], f2.cpu().numpy()[0], None, g['pc1_barycentric'],
+                                    g['pc1_lattice_offset'], g['pc1_corr_indices'], g['pc2_corr_indices'], cc, bc)
+    assert rel_err(yc.cpu().numpy()[0], yco) < 1e-5
