@@ -144,7 +144,9 @@ typedef struct hpl_gconv_desc {
                                (F == 1, reg_stride == 0 is a plain GEMM) */
     int64_t M;              /* output rows (lattice vertices, or F*H virtual vertices) */
     int32_t C;              /* channels taken from each gathered row */
-    int32_t F;              /* filter taps; contraction length K = F * C */
+    int32_t F;              /* filter taps, <= 15 per call (radius 1); contraction length K = F * C <= 32768.
+                             * Wider stencils (radius 2: 65 taps) = consecutive calls over tap ranges, each a row
+                             * range of nbr and of Wt (w_rows), accumulating through res = Y */
     /* B operand: re-laid-out weights (hpl_weight_relayout) */
     const float *Wt;        /* [>= roundup(F*C, 32)][ldw], zero padded */
     int64_t ldw;            /* multiple of 4, >= N */
