@@ -200,6 +200,9 @@ def main():
                          'read-back of vertex counts)')
     ap.add_argument('--arch', default='HPLFlowNet', choices=['HPLFlowNet', 'HPLFlowNetShallow'],
                     help='HPLFlowNetShallow + --points 4096 is BASELINE config 2')
+    ap.add_argument('--data', default='frustum', choices=['frustum', 'surface'],
+                    help='frustum: the uniform FT3D-like frustum of SURVEY.md 8(d1) (the headline workload); surface: points on '
+                         'smooth patches, the dense extreme (few lattice vertices per point)')
     ap.add_argument('--train', action='store_true',
                     help='time a training step (fwd + bwd + gradient all-reduce + Adam) instead of inference')
     a = ap.parse_args()
@@ -222,7 +225,7 @@ def main():
 
     import hplflownet_amd as H
     from hplflownet_amd import ops
-    from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_, synthetic_pair
+    from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_, surface_pair, synthetic_pair
 
     full = a.arch == 'HPLFlowNet'
     sfm = SCALES_FILTER_MAP if full else SCALES_FILTER_MAP[:5]
@@ -234,7 +237,8 @@ def main():
     model = model.to(dev).eval()
     gen = H.GenerateDataUnsymmetric(margs, device=dev)
 
-    pairs_np = [synthetic_pair(a.points, s) for s in parallel.sample_seeds(rank, world, a.pool)]
+    make_pair = surface_pair if a.data == 'surface' else synthetic_pair
+    pairs_np = [make_pair(a.points, s) for s in parallel.sample_seeds(rank, world, a.pool)]
     pairs = [(torch.from_numpy(p1.T.copy()).to(dev), torch.from_numpy(p2.T.copy()).to(dev)) for p1, p2, _ in pairs_np]
     fixed_lat = [gen.build(p1, p2) for p1, p2 in pairs] if a.no_lattice else None
     timers = KernelTimers(ops)
@@ -437,9 +441,9 @@ def main():
         line = {'metric': 'point-pairs/sec + EPE3D, N=8192 FlyingThings3D, 1/2/4/8 MI355X',
                 'value': world * a.steps / elapsed, 'unit': 'point-pairs/s', 'n_gpus': world, 'steps': a.steps,
                 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
-                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if a.data == 'frustum' else 'synthetic (surface patches)',
                 'config': {'workload': ('full HPLFlowNet %s (7 levels, 19.3M params, random init), ' if full else 'HPLFlowNetShallow %s (5 levels, random init), ') % ('training step (fwd+bwd+grad all-reduce+Adam)' if a.train else 'inference') +
-                                       'FT3D-like synthetic pair, N=%d, bs=1 per GPU' % a.points,
+                                       ('FT3D-like synthetic pair' if a.data == 'frustum' else 'synthetic pair of surface patches') + ', N=%d, bs=1 per GPU' % a.points,
                            'num_points': a.points, 'step_includes_lattice_build': not a.no_lattice,
                            'lattice_overlapped_on_second_stream': bool(overlap),
                            'lattices_under_construction': a.lattice_depth if overlap else 1,

@@ -36,6 +36,25 @@ def synthetic_pair(num_points, seed=0):
     return pc1, pc2, sf
 
 
+def surface_pair(num_points, seed=0):
+    """A surface-like pair: points on 8 smooth patches (what depth-map data such as FlyingThings3D looks like
+    to the lattice: ~0.5 vertices per point at level 0 instead of the 3.2 of the uniform frustum above), cloud 2 =
+    cloud 1 moved rigidly + 2 cm noise.  Used by `bench.py --data surface` and tests/stress/surface_check.py to
+    show the sensitivity of the numbers to the data; not part of any fixture."""
+    rng = np.random.RandomState(seed)
+    pts = []
+    per = (num_points + 7) // 8
+    for _ in range(8):
+        c = rng.uniform([-8, -3, 5], [8, 3, 30])
+        u, v = rng.uniform(-3, 3, per), rng.uniform(-2, 2, per)
+        a, b = rng.uniform(-0.5, 0.5, 2)
+        z = c[2] + a * u + b * v + 0.3 * np.sin(u) + rng.normal(0, 0.01, per)
+        pts.append(np.stack([c[0] + u, c[1] + v, z], 1))
+    pc1 = np.concatenate(pts)[:num_points].astype(np.float32)
+    pc2 = (pc1 + np.array([0.3, 0.0, 0.2], np.float32) + rng.normal(0, 0.02, pc1.shape)).astype(np.float32)
+    return pc1, pc2, pc2 - pc1
+
+
 def closed_form_fill(name, shape):
     """Deterministic parameter values so fixtures need not ship weight blobs.
 

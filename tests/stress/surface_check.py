@@ -8,19 +8,7 @@ sys.path.insert(0, ROOT)
 import hplflownet_amd as H
 from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_
 
-def surfaces(n, seed):
-    rng = np.random.RandomState(seed)
-    pts = []
-    per = n // 8
-    for k in range(8):
-        c = rng.uniform([-8, -3, 5], [8, 3, 30])
-        u, v = rng.uniform(-3, 3, per), rng.uniform(-2, 2, per)
-        a, b = rng.uniform(-0.5, 0.5, 2)
-        z = c[2] + a * u + b * v + 0.3 * np.sin(u) + rng.normal(0, 0.01, per)
-        pts.append(np.stack([c[0] + u, c[1] + v, z], 1))
-    pc1 = np.concatenate(pts)[:n].astype(np.float32)
-    pc2 = (pc1 + np.array([0.3, 0.0, 0.2], np.float32) + rng.normal(0, 0.02, pc1.shape)).astype(np.float32)
-    return pc1, pc2, pc2 - pc1
+from hplflownet_amd.synthetic import surface_pair as surfaces
 
 dev = 'cuda'
 a = types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP, evaluate=True, use_leaky=True, bcn_use_bias=True,
