@@ -185,7 +185,7 @@ def cpu_baseline(samples, sfm, state_dict, shallow=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=8192)
     ap.add_argument('--pool', type=int, default=4, help='distinct resident pairs cycled through the steps')
