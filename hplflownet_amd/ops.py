@@ -217,53 +217,63 @@ def weight_relayout(W, R, Q, F, sr, sq, sf, base=0, fmap=None):
     return Wt
 
 
+def _mat(x, what):
+    """(data_ptr, leading dimension, rows, cols) of a channel-last 2-D float32 device matrix, validated with one
+    stride() / shape read (this sits on the host's critical path: ~100 calls per forward)."""
+    st, sh = x.stride(), x.shape
+    if len(st) != 2 or x.dtype is not torch.float32 or not x.is_cuda or (st[1] != 1 and sh[1] > 1):
+        raise _lib.HplError('%s must be a channel-last 2-D float32 device tensor with unit channel stride, '
+                            'got shape %s strides %s dtype %s device %s' % (what, tuple(sh), st, x.dtype, x.device))
+    return x.data_ptr(), (st[0] if sh[0] > 1 else max(sh[1], st[0])), sh[0], sh[1]
+
+
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
               scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True):
     """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
     row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged."""
-    A = _cl(A)
     d = GConvDesc()
-    d.A, d.lda, d.rows_a = ptr(A), _ld(A), A.shape[0]
+    d.A, d.lda, d.rows_a, a_cols = _mat(A, 'activation')
     if nbr is not None:
-        if nbr.dtype != torch.int32 or nbr.dim() != 2 or nbr.shape[0] != F or nbr.shape[1] != M or \
-                nbr.stride(1) != 1:
+        nst, nsh = nbr.stride(), nbr.shape
+        if nbr.dtype is not torch.int32 or len(nsh) != 2 or nsh[0] != F or nsh[1] != M or nst[1] != 1:
             raise _lib.HplError('neighbour table must be int32 [F=%d, M=%d] with unit column stride, got %s %s'
-                                % (F, M, tuple(nbr.shape), nbr.dtype))
-        d.nbr, d.nbr_stride = ptr(nbr), nbr.stride(0)
-    else:
-        if F != 1:
-            raise _lib.HplError('F > 1 needs a neighbour table')
-        d.nbr, d.nbr_stride = None, 0
-    d.reg_stride = 0
+                                % (F, M, tuple(nsh), nbr.dtype))
+        d.nbr, d.nbr_stride = ptr(nbr), nst[0]
+    elif F != 1:
+        raise _lib.HplError('F > 1 needs a neighbour table')
     d.M, d.C, d.F = M, C, F
-    if C > A.shape[1]:
-        raise _lib.HplError('C=%d exceeds the %d channels of A' % (C, A.shape[1]))
-    if Wt.shape[0] < F * C or Wt.shape[1] < N or not Wt.is_contiguous():
-        raise _lib.HplError('Wt %s too small for K=%d N=%d' % (tuple(Wt.shape), F * C, N))
-    d.Wt, d.ldw, d.N = ptr(Wt), Wt.shape[1], N
-    d.w_rows = min(Wt.shape[0], round_up(F * C, 32))     # rows past the image read as zero
+    if C > a_cols:
+        raise _lib.HplError('C=%d exceeds the %d channels of A' % (C, a_cols))
+    wsh = Wt.shape
+    if wsh[0] < F * C or wsh[1] < N or not Wt.is_contiguous():
+        raise _lib.HplError('Wt %s too small for K=%d N=%d' % (tuple(wsh), F * C, N))
+    d.Wt, d.ldw, d.N = ptr(Wt), wsh[1], N
+    d.w_rows = min(wsh[0], round_up(F * C, 32))     # rows past the image read as zero
     d.act, d.slope = act, slope
-    d.bias = ptr(bias)
+    if bias is not None:
+        d.bias = ptr(bias)
     if res is not None:
-        _cl(res, 'res')
-        d.res, d.ldres, d.res_mod = ptr(res), _ld(res), res_mod or res.shape[0]
+        d.res, d.ldres, rrows, _ = _mat(res, 'res')
+        d.res_mod = res_mod or rrows
     if scat is not None:
         if out is None:
             raise _lib.HplError('scatter epilogue needs a zero-initialised `out`')
         d.scat, d.scat_stride, d.scat_c = ptr(scat), scat.stride(0), scat_c
     elif out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    _cl(out, 'out')
-    d.Y, d.ldy = ptr(out), _ld(out)
+    d.Y, d.ldy, _, _ = _mat(out, 'out')
     if row_perm is not None:
-        if row_perm.dtype != torch.int32 or row_perm.numel() != M or not row_perm.is_contiguous():
+        if row_perm.dtype is not torch.int32 or row_perm.numel() != M or not row_perm.is_contiguous():
             raise _lib.HplError('row_perm must be a contiguous int32 tensor of M=%d entries' % M)
         d.row_perm = ptr(row_perm)
+    st = stream()
     if split_k and not _NO_SPLITK and scat is None and M * N <= _SPLITK_MAX_ELEMS:
-        ws = _splitk_workspace(A.device)
-        d.ws, d.ws_bytes = ptr(ws), ws.numel() * 4
-    fn = _lib.load().hpl_gconv_forward_naive if naive else _lib.load().hpl_gconv_forward
-    check(fn(ctypes.byref(d), stream()), 'hpl_gconv_forward')
+        ws = _splitk_workspace(A.device, st)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    lib = _lib.load()
+    rc = (lib.hpl_gconv_forward_naive if naive else lib.hpl_gconv_forward)(ctypes.byref(d), st)
+    if rc != 0:
+        check(rc, 'hpl_gconv_forward')
     return out
 
 
@@ -272,9 +282,9 @@ _SPLITK_WS = {}
 _NO_SPLITK = bool(os.environ.get('HPL_NO_SPLITK'))      # A/B switch for benchmarking
 
 
-def _splitk_workspace(device):
+def _splitk_workspace(device, st):
     """Per-(device, stream) scratch for split-K partial tiles: 16 splits x 1M floats = 64 MB."""
-    key = (device, stream())
+    key = (device, st)
     ws = _SPLITK_WS.get(key)
     if ws is None:
         ws = _SPLITK_WS[key] = torch.empty(16 << 20, dtype=torch.float32, device=device)
@@ -561,16 +571,15 @@ _WT_CACHE_MAX = 512
 
 
 def _cached_relayout(weight, C, O, F, Ctot, c0):
-    """Inference path: the k-major weight image only changes when the parameter does
-    (tensor identity + version counter); the entry keeps the parameter alive, so its
-    address cannot be recycled while cached."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), c0, C)
+    """Inference path: the k-major weight image only changes when the parameter does (tensor identity +
+    version counter); the entry keeps the parameter alive, so its id cannot be recycled while cached."""
+    key = (id(weight), c0, C)
     hit = _WT_CACHE.get(key)
-    if hit is not None:
-        _WT_CACHE.move_to_end(key)
+    if hit is not None and hit[2] == weight._version and hit[1] is weight and hit[3] == weight.data_ptr():
         return hit[0]
     Wt = weight_relayout(weight.detach(), C, O, F, F, Ctot * F, 1, base=c0 * F)
-    _WT_CACHE[key] = (Wt, weight)
+    _WT_CACHE[key] = (Wt, weight, weight._version, weight.data_ptr())     # (.data swaps keep id and version)
+    _WT_CACHE.move_to_end(key)
     if len(_WT_CACHE) > _WT_CACHE_MAX:
         _WT_CACHE.popitem(last=False)
     return Wt
