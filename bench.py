@@ -235,7 +235,7 @@ def main():
     fill_module_(model, 1.0, 'hash')                      # random-init weights of the named architecture
     state = {k: v.numpy().copy() for k, v in model.state_dict().items()}
     model = model.to(dev).eval()
-    gen = H.GenerateDataUnsymmetric(margs, device=dev)
+    gen = H.GenerateDataUnsymmetric(margs, device=dev, wide_up=model.lattice_hint())
 
     make_pair = surface_pair if a.data == 'surface' else synthetic_pair
     pairs_np = [make_pair(a.points, s) for s in parallel.sample_seeds(rank, world, a.pool)]

@@ -300,11 +300,12 @@ def _run_conv_stack(x, stack, table, M, F, use_leaky, out=None):
         act = ACT_LEAKY if isinstance(m, _ConvReLU) else ACT_NONE
         o = out if i == n - 1 else None
         if i == 0:
+            groups = table.groups() if conv.in_channels >= GROUPS_MIN_CHANNELS else None
             x = ops.gconv(x, conv.weight, conv.bias, table.t, M, F, act=act,
                           bwd_mode=table.bwd_mode(x.shape[0]) if torch.is_grad_enabled() else 'scatter',
                           out=o, slope=_slope(use_leaky),
-                          row_perm=table.perm, taps=table.taps if conv.in_channels >= 100 else None,
-                          tap_groups=table.groups if conv.in_channels >= GROUPS_MIN_CHANNELS else None)
+                          row_perm=table.perm if groups is None else None,     # (the passes bring their own orders)
+                          taps=table.taps if conv.in_channels >= 100 else None, tap_groups=groups)
         else:
             x = ops.gconv(x, conv.weight, conv.bias, None, M, 1, act=act, bwd_mode='dense', out=o,
                           slope=_slope(use_leaky))

@@ -122,7 +122,7 @@ class Trainer(object):
             init_weights_(self.model, init)
         self.shuffle = np.random.RandomState(seed + 7919 * rank)
         self.model.to(self.device)
-        self.gen = GenerateDataUnsymmetric(self.args, device=self.device)
+        self.gen = GenerateDataUnsymmetric(self.args, device=self.device, wide_up=self.model.lattice_hint())
         if self.device.type == 'cuda':
             ops.enable_weight_bank()          # one batched weight re-layout per training step
         self.opt = torch.optim.Adam([p for p in self.model.parameters() if p.requires_grad], lr=lr, weight_decay=0)

@@ -65,8 +65,12 @@ class DeviceLattice(object):
     reference's list of dicts (host or device tensors, with or without the B=1 dimension
     added by default_collate) or directly by hplflownet_amd.lattice on the GPU."""
 
-    def __init__(self, levels):
+    def __init__(self, levels, wide_up=None):
         self.levels = levels
+        #: hint from the consumer (model.lattice_hint()): True = every Up conv on a level with tap groups is wide
+        #: enough to run as tap-group passes (the single-pass row order of those tables is never used), False =
+        #: none is (the group orders are never used), None = unknown: prepare() builds both
+        self.wide_up = wide_up
 
     def prepare(self, for_training=False):
         """Build every lazily constructed table (CSRs, tap orders, symmetry verdicts) now, on the
@@ -92,11 +96,11 @@ class DeviceLattice(object):
                 for c in lv.clouds:
                     c.csr()
                 tables = list(lv.blur) + [lv.corr1]
+            up = lv.blur[0] if isinstance(lv.blur, PairBlur) else None
+            grouped = up is not None and self.wide_up is not False and up.groups() is not None   # multi-pass row orders
             for tbl in tables:
-                if tbl is not None:
+                if tbl is not None and not (tbl is up and grouped and self.wide_up and tbl is not lv.corr1):
                     tbl.perm
-            if isinstance(lv.blur, PairBlur):
-                lv.blur[0].groups()             # row orders of the tap groups (wide Up convs, multi-pass)
         return self
 
     def symmetry_begin(self):
@@ -257,6 +261,14 @@ class _FlowNetBase(nn.Module):
         self.conv2 = Conv1dReLU(self.HEAD_IN, 1024, use_leaky=leaky)
         self.conv3 = Conv1dReLU(1024, 512, use_leaky=leaky)
         self.conv4 = nn.Conv1d(512, 3, kernel_size=1)
+
+    def lattice_hint(self):
+        """What this model needs of a lattice's lazily built tables (DeviceLattice.wide_up)."""
+        from .bcl import GROUPS_MIN_CHANNELS
+        widths = [getattr(self, 'bcn%d_' % (L + 1)).num_input for L in range(self.NLEV)]
+        if all(w >= GROUPS_MIN_CHANNELS for w in widths[:2]):
+            return True
+        return False if all(w < GROUPS_MIN_CHANNELS for w in widths) else None
 
     # -- helpers ------------------------------------------------------------------------
     def _stack(self, x, seq, out=None):

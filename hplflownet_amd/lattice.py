@@ -32,7 +32,8 @@ def _filter_size(radius, d1=4):
 
 
 class GenerateDataUnsymmetric(object):
-    def __init__(self, args, device='cuda'):
+    def __init__(self, args, device='cuda', wide_up=None):
+        self.wide_up = wide_up          # model.lattice_hint(): which lazily built row orders the consumer uses
         self.d = args.dim
         if self.d != 3:
             raise _lib.HplError('only d = 3 is implemented (reference configs use dim: 3)')
@@ -125,7 +126,7 @@ class GenerateDataUnsymmetric(object):
                 div = float(np.float32(self.expected_std * scale))         # transforms.py:462-463
                 prev = (vk, [4 * n[0], 4 * n[1]], div)
                 n = [H[0], H[1]]
-        return DeviceLattice(levels)
+        return DeviceLattice(levels, wide_up=self.wide_up)
 
     def __call__(self, data):
         pc1, pc2, sf = data
