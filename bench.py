@@ -425,19 +425,51 @@ def main():
                                     'share the GPU' % (detail_steps, n_fwd))
         else:
             roofline['measured'] = 'HIP events around the launches inside the timed loop'
-        if full and roofline.get('achieved'):
-            roofline['achieved_executed'] = roofline['achieved'] * roofline['executed_fraction']
-            roofline['frac_executed'] = roofline['achieved_executed'] / MFMA_F32_PEAK_TFLOPS
-        roofline['note'] = ('achieved = algorithmic flops (2*H*15*C_in*C_out, what the reference multiplies) / HIP-event '
-                            'time; it can exceed the peak because slices whose taps are absent are skipped: '
-                            'executed_fraction = share of 32-wide slices executed, achieved_executed / frac_executed = '
-                            'rate on those')
+        # `achieved` / `frac` are the MFMA flops the kernel EXECUTES per launch / its launch duration: a roofline
+        # fraction (<= 1).  The algorithmic rate (2*H*15*C_in*C_out, what the reference multiplies, incl. the
+        # products with absent neighbours' zero rows that the kernel skips) is kept as *_algorithmic; it can
+        # exceed the peak.  The executed share is MEASURED when profiles/r02_mfma_pmc.json exists (rocprofv3
+        # --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 on this command, tools/pmc_mfma.py), else mirrored on the host.
+        if roofline.get('achieved'):
+            roofline['achieved_algorithmic'] = roofline['achieved']
+            roofline['frac_algorithmic'] = roofline['achieved'] / MFMA_F32_PEAK_TFLOPS
+            share, src = roofline.get('executed_fraction', 1.0), 'host mirror of the kernel\'s slice lists (bench.needed_slice_fraction)'
+            pmc = os.path.join(ROOT, 'profiles', 'r02_mfma_pmc.json')
+            if full and os.path.exists(pmc):
+                try:
+                    pj = json.load(open(pmc))
+                    alg = roofline['gflop_per_step'] / roofline['launches_per_step']        # GF per launch
+                    share = pj['dominant_executed_gflop_per_launch'] / alg
+                    src = 'rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 (profiles/r02_mfma_pmc.json: %.1f GF executed per launch)' \
+                        % pj['dominant_executed_gflop_per_launch']
+                    roofline['executed_fraction_host_mirror'] = roofline.get('executed_fraction')
+                    roofline['executed_fraction'] = share
+                except Exception:
+                    pass
+            if not full:
+                share, src = 1.0, 'no tap skipping counted for this model (algorithmic = executed)'
+            roofline['executed_source'] = src
+            roofline['achieved'] = roofline['achieved_algorithmic'] * share
+            roofline['frac'] = roofline['achieved'] / MFMA_F32_PEAK_TFLOPS
+            if 'in_loop' in roofline:
+                roofline['in_loop']['achieved_algorithmic'] = roofline['in_loop']['achieved']
+                roofline['in_loop']['achieved'] = roofline['in_loop']['achieved'] * share
+                roofline['in_loop']['frac'] = roofline['in_loop']['achieved'] / MFMA_F32_PEAK_TFLOPS
+        roofline['note'] = ('achieved / frac: executed MFMA flops per launch / HIP-event launch duration (a fraction of the '
+                            '157.3 TFLOP/s fp32-MFMA peak, <= 1); *_algorithmic: 2*H*15*C_in*C_out per launch, what the '
+                            'reference multiplies -- slices whose taps are absent for a whole tile are skipped, '
+                            'executed_fraction is the share that runs')
         prof = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(prof) and full:
             try:
                 roofline['traffic'] = json.load(open(prof)).get('k_gconv_64x128_bytes_per_launch')
             except Exception:
                 pass
+        if dominant in kernels and roofline.get('executed_fraction') is not None and kernels[dominant].get('achieved'):
+            kd = kernels[dominant]           # same convention in the per-class table: frac = executed, <= 1
+            kd['achieved_algorithmic'], kd['frac_algorithmic'] = kd['achieved'], kd['frac']
+            kd['achieved'] = kd['achieved_algorithmic'] * (roofline['executed_fraction'] if full else 1.0)
+            kd['frac'] = kd['achieved'] / kd['peak']
         line = {'metric': 'point-pairs/sec + EPE3D, N=8192 FlyingThings3D, 1/2/4/8 MI355X',
                 'value': world * a.steps / elapsed, 'unit': 'point-pairs/s', 'n_gpus': world, 'steps': a.steps,
                 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,

@@ -220,17 +220,29 @@ def corr2_table(t, like):
     return _CACHE.get('corr2', (t,), make)
 
 
-def regular_table(F, H, device):
-    """Table of the displacement filter: tap f of vertex h reads row f*H + h."""
-    key = ('reg', F, H, str(device))
-    hit = _CACHE.d.get(key)
-    if hit is None:
-        t = (torch.arange(F, device=device, dtype=torch.int32)[:, None] * H +
-             torch.arange(H, device=device, dtype=torch.int32)[None, :]).contiguous()
-        hit = (NbrTable(t), ())
-        hit[0]._sym = False
-        _CACHE.d[key] = hit
-    return hit[0]
+class RegularTable(object):
+    """The displacement filter's "table": tap f of vertex h reads row f*H + h.  Nothing is stored -- the kernels
+    compute the source row from `reg_stride` (hpl_gconv_desc.reg_stride) -- so nothing needs caching per pair;
+    the F*H source rows are distinct, so the data gradient is a plain GEMM + strided copy (bwd mode 'regular')."""
+    t = None
+    perm = None
+    symmetric = False
+
+    def __init__(self, F, H):
+        self.F, self.reg_stride = F, H
+
+    def groups(self):
+        return None
+
+    def taps(self):
+        return None
+
+    def bwd_mode(self, rows_a):
+        return 'regular'
+
+
+def regular_table(F, H, device=None):
+    return RegularTable(F, H)
 
 
 # ----------------------------------------------------------------------------- sparse_sum (a1)
@@ -305,7 +317,8 @@ def _run_conv_stack(x, stack, table, M, F, use_leaky, out=None):
                           bwd_mode=table.bwd_mode(x.shape[0]) if torch.is_grad_enabled() else 'scatter',
                           out=o, slope=_slope(use_leaky),
                           row_perm=table.perm if groups is None else None,     # (the passes bring their own orders)
-                          taps=table.taps if conv.in_channels >= 100 else None, tap_groups=groups)
+                          taps=table.taps if conv.in_channels >= 100 else None, tap_groups=groups,
+                          reg_stride=getattr(table, 'reg_stride', 0))
         else:
             x = ops.gconv(x, conv.weight, conv.bias, None, M, 1, act=act, bwd_mode='dense', out=o,
                           slope=_slope(use_leaky))

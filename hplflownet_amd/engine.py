@@ -77,12 +77,14 @@ def init_weights_(model, init_type='xavier', gain=1.0):
           'orthogonal': lambda w: torch.nn.init.orthogonal_(w, gain=gain)}
     if init_type not in fn:
         raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
-    for m in model.modules():
-        name = m.__class__.__name__
-        if hasattr(m, 'weight') and ('Conv' in name or 'Linear' in name):
-            fn[init_type](m.weight.data)
-            if getattr(m, 'bias', None) is not None:
-                m.bias.data.zero_()
+    with torch.no_grad():        # in-place through the parameter itself: bumps its version, which the cached
+        for m in model.modules():    # weight images of the inference path key on (ops.invalidate_weight_cache)
+            name = m.__class__.__name__
+            if hasattr(m, 'weight') and ('Conv' in name or 'Linear' in name):
+                fn[init_type](m.weight)
+                if getattr(m, 'bias', None) is not None:
+                    m.bias.zero_()
+    ops.invalidate_weight_cache()
     return model
 
 
@@ -170,7 +172,8 @@ class Trainer(object):
             self.opt.step()
             total += loss.detach()
         self.epoch += 1
-        return float(total) / max(1, len(order))
+        tot = parallel.sum_over_ranks([float(total), float(len(order))], device=self.device)
+        return tot[0] / max(1.0, tot[1])             # mean loss over the global batch stream (all ranks)
 
     @torch.no_grad()
     def validate(self, data):
@@ -180,7 +183,11 @@ class Trainer(object):
             flow = self.model(pc1[None], pc2[None], lat)
             for k, v in flow_metrics(flow[0].t(), sf.t()).items():
                 agg[k] = agg.get(k, 0.0) + v
-        return {k: v / max(1, len(data)) for k, v in agg.items()}
+        # every rank evaluated its own shard (shards may differ in length by one): sums and the sample count are
+        # added over the ranks, so all ranks return the metrics of the WHOLE split (and agree on `best` in fit())
+        keys = list(agg) if agg else ['EPE3D', 'Acc3DS', 'Acc3DR', 'Outliers']
+        tot = parallel.sum_over_ranks([agg.get(k, 0.0) for k in keys] + [float(len(data))], device=self.device)
+        return {k: v / max(1.0, tot[-1]) for k, v in zip(keys, tot[:-1])}
 
     # ------------------------------------------------------------------ checkpoints
     def state(self):
@@ -226,8 +233,11 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument('--arch', default='HPLFlowNet', choices=sorted(ARCHS))
     ap.add_argument('--points', type=int, default=8192)
-    ap.add_argument('--pairs', type=int, default=8, help='synthetic pairs per epoch (per rank)')
-    ap.add_argument('--val-pairs', type=int, default=2)
+    ap.add_argument('--pairs', type=int, default=None,
+                    help='pairs per epoch and rank: synthetic data default 8; real datasets default 0 = the whole '
+                         'split (a positive value caps the shard and is logged)')
+    ap.add_argument('--val-pairs', type=int, default=None,
+                    help='validation pairs per rank while training: synthetic default 2, real datasets default 0 = all')
     ap.add_argument('--epochs', type=int, default=1)
     ap.add_argument('--lr', type=float, default=1e-4)
     ap.add_argument('--ckpt-dir', default=None)
@@ -237,6 +247,10 @@ def main(argv=None):
     ap.add_argument('--data-root', default=None)
     ap.add_argument('--init', default='hash', choices=['hash', 'xavier', 'normal', 'kaiming', 'orthogonal'])
     a = ap.parse_args(argv)
+    if a.pairs is None:
+        a.pairs = 8 if a.dataset == 'synthetic' else 0
+    if a.val_pairs is None:
+        a.val_pairs = 2 if a.dataset == 'synthetic' else 0
     rank, world, local_rank = parallel.init_distributed()
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
@@ -256,11 +270,21 @@ def main(argv=None):
 
 
 class _Shard(object):
-    """Every world-th sample of a reader, starting at rank (independent pairs per GPU)."""
+    """Every world-th sample of a reader, starting at rank (independent pairs per GPU).
 
-    def __init__(self, reader, rank, world, limit=0):
+    equal=True (training): every rank gets ceil(len / world) samples, the short ranks wrapping around to the
+    start of the reader (what torch's DistributedSampler does) -- train_epoch issues one gradient all-reduce per
+    step, so ranks with different step counts would leave each other blocked in a collective.  equal=False
+    (validation: no per-step collective, sums are reduced at the end): the plain strided split, no duplicates."""
+
+    def __init__(self, reader, rank, world, limit=0, equal=False):
         self.reader = reader
-        self.ids = list(range(rank, len(reader), world))
+        n = len(reader)
+        if equal and n > 0:
+            per = (n + world - 1) // world
+            self.ids = [(rank + i * world) % n for i in range(per)]
+        else:
+            self.ids = list(range(rank, n, world))
         if limit > 0:
             self.ids = self.ids[:limit]
 
@@ -273,12 +297,15 @@ class _Shard(object):
 
 def _real_data(a, tr, dev, rank, world):
     log = print if rank == 0 else (lambda *_: None)
-    if a.dataset == 'KITTI':                        # evaluation only in the reference (configs/test_ours_KITTI.yaml)
-        val = data_mod.KITTI(data_mod.ProcessData(dict(DATA_PROCESS, NO_CORR=False), a.points, True, seed=0),
-                             a.data_root, device=dev)
+    # the published evaluation protocol (configs/test_ours_KITTI.yaml:9,36-37, test_ours_FlyingThings3D.yaml:9,35-36):
+    # NO_CORR True (the two clouds are sampled independently) and allow_less_points True -- a frame with fewer than
+    # num_points valid points is evaluated on what it has, not replaced by another frame; training
+    # (configs/train_ours.yaml:6) rejects such frames
+    if a.dataset == 'KITTI':                        # evaluation only in the reference
+        val = data_mod.KITTI(data_mod.ProcessData(DATA_PROCESS, a.points, True, seed=0), a.data_root, device=dev)
         train = None
     else:
-        val = data_mod.FlyingThings3DSubset(False, data_mod.ProcessData(DATA_PROCESS, a.points, False, seed=0),
+        val = data_mod.FlyingThings3DSubset(False, data_mod.ProcessData(DATA_PROCESS, a.points, bool(a.evaluate), seed=0),
                                             a.data_root, device=dev)
         train = None if a.evaluate else data_mod.FlyingThings3DSubset(
             True, data_mod.Augmentation(AUG_TOGETHER, AUG_PC2, DATA_PROCESS, a.points, False, seed=1 + rank),
@@ -287,12 +314,17 @@ def _real_data(a, tr, dev, rank, world):
         msg = ds.check_counts() if ds is not None else None
         if msg:
             log('warning: ' + msg)
-    val = _Shard(val, rank, world, a.val_pairs if train is not None else a.pairs)
+    cap = a.val_pairs if train is not None else a.pairs
+    if cap > 0:
+        log('note: evaluating the first %d samples of each rank\'s shard only (--%s)' % (cap, 'val-pairs' if train is not None else 'pairs'))
+    if train is not None and a.pairs > 0:
+        log('note: training on the first %d samples of each rank\'s shard only (--pairs)' % a.pairs)
+    val = _Shard(val, rank, world, cap)
     if train is None:
         res = tr.validate(val)
         log(' '.join('%s %.4f' % kv for kv in res.items()))
         return res
-    return tr.fit(_Shard(train, rank, world, a.pairs), val, a.epochs, a.ckpt_dir, log=log, shuffle=True)
+    return tr.fit(_Shard(train, rank, world, a.pairs, equal=True), val, a.epochs, a.ckpt_dir, log=log, shuffle=True)
 
 
 if __name__ == '__main__':

@@ -67,9 +67,9 @@ class DeviceLattice(object):
 
     def __init__(self, levels, wide_up=None):
         self.levels = levels
-        #: hint from the consumer (model.lattice_hint()): True = every Up conv on a level with tap groups is wide
-        #: enough to run as tap-group passes (the single-pass row order of those tables is never used), False =
-        #: none is (the group orders are never used), None = unknown: prepare() builds both
+        #: hint from the consumer (model.lattice_hint()), one entry per level (or one value for all): True = the Up
+        #: conv of that level is wide enough to run as tap-group passes (the single-pass row order of its table is
+        #: never used), False = it is not (the group orders are never used), None = unknown: prepare() builds both
         self.wide_up = wide_up
 
     def prepare(self, for_training=False):
@@ -97,9 +97,10 @@ class DeviceLattice(object):
                     c.csr()
                 tables = list(lv.blur) + [lv.corr1]
             up = lv.blur[0] if isinstance(lv.blur, PairBlur) else None
-            grouped = up is not None and self.wide_up is not False and up.groups() is not None   # multi-pass row orders
+            wide = self.wide_up[L] if isinstance(self.wide_up, (list, tuple)) else self.wide_up
+            grouped = up is not None and wide is not False and up.groups() is not None   # multi-pass row orders
             for tbl in tables:
-                if tbl is not None and not (tbl is up and grouped and self.wide_up and tbl is not lv.corr1):
+                if tbl is not None and not (tbl is up and grouped and wide and tbl is not lv.corr1):
                     tbl.perm
         return self
 
@@ -263,12 +264,10 @@ class _FlowNetBase(nn.Module):
         self.conv4 = nn.Conv1d(512, 3, kernel_size=1)
 
     def lattice_hint(self):
-        """What this model needs of a lattice's lazily built tables (DeviceLattice.wide_up)."""
+        """What this model needs of a lattice's lazily built tables (DeviceLattice.wide_up): per level, whether the
+        Up conv that gathers through the level's blur table is wide enough for the tap-group passes."""
         from .bcl import GROUPS_MIN_CHANNELS
-        widths = [getattr(self, 'bcn%d_' % (L + 1)).num_input for L in range(self.NLEV)]
-        if all(w >= GROUPS_MIN_CHANNELS for w in widths[:2]):
-            return True
-        return False if all(w < GROUPS_MIN_CHANNELS for w in widths) else None
+        return [getattr(self, 'bcn%d_' % (L + 1)).num_input >= GROUPS_MIN_CHANNELS for L in range(self.NLEV)]
 
     # -- helpers ------------------------------------------------------------------------
     def _stack(self, x, seq, out=None):

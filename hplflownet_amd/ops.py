@@ -228,9 +228,11 @@ def _mat(x, what):
 
 
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
-              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True):
+              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True, reg_stride=0):
     """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
-    row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged."""
+    row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged.
+    nbr None and reg_stride > 0: tap f of row m reads row f*reg_stride + m (no table: the displacement
+    filter of the correlation layer, whose taps are the F blocks of H1 virtual vertices)."""
     d = GConvDesc()
     d.A, d.lda, d.rows_a, a_cols = _mat(A, 'activation')
     if nbr is not None:
@@ -240,7 +242,10 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
                                 % (F, M, tuple(nsh), nbr.dtype))
         d.nbr, d.nbr_stride = ptr(nbr), nst[0]
     elif F != 1:
-        raise _lib.HplError('F > 1 needs a neighbour table')
+        if reg_stride <= 0 or (F - 1) * reg_stride + M > d.rows_a:
+            raise _lib.HplError('F > 1 needs a neighbour table or a regular stride inside A (F=%d stride=%d M=%d '
+                                'rows=%d)' % (F, reg_stride, M, d.rows_a))
+        d.reg_stride = reg_stride
     d.M, d.C, d.F = M, C, F
     if C > a_cols:
         raise _lib.HplError('C=%d exceeds the %d channels of A' % (C, a_cols))
@@ -291,7 +296,7 @@ def _splitk_workspace(device, st):
     return ws
 
 
-def wgrad_raw(A, nbr, M, C, F, dY, N, taps=None, want_bias=False):
+def wgrad_raw(A, nbr, M, C, F, dY, N, taps=None, want_bias=False, reg_stride=0):
     """-> dWt [roundup(F*C,32), roundup(N,4)] = sum_m A[nbr[f,m], c] * dY[m, n]  (and, with want_bias,
     the bias gradient sum_m dY[m, :] from the same launch).
     taps = tap_lists(nbr): sum over the present vertices of each tap only (wide layers)."""
@@ -302,7 +307,8 @@ def wgrad_raw(A, nbr, M, C, F, dY, N, taps=None, want_bias=False):
     gb = buf[kp * ldw:kp * ldw + N] if want_bias else None
     tl, tr, tp = taps if (taps is not None and nbr is not None) else (None, None, None)
     check(_lib.load().hpl_gconv_wgrad(ptr(A), _ld(A), A.shape[0], ptr(nbr), nbr.stride(0) if nbr is not None else 0,
-                                      0, M, C, F, ptr(dY), _ld(dY), N, ptr(dWt), ldw, ptr(tl), ptr(tr), ptr(tp),
+                                      reg_stride if nbr is None else 0, M, C, F, ptr(dY), _ld(dY), N, ptr(dWt), ldw,
+                                      ptr(tl), ptr(tr), ptr(tp),
                                       M if tl is not None else 0, ptr(gb), stream()),
           'hpl_gconv_wgrad')
     return (dWt, gb) if want_bias else dWt
@@ -447,23 +453,26 @@ MAX_TAPS_PER_PASS = 15      # hpl_gconv_forward: F <= 15 (LDS-staged index table
 
 
 def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
-                 slope=LEAKY_RATE, row_perm=None):
+                 slope=LEAKY_RATE, row_perm=None, reg_stride=0):
     """gconv_raw, run as one pass per tap group when `groups` = [(f0, f1, perm), ...] is given: pass i
     contracts taps [f0, f1) (rows f0*C.. of Wt, rows f0.. of the table) in its own row order and adds
     to the output of the passes before it; bias / residual enter the first pass, the activation the last."""
-    if not groups and nbr is not None and F > MAX_TAPS_PER_PASS:
+    regular = nbr is None and reg_stride > 0
+    if not groups and (nbr is not None or regular) and F > MAX_TAPS_PER_PASS:
         # radius-2 stencils (65 taps): the kernel stages the indices of at most 15 taps per tile, so the
         # contraction runs as ceil(F / 15) accumulating passes over consecutive tap ranges
         groups = [(f0, min(F, f0 + MAX_TAPS_PER_PASS), None) for f0 in range(0, F, MAX_TAPS_PER_PASS)]
-    if not groups or nbr is None or len(groups) < 2:
+    if not groups or not (nbr is not None or regular) or len(groups) < 2:
         return gconv_raw(A, nbr, M, C, F, Wt, N, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope,
-                         row_perm=row_perm)
+                         row_perm=row_perm, reg_stride=reg_stride)
     y = out
     for i, (f0, f1, perm) in enumerate(groups):
         first, last = i == 0, i == len(groups) - 1
-        y = gconv_raw(A, nbr[f0:f1], M, C, f1 - f0, Wt[f0 * C:], N, bias=bias if first else None,
+        # a tap range of a regular pattern is the same pattern over the rows from f0*reg_stride on
+        y = gconv_raw(A[f0 * reg_stride:] if regular else A, None if regular else nbr[f0:f1], M, C, f1 - f0,
+                      Wt[f0 * C:], N, bias=bias if first else None,
                       act=act if last else ACT_NONE, res=res if first else y, res_mod=res_mod if first else 0,
-                      out=y, slope=slope, row_perm=perm)
+                      out=y, slope=slope, row_perm=perm, reg_stride=reg_stride)
     return y
 
 
@@ -476,12 +485,13 @@ class GConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm=None,
-                taps=None, groups=None):
+                taps=None, groups=None, reg_stride=0):
         O = weight.shape[0]
         Ctot = weight.numel() // (O * F)
         Wt = _train_relayout(weight, C, O, F, F, Ctot * F, 1, base=c0 * F)
         Y = gconv_passes(A, nbr, M, C, F, Wt, O, groups, bias=bias, act=act, res=res, res_mod=res_mod, slope=slope,
-                         row_perm=row_perm)
+                         row_perm=row_perm, reg_stride=reg_stride)
+        ctx.reg_stride = reg_stride
         ctx.groups = groups          # the mirror backward gathers through the same table: same groups
         ctx.slope = slope
         ctx.row_perm = row_perm      # same table in the mirror backward -> same tap masks -> same order
@@ -513,8 +523,20 @@ class GConvFn(torch.autograd.Function):
                 # columns ordered (f, c): source element (o, f*C + c) = W[o, c0 + c, f]
                 Wcols = weight.view(O, Ctot, F)[:, c0:c0 + C, :].permute(0, 2, 1).reshape(O, F * C).contiguous()
                 WtS = weight_relayout(Wcols, O, F * C, 1, F * C, 1, 1)
-                gA_c = torch.zeros((rows, C), dtype=torch.float32, device=A.device)
-                gconv_raw(g, None, M, O, 1, WtS, F * C, out=gA_c, scat=nbr, scat_c=C)
+                if bwd_mode == 'regular':
+                    # source rows f*stride + m are all distinct: block f of G IS the gradient of rows
+                    # [f*stride, f*stride + M) -- a plain GEMM and one strided copy, no atomics
+                    G = gconv_raw(g, None, M, O, 1, WtS, F * C)
+                    rs = ctx.reg_stride
+                    if rs == M and rows == F * M:
+                        gA_c = G.view(M, F, C).transpose(0, 1).reshape(F * M, C)
+                    else:
+                        gA_c = torch.zeros((rows, C), dtype=torch.float32, device=A.device)
+                        for f in range(F):
+                            gA_c[f * rs:f * rs + M] = G[:, f * C:(f + 1) * C]
+                else:
+                    gA_c = torch.zeros((rows, C), dtype=torch.float32, device=A.device)
+                    gconv_raw(g, None, M, O, 1, WtS, F * C, out=gA_c, scat=nbr, scat_c=C)
             if C == A.shape[1]:
                 gA = gA_c
             else:
@@ -522,7 +544,7 @@ class GConvFn(torch.autograd.Function):
                 gA[:, :C] = gA_c
         want_gb = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dWt = wgrad_raw(A, nbr, M, C, F, g, O, taps=ctx.taps, want_bias=want_gb)
+            dWt = wgrad_raw(A, nbr, M, C, F, g, O, taps=ctx.taps, want_bias=want_gb, reg_stride=ctx.reg_stride)
             if want_gb:
                 dWt, gb = dWt
             # the un-layout writes every element of the channel range: zeros only for partial ranges
@@ -536,11 +558,11 @@ class GConvFn(torch.autograd.Function):
                 gres = g.view(M // res_mod, res_mod, O).sum(dim=0)
             else:
                 gres = g
-        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None, None, None, None
+        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None, None, None, None, None
 
 
 def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_mod=0, bwd_mode='scatter',
-          out=None, slope=LEAKY_RATE, row_perm=None, taps=None, tap_groups=None):
+          out=None, slope=LEAKY_RATE, row_perm=None, taps=None, tap_groups=None, reg_stride=0):
     """Autograd-aware gathered convolution; with grad disabled it can write into `out`.
 
     tap_groups: [(f0, f1, perm), ...] -- the contraction is run as one pass per group of
@@ -555,7 +577,7 @@ def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_
                                     (res is not None and res.requires_grad)):
         y = GConvFn.apply(A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm,
                           taps() if callable(taps) else taps,
-                          tap_groups() if callable(tap_groups) else tap_groups)
+                          tap_groups() if callable(tap_groups) else tap_groups, reg_stride)
         if out is not None:
             out.copy_(y)
             return out
@@ -563,22 +585,44 @@ def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_
     Wt = _cached_relayout(weight, C, O, F, Ctot, c0)
     groups = tap_groups() if callable(tap_groups) else tap_groups
     return gconv_passes(A, nbr, M, C, F, Wt, O, groups, bias=bias, act=act, res=res, res_mod=res_mod, out=out,
-                        slope=slope, row_perm=row_perm)
+                        slope=slope, row_perm=row_perm, reg_stride=reg_stride)
 
 
 _WT_CACHE = collections.OrderedDict()
 _WT_CACHE_MAX = 512
 
 
+def invalidate_weight_cache():
+    """Drop every cached weight image of the inference path.  The cache keys on the parameter's identity,
+    version counter and data pointer, which writes through `param.data` (`p.data.copy_(...)`, reference-style
+    `model.apply(init)` with `m.weight.data`) do NOT change: call this after editing weights that way.
+    (In-place writes through the parameter under torch.no_grad(), load_state_dict and optimiser steps bump the
+    version and need nothing.)"""
+    _WT_CACHE.clear()
+
+
 def _cached_relayout(weight, C, O, F, Ctot, c0):
     """Inference path: the k-major weight image only changes when the parameter does (tensor identity +
-    version counter); the entry keeps the parameter alive, so its id cannot be recycled while cached."""
+    version counter); the entry keeps the parameter alive, so its id cannot be recycled while cached.
+    An image is produced on one stream and may be consumed on others (bench.py alternates forwards over
+    several): the entry carries the event recorded behind its re-layout kernel, and a consumer on another
+    stream waits for it until it has been seen complete once."""
     key = (id(weight), c0, C)
     hit = _WT_CACHE.get(key)
     if hit is not None and hit[2] == weight._version and hit[1] is weight and hit[3] == weight.data_ptr():
+        ev = hit[4]
+        if ev is not None:
+            st = stream()
+            if st != hit[5]:
+                if ev.query():
+                    hit[4] = None
+                else:
+                    torch.cuda.current_stream().wait_event(ev)
         return hit[0]
     Wt = weight_relayout(weight.detach(), C, O, F, F, Ctot * F, 1, base=c0 * F)
-    _WT_CACHE[key] = (Wt, weight, weight._version, weight.data_ptr())     # (.data swaps keep id and version)
+    ev = torch.cuda.Event()
+    ev.record()
+    _WT_CACHE[key] = [Wt, weight, weight._version, weight.data_ptr(), ev, stream()]     # (.data swaps keep id and version)
     _WT_CACHE.move_to_end(key)
     if len(_WT_CACHE) > _WT_CACHE_MAX:
         _WT_CACHE.popitem(last=False)

@@ -51,6 +51,15 @@ def max_over_ranks(value, device='cpu'):
     return float(t.item())
 
 
+def sum_over_ranks(values, device='cpu'):
+    """element-wise sum of a list of python floats over all ranks (validation sums and sample counts)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
@@ -69,8 +78,11 @@ class GradAllReducer(object):
     order -- a bucket that completes early waits for its predecessors -- so ranks cannot interleave them
     differently."""
 
-    def __init__(self, params, bucket_bytes=32 << 20, overlap=True):
+    def __init__(self, params, bucket_bytes=32 << 20, overlap=True, single_rank=False):
         self.params = [p for p in params if p.requires_grad]
+        #: run the collectives in a process group of ONE rank too (a 1-GPU box exercising the RCCL path:
+        #: hooks, packing, asynchronous all-reduce, write-back); off by default -- nothing to reduce
+        self.single_rank = bool(single_rank)
         self.buckets = []
         cur, size = [], 0
         for p in reversed(self.params):
@@ -95,9 +107,8 @@ class GradAllReducer(object):
                     self._bucket_of[id(p)] = b
                     p.register_post_accumulate_grad_hook(self._on_grad)
 
-    @staticmethod
-    def _active():
-        return dist.is_initialized() and dist.get_world_size() > 1
+    def _active(self):
+        return dist.is_initialized() and (dist.get_world_size() > 1 or self.single_rank)
 
     def _on_grad(self, p):
         if not self._active():

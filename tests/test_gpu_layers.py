@@ -220,10 +220,11 @@ def test_config2_shallow_n4096_vs_oracle():
     assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
 
 
-def test_config3_full_n8192_mfma_vs_naive_and_determinism():
-    """BASELINE config 3 size: full HPLFlowNet forward at N=8192.  The numpy oracle needs minutes
-    at this size, so the check is MFMA path vs the one-thread-per-output HIP kernel (same C ABI,
-    no matrix cores), bit-determinism across two runs, and finiteness."""
+def test_full_n8192_mfma_vs_naive_kernel_and_determinism():
+    """Full HPLFlowNet forward at N=8192: the MFMA gather-GEMM against the one-thread-per-output HIP kernel
+    (same C ABI, no matrix cores, k-ordered fmaf chain), bit-determinism across two runs, finiteness.  A
+    self-consistency check of the kernel; parity with the reference / the oracle at this size is
+    tests/test_gpu_bench_size.py."""
     import hplflownet_amd as H
     from hplflownet_amd import ops
     n = 8192

@@ -117,6 +117,33 @@ def test_map_against_reference_khash():
     L.hpl_i2i_destroy(None)                      # NULL-safe like khash_int2int.h:12-15
 
 
+def test_khash_names_drive_the_reference_build_unsymmetric():
+    """The oracle library exports the four functions under the names the reference's CFFI cdef binds
+    (/root/reference/models/build_khash_cffi.py:15-22): the same get / set / destroy contract through
+    `khash_int2int_*` as through `hpl_i2i_*`."""
+    so = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'liblattice_oracle.so'))
+    so.khash_int2int_init.restype = ctypes.c_void_p
+    so.khash_int2int_destroy.argtypes = [ctypes.c_void_p]
+    so.khash_int2int_get.restype = ctypes.c_int64
+    so.khash_int2int_get.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+    so.khash_int2int_set.restype = ctypes.c_int
+    so.khash_int2int_set.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+    h = so.khash_int2int_init()
+    rng = np.random.RandomState(3)
+    truth = {}
+    for k, v in zip(rng.randint(-2 ** 50, 2 ** 50, 5000).tolist(), rng.randint(0, 2 ** 31, 5000).tolist()):
+        assert so.khash_int2int_set(h, k, v) >= 0
+        truth[k] = v
+    assert so.khash_int2int_set(h, 7, 1) >= 0 and so.khash_int2int_set(h, 7, 2) >= 0      # overwrite
+    truth[7] = 2
+    for k, v in truth.items():
+        assert so.khash_int2int_get(h, k, -1) == v
+    assert so.khash_int2int_get(h, 2 ** 55 + 1, -123) == -123
+    assert so.khash_int2int_set(None, 1, 2) == -1                                          # khash_int2int.h:29
+    so.khash_int2int_destroy(h)
+    so.khash_int2int_destroy(None)                                                         # :12-15
+
+
 def test_edge_cases():
     # one point, duplicate points, and a cloud that is a single repeated point
     pc = np.array([[0.1, -0.2, 5.0]], np.float32)

@@ -15,6 +15,14 @@ files hold the reference's outputs.  Fixture ids follow SURVEY.md §8(c5):
                         stored as a flat stride-5 subsample, synthetic.subsample)
   F5 models.npz         whole-model outputs, EPE3D loss, per-parameter grad norms
   F6 state_dict.json    parameter/buffer names + shapes of both models
+  F8 models_large.npz   benchmark-size runs of the reference itself (BASELINE configs 3 and 4): full HPLFlowNet
+                        forward at N=8192 on two frustum seeds and one surface pair (flow subsample + EPE3D loss),
+                        full HPLFlowNet train-mode (chunked blur, HPLFlowNet.py:17) forward + backward at N=4096
+                        (loss, flow subsample, per-parameter gradient norms)
+  F9 train_steps.npz    three optimiser steps of the reference training loop (main.py:203-217: Adam lr 1e-4,
+                        EPE3DLoss mean) on HPLFlowNetShallow, N=256: losses, per-parameter norms after step 3,
+                        a strided sample of one weight; evaluate_3d (evaluation_utils.py:4-19) on a fixed
+                        prediction / ground-truth pair
 """
 import argparse
 import hashlib
@@ -33,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 from ref_import import import_reference  # noqa: E402
 from hplflownet_amd.synthetic import (SCALES_FILTER_MAP, closed_form_fill,  # noqa: E402
-                                      fill_module_, subsample, synthetic_pair)
+                                      fill_module_, subsample, surface_pair, synthetic_pair)
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
@@ -239,6 +247,87 @@ def main():
         if want('F6'):
             with open(os.path.join(GOLD, 'state_dict.json'), 'w') as f:
                 json.dump(manifest, f, indent=0, sort_keys=True)
+
+    # ------------------------------------------------------------------ F8: benchmark-size runs of the reference
+    if want('F8'):
+        out = {}
+
+        def ref_lattice(pc1, pc2, sf):
+            _, _, _, gd = gen7([pc1.copy(), pc2.copy(), sf.copy()])
+            return gd
+
+        for tag, (pc1, pc2, sf) in (('full_n8192_s0', synthetic_pair(8192, 0)),
+                                    ('full_n8192_s1', synthetic_pair(8192, 1)),
+                                    ('surf_n8192_s0', surface_pair(8192, 0))):
+            gd = ref_lattice(pc1, pc2, sf)
+            m = R.HPLFlowNet(model_args(7, evaluate=True))
+            fill_module_(m, 1.0, 'hash')
+            with torch.no_grad():
+                y = m(torch.from_numpy(pc1.T.copy())[None], torch.from_numpy(pc2.T.copy())[None], gd_batched(gd))
+            loss = torch.norm(y - torch.from_numpy(sf.T.copy())[None], p=2, dim=1).mean()
+            out[tag + '_flow'] = subsample(y.numpy()[0])
+            out[tag + '_loss'] = np.float64(loss.item())
+            out[tag + '_H1'] = np.array([d['pc1_hash_cnt'] for d in gd], np.int64)
+            print(tag, 'loss', loss.item(), 'H1', out[tag + '_H1'].tolist())
+        # BASELINE config 4 at half size: train mode = chunk_size 25 M (HPLFlowNet.py:17), forward + backward
+        pc1, pc2, sf = synthetic_pair(4096, 0)
+        gd = ref_lattice(pc1, pc2, sf)
+        m = R.HPLFlowNet(model_args(7, evaluate=False))
+        fill_module_(m, 1.0, 'hash')
+        m.train()
+        y = m(torch.from_numpy(pc1.T.copy())[None], torch.from_numpy(pc2.T.copy())[None], gd_batched(gd))
+        loss = torch.norm(y - torch.from_numpy(sf.T.copy())[None], p=2, dim=1).mean()
+        loss.backward()
+        tag = 'train_n4096_s0'
+        out[tag + '_flow'] = subsample(y.detach().numpy()[0])
+        out[tag + '_loss'] = np.float64(loss.item())
+        names = [k for k, _ in m.named_parameters()]
+        out[tag + '_gradnorm'] = np.array([p.grad.norm().item() for _, p in m.named_parameters()])
+        out[tag + '_gradnames'] = np.frombuffer('\n'.join(names).encode(), dtype=np.uint8)
+        print(tag, 'loss', loss.item())
+        np.savez_compressed(os.path.join(GOLD, 'models_large.npz'), **out)
+
+    # ------------------------------------------------------------------ F9: the reference's training loop + metrics
+    if want('F9'):
+        out = {}
+        pc1, pc2, sf, gd = lat[256]
+        m = R.HPLFlowNetShallow(model_args(5, evaluate=False))
+        fill_module_(m, 1.0, 'hash')
+        m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=0)             # main.py:138-140
+        p1, p2 = torch.from_numpy(pc1.T.copy())[None], torch.from_numpy(pc2.T.copy())[None]
+        tgt = torch.from_numpy(sf.T.copy())[None]
+        losses = []
+        for _ in range(3):                                                           # main.py:209-217
+            output = m(p1, p2, gd_batched(gd[:5]))
+            loss = torch.norm(output - tgt, p=2, dim=1).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        names = [k for k, _ in m.named_parameters()]
+        out['adam3_losses'] = np.array(losses, np.float64)
+        out['adam3_names'] = np.frombuffer('\n'.join(names).encode(), dtype=np.uint8)
+        out['adam3_norms'] = np.array([p.detach().double().norm().item() for _, p in m.named_parameters()])
+        out['adam3_bcn1_w'] = dict(m.named_parameters())['bcn1_.blur_conv.0.weight'].detach().numpy().reshape(-1)[::61].copy()
+        # per-parameter change against the start: what three Adam steps of lr 1e-4 did
+        start = R.HPLFlowNetShallow(model_args(5, evaluate=False))
+        fill_module_(start, 1.0, 'hash')
+        out['adam3_delta'] = np.array([(p.detach() - q.detach()).double().norm().item()
+                                       for (_, p), (_, q) in zip(m.named_parameters(), start.named_parameters())])
+        print('adam3 losses', losses)
+        # metrics: evaluation_utils.evaluate_3d uses np.float (removed in numpy >= 1.24): alias for the call
+        if not hasattr(np, 'float'):
+            np.float = float
+        import evaluation_utils as EU
+        rng = np.random.RandomState(5)
+        gt = rng.normal(0, 0.4, (1024, 3)).astype(np.float32)
+        pred = (gt + rng.normal(0, 0.08, gt.shape) * rng.uniform(0, 3, (1024, 1))).astype(np.float32)
+        out['metrics_pred'] = pred
+        out['metrics_gt'] = gt
+        out['metrics_ref'] = np.array(EU.evaluate_3d(pred, gt), np.float64)
+        print('evaluate_3d', out['metrics_ref'])
+        np.savez_compressed(os.path.join(GOLD, 'train_steps.npz'), **out)
     for fn in sorted(os.listdir(GOLD)):
         print('%-24s %8.1f KB' % (fn, os.path.getsize(os.path.join(GOLD, fn)) / 1024.))
 
