@@ -203,6 +203,8 @@ def main():
     ap.add_argument('--data', default='frustum', choices=['frustum', 'surface'],
                     help='frustum: the uniform FT3D-like frustum of SURVEY.md 8(d1) (the headline workload); surface: points on '
                          'smooth patches, the dense extreme (few lattice vertices per point)')
+    ap.add_argument('--python-forward', action='store_true',
+                    help='issue the forward launch by launch from Python instead of one native hpl_plan_run per pair')
     ap.add_argument('--train', action='store_true',
                     help='time a training step (fwd + bwd + gradient all-reduce + Adam) instead of inference')
     a = ap.parse_args()
@@ -243,6 +245,10 @@ def main():
     fixed_lat = [gen.build(p1, p2) for p1, p2 in pairs] if a.no_lattice else None
     timers = KernelTimers(ops)
     ceiling = mfma_ceiling(dev)
+    # inference runs each forward as ONE native call (hplflownet_amd.plan / csrc/executor.hip); --python-forward
+    # keeps the per-launch Python path (what round 1 measured).  Training is autograd, i.e. the Python path.
+    native = bool(model.native_forward) and not a.python_forward and not a.train
+    model.native_forward = native
 
     def step(i):
         p1, p2 = pairs[i % a.pool]
@@ -332,9 +338,11 @@ def main():
     dominant = DOMINANT
     if not full:
         timers.enabled, timers.only = True, None
+        model.native_forward = False         # the per-launch HIP events wrap the Python ops
         with torch.set_grad_enabled(a.train):
             step(0)
         torch.cuda.synchronize()
+        model.native_forward = native
         timers.enabled = False
         pre = {k: v for k, v in timers.summary(1).items() if k.startswith('gconv')}
         dominant = max(pre, key=lambda k: pre[k]['ms_per_step'])
@@ -353,6 +361,10 @@ def main():
         timers.enabled = True
         timers.only = {dominant}
         host = dict.fromkeys(host, 0.0)
+        plan = model.forward_plan() if native else None
+        if plan is not None:
+            from hplflownet_amd.plan import TAG_WIDE_BLUR
+            plan.profile(TAG_WIDE_BLUR)       # HIP events around the wide stencil convs, on the stream they run on
         t0 = time.perf_counter()
         if overlap:
             y = run_pipelined(PREWARM + a.warmup, a.steps)
@@ -362,6 +374,10 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         timers.enabled = False
+        native_prof = None
+        if plan is not None:
+            plan.profile(-1)
+            native_prof = plan.profile_read()
         parallel.barrier()
         elapsed = parallel.max_over_ranks(elapsed, device=dev)
 
@@ -373,16 +389,28 @@ def main():
         torch.cuda.synchronize()
         pipe_check = {'max_abs_diff': float((y - ref).abs().max()), 'max_abs': float(ref.abs().max())}
     dom = timers.summary(a.steps).get(dominant, {})
+    if native_prof is not None and native_prof[0] > 0 and full:
+        # the native run brackets exactly the launches of the dominant class (bcn1_ / bcn2_ blur convs, two
+        # tap-group passes each): the same record the Python-path timers produce
+        lat0 = gen.build(*pairs[0])
+        gf = sum(2.0 * lat0.levels[L].H[0] * 15 * c * o for L, c, o in ((0, 580, 1024), (1, 324, 512))) / 1e9
+        n_l, ms = native_prof
+        dom = {'launches_per_step': n_l / float(a.steps), 'avg_launch_us': 1e3 * ms / n_l, 'ms_per_step': ms / a.steps,
+               'bound': 'mfma', 'achieved': gf * a.steps / (ms * 1e-3) / 1e3, 'peak': MFMA_F32_PEAK_TFLOPS,
+               'unit': 'TFLOP/s', 'gflop_per_step': gf}
+        dom['frac'] = dom['achieved'] / dom['peak']
     # per-kernel detail: a separate, untimed, non-overlapped pass (an event pair around each of the
     # ~130 launches costs ~1.5 ms of host time per step, which the timed loop does not pay)
     detail_steps = min(a.steps, 10)
     timers.records = []
     timers.only = None
     timers.enabled = True
+    model.native_forward = False             # launch by launch, an event pair around each
     with torch.set_grad_enabled(a.train):
         for i in range(detail_steps):
             step(i)
     torch.cuda.synchronize()
+    model.native_forward = native
     timers.enabled = False
     kernels = timers.summary(detail_steps)
     if rank == 0:
@@ -480,6 +508,7 @@ def main():
                            'lattice_overlapped_on_second_stream': bool(overlap),
                            'lattices_under_construction': a.lattice_depth if overlap else 1,
                            'forward_streams': n_fwd if overlap else 1,
+                           'forward_issue': 'one native hpl_plan_run per pair' if native else 'python, launch by launch',
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,

@@ -38,6 +38,38 @@ class GConvDesc(ctypes.Structure):
                 ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64)]
 
 
+class Ref(ctypes.Structure):
+    """Mirror of `hpl_ref`."""
+    _fields_ = [('buf', c_i32), ('row_off_sym', c_i32), ('rows_sym', c_i32), ('col_off', c_i32), ('cols', c_i32)]
+
+
+class Buf(ctypes.Structure):
+    """Mirror of `hpl_buf`."""
+    _fields_ = [('rows_sym', c_i32), ('cols', c_i32)]
+
+
+class Weight(ctypes.Structure):
+    """Mirror of `hpl_weight`."""
+    _fields_ = [('Wt', c_vp), ('ldw', c_i64), ('rows', c_i64)]
+
+
+class Op(ctypes.Structure):
+    """Mirror of `hpl_op`."""
+    _fields_ = [('kind', c_i32), ('tag', c_i32), ('a', Ref), ('out', Ref), ('res', Ref), ('m_sym', c_i32),
+                ('res_mod_sym', c_i32), ('level', c_i32), ('table', c_i32), ('order', c_i32), ('F', c_i32), ('C', c_i32),
+                ('N', c_i32), ('weight', c_i32), ('bias', c_i32), ('act', c_i32), ('slope', c_f32), ('use_norm', c_i32),
+                ('reg_stride_sym', c_i32), ('ext', c_i32), ('cond', c_i32), ('cond_level', c_i32)]
+
+
+class LevelTables(ctypes.Structure):
+    """Mirror of `hpl_level_tables`."""
+    _fields_ = [('n0', c_i64), ('n1', c_i64), ('H0', c_i64), ('H1', c_i64), ('emg_pair', c_vp),
+                ('csr_ptr', c_vp), ('csr_pt', c_vp), ('csr_w', c_vp), ('csr_norm', c_vp), ('bary0', c_vp), ('off0', c_vp),
+                ('blur', c_vp), ('blur_stride', c_i64), ('blur_perm', c_vp), ('up_perm', c_vp), ('n_up_groups', c_i32),
+                ('up_group_cut', c_i32 * 5), ('up_group_perm', c_vp * 4), ('corr1', c_vp), ('corr1_stride', c_i64),
+                ('corr1_perm', c_vp), ('corr2', c_vp)]
+
+
 _SIGNATURES = {
     'hpl_version': (ctypes.c_int, []),
     'hpl_last_error': (ctypes.c_char_p, []),
@@ -75,6 +107,13 @@ _SIGNATURES = {
     'hpl_lattice_neighbors': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'hpl_lattice_next_points': (ctypes.c_int, [c_vp, c_i64, c_i64, c_f32, c_vp, c_vp]),
+    'hpl_plan_create': (c_vp, [ctypes.POINTER(Op), ctypes.c_int, ctypes.POINTER(Buf), ctypes.c_int,
+                               ctypes.POINTER(Weight), ctypes.c_int, ctypes.POINTER(c_vp), ctypes.c_int]),
+    'hpl_plan_destroy': (None, [c_vp]),
+    'hpl_plan_workspace_bytes': (c_i64, [c_vp, ctypes.POINTER(LevelTables), ctypes.c_int]),
+    'hpl_plan_run': (ctypes.c_int, [c_vp, ctypes.POINTER(LevelTables), ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'hpl_plan_profile': (ctypes.c_int, [c_vp, ctypes.c_int]),
+    'hpl_plan_profile_read': (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(c_f32)]),
 }
 
 #: every symbol include/hpl_bcl.h declares (checked by tests/test_abi.py against the header text)

@@ -1,0 +1,387 @@
+// executor.hip -- native forward executor: one C call per forward (include/hpl_bcl.h, "Native forward
+// executor").  The plan is a flat program over symbolic row counts written once per model by
+// hplflownet_amd/plan.py from the wiring of /root/reference/models/HPLFlowNet.py:238-430 (and
+// HPLFlowNet_shallow.py:171-311); a run resolves the symbols from the pair's vertex counts, carves the
+// activation matrices out of the caller's workspace and enqueues every kernel through the same entry points
+// the Python path uses (hpl_gconv_forward, hpl_splat, hpl_slice, hpl_transpose) -- same kernels, same
+// arguments, same results, without ~130 Python round trips.  Host cost per forward: the launches themselves.
+#include "common.h"
+
+#include <new>
+#include <vector>
+
+using namespace hpl;
+
+namespace {
+
+constexpr int64_t SPLITK_ELEMS = 1 << 20;          // ops.py: split-K only for outputs of <= 1 M elements
+constexpr int64_t SPLITK_WS_BYTES = 64ll << 20;    // 16 splits x 1 M floats
+constexpr int MAX_SYMS = HPL_SYM_LEVEL0 + 8 * HPL_MAX_LEVELS;
+
+__global__ void k_copy_cols(const float *__restrict__ src, int64_t lds, float *__restrict__ dst, int64_t ldd,
+                            int64_t rows, int cols) {
+    const int64_t total = rows * cols;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+
+__global__ void k_copy_cols4(const float4 *__restrict__ src, int64_t lds4, float4 *__restrict__ dst, int64_t ldd4,
+                             int64_t rows, int cols4) {
+    const int64_t total = rows * cols4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int64_t r = i / cols4;
+        const int c = (int)(i - r * cols4);
+        dst[r * ldd4 + c] = src[r * lds4 + c];
+    }
+}
+
+struct View {                 // a resolved hpl_ref
+    float *p;
+    int64_t ld;
+    int64_t rows;
+    int cols;
+};
+
+}  // namespace
+
+struct hpl_plan {
+    std::vector<hpl_op> ops;
+    std::vector<hpl_buf> bufs;
+    std::vector<hpl_weight> weights;
+    std::vector<const float *> biases;
+    int profile_tag = -1;
+    std::vector<hipEvent_t> pool;           // events owned by the plan (reused)
+    size_t pool_used = 0;
+    std::vector<float *> base;              // per run: buffer base pointers
+    std::vector<int64_t> rows;              // per run: buffer row counts
+};
+
+namespace {
+
+int resolve_syms(const hpl_level_tables *lv, int n_levels, int64_t *sym) {
+    HPL_REQUIRE(lv && n_levels >= 1 && n_levels <= HPL_MAX_LEVELS, "hpl_plan: 1 .. %d lattice levels expected, got %d",
+                HPL_MAX_LEVELS, n_levels);
+    for (int i = 0; i < MAX_SYMS; ++i) sym[i] = 0;
+    sym[HPL_SYM_N0] = lv[0].n0;
+    sym[HPL_SYM_N1] = lv[0].n1;
+    sym[HPL_SYM_NP] = lv[0].n0 + lv[0].n1;
+    for (int L = 0; L < n_levels; ++L) {
+        int64_t *s = sym + HPL_SYM_LEVEL0 + 8 * L;
+        HPL_REQUIRE(lv[L].n0 > 0 && lv[L].n1 > 0 && lv[L].H0 > 0 && lv[L].H1 > 0, "hpl_plan: empty lattice level %d", L);
+        HPL_REQUIRE(L == 0 || (lv[L].n0 == lv[L - 1].H0 && lv[L].n1 == lv[L - 1].H1),
+                    "hpl_plan: level %d has %lld / %lld input points, level %d has %lld / %lld vertices", L,
+                    (long long)lv[L].n0, (long long)lv[L].n1, L - 1, (long long)lv[L - 1].H0, (long long)lv[L - 1].H1);
+        s[HPL_SYM_H0] = lv[L].H0;
+        s[HPL_SYM_H1] = lv[L].H1;
+        s[HPL_SYM_HP] = lv[L].H0 + lv[L].H1;
+        s[HPL_SYM_FH0] = 15 * lv[L].H0;
+        s[HPL_SYM_IN0] = lv[L].n0;
+        s[HPL_SYM_INP] = lv[L].n0 + lv[L].n1;
+    }
+    return HPL_OK;
+}
+
+inline int64_t symv(const int64_t *sym, int id) { return id < 0 ? 0 : sym[id]; }
+
+inline int64_t buf_bytes(int64_t rows, int cols) { return (rows * cols * 4 + 255) / 256 * 256; }
+
+struct Runner {
+    hpl_plan &pl;
+    const hpl_level_tables *lv;
+    int n_levels;
+    const int64_t *sym;
+    const float *pc[2];
+    float *out;
+    float *splitk;
+    hipStream_t s;
+    hplStream hs;
+
+    int view(const hpl_ref &r, View &v, const char *what) const {
+        if (r.buf == HPL_BUF_OUT) {
+            v.p = out + r.col_off;
+            v.ld = 3;
+            v.rows = sym[HPL_SYM_N0];
+            v.cols = r.cols;
+            HPL_REQUIRE(r.col_off + r.cols <= 3, "hpl_plan_run: %s exceeds the [N][3] output", what);
+            return HPL_OK;
+        }
+        HPL_REQUIRE(r.buf >= 0 && r.buf < (int)pl.bufs.size(), "hpl_plan_run: %s refers to buffer %d", what, r.buf);
+        const int64_t off = symv(sym, r.row_off_sym);
+        const int64_t have = pl.rows[r.buf] - off;
+        v.rows = r.rows_sym < 0 ? have : sym[r.rows_sym];
+        HPL_REQUIRE(off >= 0 && v.rows >= 0 && v.rows <= have && r.col_off >= 0 &&
+                        r.col_off + r.cols <= pl.bufs[r.buf].cols,
+                    "hpl_plan_run: %s outside buffer %d (%lld x %d): rows %lld + %lld, columns %d + %d", what, r.buf,
+                    (long long)pl.rows[r.buf], pl.bufs[r.buf].cols, (long long)off, (long long)v.rows, r.col_off, r.cols);
+        v.ld = pl.bufs[r.buf].cols;
+        v.p = pl.base[r.buf] + off * v.ld + r.col_off;
+        v.cols = r.cols;
+        return HPL_OK;
+    }
+
+    void bracket(bool on, bool stop) {
+        if (!on) return;
+        if (pl.pool_used == pl.pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            pl.pool.push_back(e);
+        }
+        (void)stop;
+        hipEventRecord(pl.pool[pl.pool_used++], s);
+    }
+
+    int gconv(const hpl_op &op) {
+        View A, Y, R;
+        int rc = view(op.a, A, "gconv input");
+        if (rc) return rc;
+        rc = view(op.out, Y, "gconv output");
+        if (rc) return rc;
+        const bool has_res = op.res.buf != -1;
+        if (has_res && (rc = view(op.res, R, "gconv residual"))) return rc;
+        HPL_REQUIRE(op.weight >= 0 && op.weight < (int)pl.weights.size(), "hpl_plan_run: weight image %d", op.weight);
+        HPL_REQUIRE(op.level >= 0 && op.level < n_levels, "hpl_plan_run: op uses lattice level %d of %d", op.level, n_levels);
+        const hpl_level_tables &t = lv[op.level];
+        const hpl_weight &w = pl.weights[op.weight];
+        const int64_t M = symv(sym, op.m_sym);
+        const int32_t *nbr = nullptr, *perm = nullptr;
+        int64_t stride = 0, reg = 0;
+        int ngroups = 0;
+        switch (op.table) {
+        case HPL_TBL_NONE: break;
+        case HPL_TBL_BLUR_PAIR: nbr = t.blur; stride = t.blur_stride; if (op.order != HPL_ORD_NONE) perm = t.blur_perm; break;
+        case HPL_TBL_BLUR0:
+            nbr = t.blur; stride = t.blur_stride;
+            if (op.order == HPL_ORD_GROUPS && t.n_up_groups >= 2) ngroups = t.n_up_groups;
+            else if (op.order != HPL_ORD_NONE) perm = t.up_perm;
+            break;
+        case HPL_TBL_CORR1: nbr = t.corr1; stride = t.corr1_stride; if (op.order != HPL_ORD_NONE) perm = t.corr1_perm; break;
+        case HPL_TBL_CORR2: nbr = t.corr2; stride = 15 * t.H0; break;
+        case HPL_TBL_REGULAR: reg = symv(sym, op.reg_stride_sym); break;
+        default: HPL_REQUIRE(false, "hpl_plan_run: gconv with table kind %d", op.table);
+        }
+        HPL_REQUIRE(op.table == HPL_TBL_NONE || op.table == HPL_TBL_REGULAR || nbr, "hpl_plan_run: level %d lacks table %d",
+                    op.level, op.table);
+        HPL_REQUIRE(op.table != HPL_TBL_REGULAR || (reg > 0 && (op.F - 1) * reg + M <= A.rows),
+                    "hpl_plan_run: regular stride %lld x %d taps outside the %lld input rows", (long long)reg, op.F,
+                    (long long)A.rows);
+        HPL_REQUIRE(A.cols >= op.C && Y.cols >= op.N && Y.rows >= M, "hpl_plan_run: gconv shapes (C=%d of %d, N=%d of %d)",
+                    op.C, A.cols, op.N, Y.cols);
+        const bool prof = pl.profile_tag >= 0 && op.tag == pl.profile_tag;
+        auto pass = [&](int f0, int F, const int32_t *row_perm, bool first, bool last) -> int {
+            hpl_gconv_desc d = {};
+            d.A = A.p + (reg ? (int64_t)f0 * reg * A.ld : 0);
+            d.lda = A.ld;
+            d.rows_a = A.rows - (reg ? (int64_t)f0 * reg : 0);
+            d.nbr = nbr ? nbr + (int64_t)f0 * stride : nullptr;
+            d.nbr_stride = stride;
+            d.reg_stride = reg;
+            d.M = M; d.C = op.C; d.F = F;
+            const int64_t wrows = w.rows - (int64_t)f0 * op.C;
+            d.Wt = w.Wt + (int64_t)f0 * op.C * w.ldw;
+            d.ldw = w.ldw;
+            d.N = op.N;
+            d.w_rows = (int32_t)imin(wrows, cdiv((int64_t)F * op.C, 32) * 32);
+            d.act = last ? op.act : HPL_ACT_NONE;
+            d.slope = op.slope;
+            d.bias = (first && op.bias >= 0) ? pl.biases[op.bias] : nullptr;
+            if (first) {
+                if (has_res) { d.res = R.p; d.ldres = R.ld; d.res_mod = op.res_mod_sym >= 0 ? sym[op.res_mod_sym] : R.rows; }
+            } else {
+                d.res = Y.p; d.ldres = Y.ld; d.res_mod = M;
+            }
+            d.Y = Y.p; d.ldy = Y.ld;
+            d.row_perm = row_perm;
+            if (M * op.N <= SPLITK_ELEMS) { d.ws = splitk; d.ws_bytes = SPLITK_WS_BYTES; }
+            bracket(prof, false);
+            const int r = hpl_gconv_forward(&d, hs);
+            bracket(prof, true);
+            return r;
+        };
+        if (ngroups >= 2) {
+            for (int g = 0; g < ngroups; ++g) {
+                rc = pass(t.up_group_cut[g], t.up_group_cut[g + 1] - t.up_group_cut[g], t.up_group_perm[g], g == 0,
+                          g == ngroups - 1);
+                if (rc) return rc;
+            }
+            return HPL_OK;
+        }
+        if ((nbr || reg) && op.F > 15) {            // radius-2 stencils: accumulating passes over tap ranges
+            for (int f0 = 0; f0 < op.F; f0 += 15) {
+                rc = pass(f0, (int)imin(15, op.F - f0), nullptr, f0 == 0, f0 + 15 >= op.F);
+                if (rc) return rc;
+            }
+            return HPL_OK;
+        }
+        return pass(0, op.F, perm, true, true);
+    }
+
+    int run_op(const hpl_op &op) {
+        const bool prof = pl.profile_tag >= 0 && op.tag == pl.profile_tag && op.kind != HPL_OP_GCONV;
+        int rc = HPL_OK;
+        View A, Y;
+        switch (op.kind) {
+        case HPL_OP_GCONV: return gconv(op);
+        case HPL_OP_SPLAT: {
+            if ((rc = view(op.a, A, "splat input")) || (rc = view(op.out, Y, "splat output"))) return rc;
+            HPL_REQUIRE(op.level >= 0 && op.level < n_levels, "hpl_plan_run: splat at level %d", op.level);
+            const hpl_level_tables &t = lv[op.level];
+            const int64_t H = symv(sym, op.m_sym);
+            HPL_REQUIRE(op.table == HPL_TBL_CSR_PAIR || op.table == HPL_TBL_CSR_C0, "hpl_plan_run: splat table kind %d", op.table);
+            HPL_REQUIRE(H == (op.table == HPL_TBL_CSR_PAIR ? t.H0 + t.H1 : t.H0) && Y.rows >= H && Y.cols >= op.C &&
+                            A.cols >= op.C && A.rows >= (op.table == HPL_TBL_CSR_PAIR ? t.n0 + t.n1 : t.n0),
+                        "hpl_plan_run: splat shapes at level %d", op.level);
+            bracket(prof, false);
+            rc = hpl_splat(A.p, A.ld, op.C, t.csr_ptr, t.csr_pt, t.csr_w, op.use_norm ? t.csr_norm : nullptr, H, Y.p, Y.ld, hs);
+            bracket(prof, true);
+            return rc;
+        }
+        case HPL_OP_SLICE: {
+            if ((rc = view(op.a, A, "slice input")) || (rc = view(op.out, Y, "slice output"))) return rc;
+            HPL_REQUIRE(op.level >= 0 && op.level < n_levels && op.table == HPL_TBL_CLOUD0, "hpl_plan_run: slice at level %d", op.level);
+            const hpl_level_tables &t = lv[op.level];
+            const int64_t N = symv(sym, op.m_sym);
+            HPL_REQUIRE(N == t.n0 && A.rows >= t.H0 && A.cols >= op.C && Y.cols >= op.C && Y.rows >= N,
+                        "hpl_plan_run: slice shapes at level %d", op.level);
+            bracket(prof, false);
+            rc = hpl_slice(A.p, A.ld, op.C, t.bary0, t.off0, N, nullptr, op.bias >= 0 ? pl.biases[op.bias] : nullptr, Y.p,
+                           Y.ld, hs);
+            bracket(prof, true);
+            return rc;
+        }
+        case HPL_OP_COPY: {
+            if ((rc = view(op.out, Y, "copy output"))) return rc;
+            const int64_t rows = symv(sym, op.m_sym);
+            const float *src;
+            int64_t lds;
+            if (op.a.buf == -1) {                 // el_minus_gr of the level: external table [rows][4]
+                HPL_REQUIRE(op.level >= 0 && op.level < n_levels && op.C == 4, "hpl_plan_run: emg copy at level %d", op.level);
+                src = lv[op.level].emg_pair;
+                lds = 4;
+                HPL_REQUIRE(rows <= lv[op.level].n0 + lv[op.level].n1, "hpl_plan_run: emg copy of %lld rows", (long long)rows);
+            } else {
+                if ((rc = view(op.a, A, "copy input"))) return rc;
+                HPL_REQUIRE(A.rows >= rows && A.cols >= op.C, "hpl_plan_run: copy input too small");
+                src = A.p;
+                lds = A.ld;
+            }
+            HPL_REQUIRE(Y.rows >= rows && Y.cols >= op.C, "hpl_plan_run: copy output too small");
+            if (rows == 0) return HPL_OK;
+            if (op.C % 4 == 0 && lds % 4 == 0 && Y.ld % 4 == 0 && aligned16(src) && aligned16(Y.p)) {
+                const int grid = (int)imin(cdiv(rows * (op.C / 4), 256), 4096);
+                k_copy_cols4<<<grid, 256, 0, s>>>(reinterpret_cast<const float4 *>(src), lds / 4,
+                                                  reinterpret_cast<float4 *>(Y.p), Y.ld / 4, rows, op.C / 4);
+            } else {
+                const int grid = (int)imin(cdiv(rows * op.C, 256), 4096);
+                k_copy_cols<<<grid, 256, 0, s>>>(src, lds, Y.p, Y.ld, rows, op.C);
+            }
+            HPL_CHECK_LAUNCH("hpl_plan_run (copy)");
+            return HPL_OK;
+        }
+        case HPL_OP_LOAD: {
+            if ((rc = view(op.out, Y, "load output"))) return rc;
+            const int64_t n = symv(sym, op.m_sym);
+            HPL_REQUIRE((op.ext == 0 || op.ext == 1) && Y.rows >= n && Y.cols >= 3, "hpl_plan_run: load");
+            return hpl_transpose(pc[op.ext], n, Y.p, Y.ld, 3, n, hs);
+        }
+        default: HPL_REQUIRE(false, "hpl_plan_run: unknown op kind %d", op.kind);
+        }
+        return HPL_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" hpl_plan *hpl_plan_create(const hpl_op *ops, int n_ops, const hpl_buf *bufs, int n_bufs,
+                                     const hpl_weight *weights, int n_weights, const float *const *biases,
+                                     int n_biases) {
+    if (!ops || n_ops <= 0 || !bufs || n_bufs <= 0 || n_weights < 0 || n_biases < 0) {
+        set_error("hpl_plan_create: bad arguments");
+        return nullptr;
+    }
+    hpl_plan *p = new (std::nothrow) hpl_plan();
+    if (!p) return nullptr;
+    p->ops.assign(ops, ops + n_ops);
+    p->bufs.assign(bufs, bufs + n_bufs);
+    if (n_weights) p->weights.assign(weights, weights + n_weights);
+    if (n_biases) p->biases.assign(biases, biases + n_biases);
+    for (const hpl_buf &b : p->bufs)
+        if (b.cols <= 0 || b.rows_sym < 0 || b.rows_sym >= MAX_SYMS) {
+            set_error("hpl_plan_create: bad buffer (rows symbol %d, %d columns)", b.rows_sym, b.cols);
+            delete p;
+            return nullptr;
+        }
+    return p;
+}
+
+extern "C" void hpl_plan_destroy(hpl_plan *plan) {
+    if (!plan) return;
+    for (hipEvent_t e : plan->pool) hipEventDestroy(e);
+    delete plan;
+}
+
+extern "C" int64_t hpl_plan_workspace_bytes(const hpl_plan *plan, const hpl_level_tables *levels, int n_levels) {
+    int64_t sym[MAX_SYMS];
+    if (!plan || resolve_syms(levels, n_levels, sym) != HPL_OK) return -1;
+    int64_t total = SPLITK_WS_BYTES + 256;
+    for (const hpl_buf &b : plan->bufs) total += buf_bytes(sym[b.rows_sym], b.cols);
+    return total;
+}
+
+extern "C" int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels, int n_levels, const float *pc1,
+                            const float *pc2, float *out, void *workspace, int64_t workspace_bytes, hplStream stream) {
+    HPL_REQUIRE(plan && pc1 && pc2 && out && workspace, "hpl_plan_run: null argument");
+    int64_t sym[MAX_SYMS];
+    int rc = resolve_syms(levels, n_levels, sym);
+    if (rc) return rc;
+    // carve the activation matrices and the split-K scratch out of the workspace
+    char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
+    char *const end = reinterpret_cast<char *>(workspace) + workspace_bytes;
+    plan->base.resize(plan->bufs.size());
+    plan->rows.resize(plan->bufs.size());
+    for (size_t i = 0; i < plan->bufs.size(); ++i) {
+        plan->rows[i] = sym[plan->bufs[i].rows_sym];
+        plan->base[i] = reinterpret_cast<float *>(w);
+        w += buf_bytes(plan->rows[i], plan->bufs[i].cols);
+    }
+    float *splitk = reinterpret_cast<float *>(w);
+    w += SPLITK_WS_BYTES;
+    HPL_REQUIRE(w <= end, "hpl_plan_run: workspace of %lld bytes is too small (hpl_plan_workspace_bytes: %lld)",
+                (long long)workspace_bytes, (long long)hpl_plan_workspace_bytes(plan, levels, n_levels));
+    Runner r{*plan, levels, n_levels, sym, {pc1, pc2}, out, splitk, to_stream(stream), stream};
+    for (const hpl_op &op : plan->ops) {
+        if (op.cond != HPL_COND_ALWAYS) {
+            HPL_REQUIRE(op.cond_level >= 0 && op.cond_level < n_levels, "hpl_plan_run: condition on level %d", op.cond_level);
+            const bool shrink = levels[op.cond_level].n0 < levels[op.cond_level].H0;
+            if ((op.cond == HPL_COND_SHRINK) != shrink) continue;
+        }
+        rc = r.run_op(op);
+        if (rc) return rc;
+    }
+    return HPL_OK;
+}
+
+extern "C" int hpl_plan_profile(hpl_plan *plan, int tag) {
+    HPL_REQUIRE(plan, "hpl_plan_profile: null plan");
+    plan->profile_tag = tag;
+    return HPL_OK;
+}
+
+extern "C" int hpl_plan_profile_read(hpl_plan *plan, int *launches, float *total_ms) {
+    HPL_REQUIRE(plan && launches && total_ms, "hpl_plan_profile_read: null argument");
+    *launches = 0;
+    *total_ms = 0.f;
+    for (size_t i = 0; i + 1 < plan->pool_used; i += 2) {
+        if (hipEventSynchronize(plan->pool[i + 1]) != hipSuccess) { set_error("hpl_plan_profile_read: event wait failed"); return HPL_EHIP; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, plan->pool[i], plan->pool[i + 1]) == hipSuccess) { *total_ms += ms; ++*launches; }
+    }
+    plan->pool_used = 0;
+    return HPL_OK;
+}

@@ -12,6 +12,7 @@ Level L (0-based) hosts bcn{L+1} (Down, shared by both clouds), bcn{L+1}_ (Up) a
 L >= 2, corr{L-1}.
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -203,6 +204,9 @@ def _assemble(rows, parts, device):
 
 
 # ----------------------------------------------------------------------------- the two models
+_PLANS = weakref.WeakKeyDictionary()        # model -> plan.ForwardPlan (kept outside the module: deepcopy / state_dict safe)
+
+
 class _FlowNetBase(nn.Module):
     """Shared wiring.  Subclasses define SPEC."""
 
@@ -215,6 +219,9 @@ class _FlowNetBase(nn.Module):
     #: on a device-built lattice the Down path runs once per PAIR (both clouds stacked), in inference and
     #: in training; False forces the per-cloud path (what reference-format lattices use)
     pair_batched = not os.environ.get('HPL_NO_PAIR')      # env: A/B switch for benchmarking
+    #: inference on a device-built lattice runs as ONE native call (plan.ForwardPlan: the same launches issued by
+    #: csrc/executor.hip instead of ~130 Python round trips); False forces the Python path below
+    native_forward = not os.environ.get('HPL_NO_NATIVE')
 
     def __init__(self, args):
         super(_FlowNetBase, self).__init__()
@@ -269,6 +276,15 @@ class _FlowNetBase(nn.Module):
         from .bcl import GROUPS_MIN_CHANNELS
         return [getattr(self, 'bcn%d_' % (L + 1)).num_input >= GROUPS_MIN_CHANNELS for L in range(self.NLEV)]
 
+    def forward_plan(self):
+        """The native plan of this model's inference forward (built on first use, rebuilt when a parameter was
+        replaced by a new tensor; in-place parameter updates only refresh its weight images)."""
+        from .plan import ForwardPlan
+        plan = _PLANS.get(self)
+        if plan is None or not plan.fresh():
+            plan = _PLANS[self] = ForwardPlan(self)
+        return plan
+
     # -- helpers ------------------------------------------------------------------------
     def _stack(self, x, seq, out=None):
         mods = list(seq)
@@ -296,6 +312,10 @@ class _FlowNetBase(nn.Module):
         lat = generated_data if isinstance(generated_data, DeviceLattice) else \
             DeviceLattice.from_generated_data(generated_data[:self.NLEV], dev)
         nlev = self.NLEV
+        if self.native_forward and self.pair_batched and not torch.is_grad_enabled():
+            plan = self.forward_plan()
+            if plan.accepts(lat):
+                return plan(pc1, pc2, lat)
         if torch.is_grad_enabled():
             lat.resolve_symmetry()
             if ops.BANK is not None:

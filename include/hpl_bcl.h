@@ -295,6 +295,141 @@ int hpl_lattice_neighbors(const void *workspace, int64_t n1, int64_t n2,
 int hpl_lattice_next_points(const int32_t *vkeys, int64_t vstride, int64_t H, float divisor,
                             float *out, hplStream stream);
 
+
+/* ------------------------------------------------------------------------ *
+ * Native forward executor: a whole model forward in ONE call
+ *
+ * The reference's forward (models/HPLFlowNet.py:238-430, models/HPLFlowNet_shallow.py:171-311) is ~130 kernel
+ * launches per pair whose shapes follow the pair's vertex counts.  Issuing them from Python costs more host time
+ * than the GPU needs on dense clouds; here the host side prepares a PLAN once per model -- the list of
+ * operations with symbolic row counts, weight images and biases already resolved to device pointers -- and every
+ * forward is one hpl_plan_run() that walks it with the lattice tables of the pair (hpl_level_tables).
+ * The plan knows nothing about HPLFlowNet: hplflownet_amd/plan.py writes the program from the model's wiring.
+ * ------------------------------------------------------------------------ */
+/* Row-count symbols.  Level L (0-based) owns symbols HPL_SYM_LEVEL0 + 8*L + k. */
+#define HPL_SYM_ZERO (-1)
+#define HPL_SYM_N0 0          /* points of cloud 1 */
+#define HPL_SYM_N1 1          /* points of cloud 2 */
+#define HPL_SYM_NP 2          /* N0 + N1 */
+#define HPL_SYM_LEVEL0 8
+#define HPL_SYM_H0 0          /* vertices of cloud 1 at level L */
+#define HPL_SYM_H1 1          /* vertices of cloud 2 */
+#define HPL_SYM_HP 2          /* H0 + H1 */
+#define HPL_SYM_FH0 3         /* 15 * H0: virtual vertices of the patch correlation */
+#define HPL_SYM_IN0 4         /* input points of cloud 1 at level L (N0, or H0 of level L-1) */
+#define HPL_SYM_INP 5         /* input points of both clouds */
+#define HPL_MAX_LEVELS 8
+
+#define HPL_OP_GCONV 1        /* hpl_gconv_forward (incl. tap-group passes) */
+#define HPL_OP_SPLAT 2        /* hpl_splat */
+#define HPL_OP_SLICE 3        /* hpl_slice */
+#define HPL_OP_COPY 4         /* out[:, cols] = a[:, cols]   (the torch.cat calls of the reference forward) */
+#define HPL_OP_LOAD 5         /* out rows = transpose of an external (3, N) cloud (ext: 0 = pc1, 1 = pc2) */
+
+#define HPL_TBL_NONE 0
+#define HPL_TBL_BLUR_PAIR 1   /* blur table of the stacked pair [15][H0+H1]          (Down convs) */
+#define HPL_TBL_BLUR0 2       /* its cloud-1 columns                                  (Up convs) */
+#define HPL_TBL_CORR1 3       /* pc1_corr_indices [15][H0] */
+#define HPL_TBL_CORR2 4       /* pc2_corr_indices, permuted [15][15*H0] */
+#define HPL_TBL_REGULAR 5     /* no table: tap f of row m reads row f*sym[reg_stride_sym] + m */
+#define HPL_TBL_CSR_PAIR 6    /* splat CSR of the stacked pair */
+#define HPL_TBL_CSR_C0 7      /* splat CSR of cloud 1 alone (prefix of the pair CSR) */
+#define HPL_TBL_CLOUD0 8      /* barycentric / offsets of cloud 1's input points (slice) */
+
+#define HPL_ORD_NONE 0
+#define HPL_ORD_PERM 1        /* rows in the table's single-pass tap order when the lattice has one */
+#define HPL_ORD_GROUPS 2      /* tap-group passes when the lattice has group orders, else as HPL_ORD_PERM */
+
+#define HPL_COND_ALWAYS 0
+#define HPL_COND_SHRINK 1     /* the level's slice shrinks the row count: input points of cloud 1 < its vertices
+                                 (the slice-before-1x1 order of an Up layer pays, bcl.BilateralConvFlex.forward_cl) */
+#define HPL_COND_NOT_SHRINK 2
+
+#define HPL_BUF_OUT (-2)      /* hpl_ref.buf: the caller's output matrix [N0][3] */
+
+typedef struct hpl_ref {      /* rows [sym[row_off_sym], + sym[rows_sym]) x columns [col_off, col_off+cols) of buffer `buf` */
+    int32_t buf;              /* index into the plan's buffers, HPL_BUF_OUT, or -1 = absent */
+    int32_t row_off_sym;      /* HPL_SYM_ZERO: from the first row */
+    int32_t rows_sym;         /* HPL_SYM_ZERO: to the last row */
+    int32_t col_off;
+    int32_t cols;
+} hpl_ref;
+
+typedef struct hpl_buf {      /* an activation matrix the executor allocates from the workspace per run */
+    int32_t rows_sym;
+    int32_t cols;
+} hpl_buf;
+
+typedef struct hpl_weight {   /* a re-laid weight image (hpl_weight_relayout) */
+    const float *Wt;
+    int64_t ldw;
+    int64_t rows;
+} hpl_weight;
+
+typedef struct hpl_op {
+    int32_t kind;             /* HPL_OP_* */
+    int32_t tag;              /* profiling class (hpl_plan_profile) */
+    hpl_ref a, out, res;
+    int32_t m_sym;            /* rows produced: gconv M, splat H, slice N, copy / load rows */
+    int32_t res_mod_sym;      /* gconv residual period (HPL_SYM_ZERO: the residual has M rows) */
+    int32_t level;            /* lattice level whose tables are used */
+    int32_t table;            /* HPL_TBL_* */
+    int32_t order;            /* HPL_ORD_* */
+    int32_t F, C, N;          /* taps, channels taken from `a`, output channels */
+    int32_t weight;           /* index into the plan's weight images, -1 = none */
+    int32_t bias;             /* index into the plan's bias pointers, -1 = none */
+    int32_t act;              /* HPL_ACT_* */
+    float slope;
+    int32_t use_norm;         /* splat: density normalisation */
+    int32_t reg_stride_sym;   /* HPL_TBL_REGULAR */
+    int32_t ext;              /* HPL_OP_LOAD: 0 = pc1, 1 = pc2 */
+    int32_t cond;             /* HPL_COND_*: run the op only if the condition holds at level cond_level */
+    int32_t cond_level;
+} hpl_op;
+
+/* Kernel-ready tables of one lattice level of a pair (what hplflownet_amd.lattice builds on the device;
+ * the schema of `generated_data`, transforms/transforms.py:471-483, in int32 / CSR form). */
+typedef struct hpl_level_tables {
+    int64_t n0, n1;                   /* input points per cloud */
+    int64_t H0, H1;                   /* vertices per cloud */
+    const float *emg_pair;            /* el_minus_gr, both clouds, point-major [n0+n1][4] */
+    const int32_t *csr_ptr;           /* pair CSR (hpl_csr_build_pair): [H0+H1+1] */
+    const int32_t *csr_pt;            /* [4*(n0+n1)] */
+    const float *csr_w;
+    const float *csr_norm;            /* [H0+H1] */
+    const float *bary0;               /* cloud 1: [4][n0] */
+    const int32_t *off0;
+    const int32_t *blur;              /* pair blur table [15][blur_stride], NULL if the level has none */
+    int64_t blur_stride;
+    const int32_t *blur_perm;         /* hpl_tap_order of the pair table or NULL */
+    const int32_t *up_perm;           /* hpl_tap_order of its cloud-1 columns or NULL */
+    int32_t n_up_groups;              /* >= 2: tap groups [cut[i], cut[i+1]) with their own row orders */
+    int32_t up_group_cut[5];
+    const int32_t *up_group_perm[4];
+    const int32_t *corr1;             /* [15][corr1_stride] or NULL */
+    int64_t corr1_stride;
+    const int32_t *corr1_perm;
+    const int32_t *corr2;             /* [15][15*H0] or NULL */
+} hpl_level_tables;
+
+typedef struct hpl_plan hpl_plan;
+
+/* HOST arrays, copied.  The weight images and biases must stay alive (and may be refreshed in place). */
+hpl_plan *hpl_plan_create(const hpl_op *ops, int n_ops, const hpl_buf *bufs, int n_bufs,
+                          const hpl_weight *weights, int n_weights, const float *const *biases, int n_biases);
+void hpl_plan_destroy(hpl_plan *plan);
+/* bytes of workspace a run with these tables needs (activations + 64 MB of split-K partials) */
+int64_t hpl_plan_workspace_bytes(const hpl_plan *plan, const hpl_level_tables *levels /* HOST */, int n_levels);
+/* One forward: pc1 (3, n0), pc2 (3, n1) float32 -> out [n0][3] (the flow, point-major); everything is enqueued
+ * on `stream`; `workspace` must not be reused before the run has finished on the device. */
+int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels /* HOST */, int n_levels, const float *pc1,
+                 const float *pc2, float *out, void *workspace, int64_t workspace_bytes, hplStream stream);
+/* Profiling: with tag >= 0 every following run brackets the ops of that tag with HIP events on the run's stream
+ * (tag < 0: off).  hpl_plan_profile_read waits for the recorded events and returns the number of bracketed
+ * launches, their total duration in ms, and resets the record. */
+int hpl_plan_profile(hpl_plan *plan, int tag);
+int hpl_plan_profile_read(hpl_plan *plan, int *launches, float *total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,3 +71,29 @@ def test_product_does_not_import_oracle():
         if fn.endswith('.py'):
             src = open(os.path.join(pkg, fn)).read()
             assert 'import oracle' not in src and 'from oracle' not in src, fn
+
+
+def test_executor_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors of the native executor's structs (hpl_ref, hpl_buf, hpl_weight, hpl_op, hpl_level_tables)
+    against the C compiler's view of include/hpl_bcl.h: sizes and the offset of every field."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    mirrors = {'hpl_ref': _lib.Ref, 'hpl_buf': _lib.Buf, 'hpl_weight': _lib.Weight, 'hpl_op': _lib.Op,
+               'hpl_level_tables': _lib.LevelTables, 'hpl_gconv_desc': _lib.GConvDesc, 'hpl_relayout_job': _lib.RelayoutJob}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hpl_bcl.h"', 'int main(void) {']
+    for cname, cls in mirrors.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    lines.append('return 0; }')
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in mirrors.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f in cls._fields_:
+            assert int(got['%s.%s' % (cname, f[0])]) == getattr(cls, f[0]).offset, (cname, f[0])
