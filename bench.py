@@ -405,6 +405,8 @@ def main():
     timers.records = []
     timers.only = None
     timers.enabled = True
+    clk = torch.zeros(4, dtype=torch.int64, device=dev)
+    ops.CLOCK_PROBE = clk                    # the wide row-ordered launches stamp their first workgroup's clocks
     model.native_forward = False             # launch by launch, an event pair around each
     with torch.set_grad_enabled(a.train):
         for i in range(detail_steps):
@@ -412,6 +414,9 @@ def main():
     torch.cuda.synchronize()
     model.native_forward = native
     timers.enabled = False
+    ops.CLOCK_PROBE = None
+    cyc, ticks = clk.tolist()[:2]
+    clock_ghz = cyc / float(ticks) * 0.1 if ticks > 0 else None
     kernels = timers.summary(detail_steps)
     if rank == 0:
         roofline = {'bound': 'mfma', 'achieved': dom.get('achieved'), 'peak': MFMA_F32_PEAK_TFLOPS,
@@ -479,10 +484,20 @@ def main():
             roofline['executed_source'] = src
             roofline['achieved'] = roofline['achieved_algorithmic'] * share
             roofline['frac'] = roofline['achieved'] / MFMA_F32_PEAK_TFLOPS
+            if 'in_loop' in roofline and roofline['in_loop'].get('achieved') is None:
+                del roofline['in_loop']          # nothing was bracketed inside the timed loop (native run, other model)
             if 'in_loop' in roofline:
                 roofline['in_loop']['achieved_algorithmic'] = roofline['in_loop']['achieved']
                 roofline['in_loop']['achieved'] = roofline['in_loop']['achieved'] * share
                 roofline['in_loop']['frac'] = roofline['in_loop']['achieved'] / MFMA_F32_PEAK_TFLOPS
+        if clock_ghz:
+            # the chip clocks to its power budget: the fp32 matrix pipe alone sustains 2.39 GHz on changing operands
+            # (tools/mfma_probe3.py), this kernel's global-load traffic pulls the clock down (profiles/r02g_ablate.txt:
+            # 2.19 GHz with the loads removed, 2.04 when every load hits cache, 1.88 as shipped)
+            roofline['shader_clock_ghz'] = clock_ghz
+            roofline['peak_at_measured_clock'] = 1024 * 64 * clock_ghz / 1e3          # 1024 SIMDs x 64 FLOP/clk
+            if roofline.get('achieved'):
+                roofline['frac_at_measured_clock'] = roofline['achieved'] / roofline['peak_at_measured_clock']
         roofline['note'] = ('achieved / frac: executed MFMA flops per launch / HIP-event launch duration (a fraction of the '
                             '157.3 TFLOP/s fp32-MFMA peak, <= 1); *_algorithmic: 2*H*15*C_in*C_out per launch, what the '
                             'reference multiplies -- slices whose taps are absent for a whole tile are skipped, '

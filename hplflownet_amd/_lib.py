@@ -35,7 +35,8 @@ class GConvDesc(ctypes.Structure):
                 ('bias', c_vp), ('res', c_vp), ('ldres', c_i64), ('res_mod', c_i64),
                 ('Y', c_vp), ('ldy', c_i64),
                 ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('w_rows', c_i32),
-                ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64)]
+                ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64),
+                ('tile_idx', c_vp), ('tile_mask', c_vp), ('tile_bm', c_i32), ('clock_probe', c_vp)]
 
 
 class Ref(ctypes.Structure):
@@ -67,7 +68,10 @@ class LevelTables(ctypes.Structure):
                 ('csr_ptr', c_vp), ('csr_pt', c_vp), ('csr_w', c_vp), ('csr_norm', c_vp), ('bary0', c_vp), ('off0', c_vp),
                 ('blur', c_vp), ('blur_stride', c_i64), ('blur_perm', c_vp), ('up_perm', c_vp), ('n_up_groups', c_i32),
                 ('up_group_cut', c_i32 * 5), ('up_group_perm', c_vp * 4), ('corr1', c_vp), ('corr1_stride', c_i64),
-                ('corr1_perm', c_vp), ('corr2', c_vp)]
+                ('corr1_perm', c_vp), ('corr2', c_vp), ('tile_bm', c_i32),
+                ('blur_perm_tidx', c_vp), ('blur_perm_tmask', c_vp), ('up_perm_tidx', c_vp), ('up_perm_tmask', c_vp),
+                ('up_group_tidx', c_vp * 4), ('up_group_tmask', c_vp * 4), ('corr1_perm_tidx', c_vp),
+                ('corr1_perm_tmask', c_vp)]
 
 
 _SIGNATURES = {
@@ -89,12 +93,14 @@ _SIGNATURES = {
     'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,
                                            c_i64, c_i64, c_i64, ctypes.c_int, c_vp]),
     'hpl_tap_order': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
+    'hpl_tile_index': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_vp, c_vp, c_vp]),
     'hpl_gconv_forward': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
     'hpl_gconv_forward_naive': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
     'hpl_gconv_wgrad': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,
                                        c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     'hpl_tap_lists': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'hpl_mfma_probe': (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp]),
+    'hpl_mfma_probe_data': (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     'hpl_colsum': (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     'hpl_leaky_bwd': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_i64, ctypes.c_int, c_vp]),
     'hpl_transpose': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
@@ -113,6 +119,7 @@ _SIGNATURES = {
     'hpl_plan_workspace_bytes': (c_i64, [c_vp, ctypes.POINTER(LevelTables), ctypes.c_int]),
     'hpl_plan_run': (ctypes.c_int, [c_vp, ctypes.POINTER(LevelTables), ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'hpl_plan_profile': (ctypes.c_int, [c_vp, ctypes.c_int]),
+    'hpl_plan_clock_probe': (ctypes.c_int, [c_vp, c_vp]),
     'hpl_plan_profile_read': (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(c_f32)]),
 }
 

@@ -101,6 +101,9 @@ def pointwise_conv(x, conv, act, use_leaky, out=None):
 GROUPS_MIN_CHANNELS = 256
 
 
+_NO_TILES = bool(os.environ.get('HPL_NO_TILES'))       # A/B switch: no precomputed per-tile index tables
+
+
 class NbrTable(object):
     """int32 neighbour table [F, M] on the device + lazily checked symmetry."""
 
@@ -114,6 +117,8 @@ class NbrTable(object):
         self._perm = False      # False = not computed yet, None = not applicable
         self._taps = False
         self._groups = False
+        self._perm_tiles = False
+        self._group_tiles = False
         #: set by the lattice builder: vertices per input point of this level.  A sparse lattice (few
         #: points per vertex -> most neighbour slots empty) is where the multi-pass contraction pays
         #: (bcn1_, 42 % of the taps present: 2.62 -> 2.08 ms; bcn2_, 72 %: no gain)
@@ -146,6 +151,20 @@ class NbrTable(object):
                 cuts = [round(i * F / G) for i in range(G + 1)]
                 self._groups = [(f0, f1, ops.tap_order(self.t[f0:f1])) for f0, f1 in zip(cuts[:-1], cuts[1:])]
         return self._groups
+
+    @property
+    def perm_tiles(self):
+        """(tile_idx, tile_mask) of the single-pass row order (ops.tile_index), None without one."""
+        if self._perm_tiles is False:
+            self._perm_tiles = ops.tile_index(self.t, self.perm) if (self.perm is not None and not _NO_TILES) else None
+        return self._perm_tiles
+
+    def group_tiles(self):
+        """[(tile_idx, tile_mask)] aligned with groups(), None without groups."""
+        if self._group_tiles is False:
+            g = self.groups()
+            self._group_tiles = [ops.tile_index(self.t[f0:f1], pm) for f0, f1, pm in g] if (g and not _NO_TILES) else None
+        return self._group_tiles
 
     #: per-tap vertex lists pay for wide layers only (wgrad tap mode needs C >= 128-ish) and big tables
     TAPS_MIN_ROWS = 4096
@@ -318,7 +337,8 @@ def _run_conv_stack(x, stack, table, M, F, use_leaky, out=None):
                           out=o, slope=_slope(use_leaky),
                           row_perm=table.perm if groups is None else None,     # (the passes bring their own orders)
                           taps=table.taps if conv.in_channels >= 100 else None, tap_groups=groups,
-                          reg_stride=getattr(table, 'reg_stride', 0))
+                          reg_stride=getattr(table, 'reg_stride', 0),
+                          tiles=(table.group_tiles() if groups is not None else table.perm_tiles) if table.t is not None else None)
         else:
             x = ops.gconv(x, conv.weight, conv.bias, None, M, 1, act=act, bwd_mode='dense', out=o,
                           slope=_slope(use_leaky))
@@ -456,7 +476,7 @@ class BilateralCorrelationFlex(nn.Module):
         mode1 = corr1.bwd_mode(H1) if torch.is_grad_enabled() else 'scatter'   # symmetry check syncs
         # A-term: pc1 half, independent of the displacement tap
         perm1 = corr1.perm
-        a = ops.gconv(f1, w0, None, corr1.t, H1, K, c0=P, C=C, bwd_mode=mode1, row_perm=perm1)
+        a = ops.gconv(f1, w0, None, corr1.t, H1, K, c0=P, C=C, bwd_mode=mode1, row_perm=perm1, tiles=corr1.perm_tiles)
         if prev is not None:
             if P == 0:
                 raise _lib.HplError('prev_corr_feat given but prev_corr_dim == 0')
@@ -464,7 +484,8 @@ class BilateralCorrelationFlex(nn.Module):
                 ps = ops.SplatFn.apply(prev, cloud1, self.use_norm)
             else:
                 ps = ops.splat_raw(prev, cloud1.csr(), H1, self.use_norm)
-            a = ops.gconv(ps, w0, None, corr1.t, H1, K, c0=0, C=P, res=a, res_mod=H1, bwd_mode=mode1, row_perm=perm1)
+            a = ops.gconv(ps, w0, None, corr1.t, H1, K, c0=0, C=P, res=a, res_mod=H1, bwd_mode=mode1, row_perm=perm1,
+                          tiles=corr1.perm_tiles)
         # B-term over the F*H1 virtual vertices, + broadcast A-term + bias, LeakyReLU
         p = ops.gconv(f2, w0, conv0.bias, corr2.t, F * H1, K, act=ACT_LEAKY, c0=P + C, C=C, res=a,
                       res_mod=H1, bwd_mode='scatter', slope=sl)

@@ -57,6 +57,7 @@ struct hpl_plan {
     std::vector<hpl_weight> weights;
     std::vector<const float *> biases;
     int profile_tag = -1;
+    int64_t *clock_probe = nullptr;
     std::vector<hipEvent_t> pool;           // events owned by the plan (reused)
     size_t pool_used = 0;
     std::vector<float *> base;              // per run: buffer base pointers
@@ -150,18 +151,24 @@ struct Runner {
         const hpl_level_tables &t = lv[op.level];
         const hpl_weight &w = pl.weights[op.weight];
         const int64_t M = symv(sym, op.m_sym);
-        const int32_t *nbr = nullptr, *perm = nullptr;
+        const int32_t *nbr = nullptr, *perm = nullptr, *tidx = nullptr, *tmask = nullptr;
         int64_t stride = 0, reg = 0;
         int ngroups = 0;
         switch (op.table) {
         case HPL_TBL_NONE: break;
-        case HPL_TBL_BLUR_PAIR: nbr = t.blur; stride = t.blur_stride; if (op.order != HPL_ORD_NONE) perm = t.blur_perm; break;
+        case HPL_TBL_BLUR_PAIR:
+            nbr = t.blur; stride = t.blur_stride;
+            if (op.order != HPL_ORD_NONE) { perm = t.blur_perm; tidx = t.blur_perm_tidx; tmask = t.blur_perm_tmask; }
+            break;
         case HPL_TBL_BLUR0:
             nbr = t.blur; stride = t.blur_stride;
             if (op.order == HPL_ORD_GROUPS && t.n_up_groups >= 2) ngroups = t.n_up_groups;
-            else if (op.order != HPL_ORD_NONE) perm = t.up_perm;
+            else if (op.order != HPL_ORD_NONE) { perm = t.up_perm; tidx = t.up_perm_tidx; tmask = t.up_perm_tmask; }
             break;
-        case HPL_TBL_CORR1: nbr = t.corr1; stride = t.corr1_stride; if (op.order != HPL_ORD_NONE) perm = t.corr1_perm; break;
+        case HPL_TBL_CORR1:
+            nbr = t.corr1; stride = t.corr1_stride;
+            if (op.order != HPL_ORD_NONE) { perm = t.corr1_perm; tidx = t.corr1_perm_tidx; tmask = t.corr1_perm_tmask; }
+            break;
         case HPL_TBL_CORR2: nbr = t.corr2; stride = 15 * t.H0; break;
         case HPL_TBL_REGULAR: reg = symv(sym, op.reg_stride_sym); break;
         default: HPL_REQUIRE(false, "hpl_plan_run: gconv with table kind %d", op.table);
@@ -174,7 +181,8 @@ struct Runner {
         HPL_REQUIRE(A.cols >= op.C && Y.cols >= op.N && Y.rows >= M, "hpl_plan_run: gconv shapes (C=%d of %d, N=%d of %d)",
                     op.C, A.cols, op.N, Y.cols);
         const bool prof = pl.profile_tag >= 0 && op.tag == pl.profile_tag;
-        auto pass = [&](int f0, int F, const int32_t *row_perm, bool first, bool last) -> int {
+        auto pass = [&](int f0, int F, const int32_t *row_perm, bool first, bool last, const int32_t *ti,
+                        const int32_t *tm) -> int {
             hpl_gconv_desc d = {};
             d.A = A.p + (reg ? (int64_t)f0 * reg * A.ld : 0);
             d.lda = A.ld;
@@ -198,6 +206,8 @@ struct Runner {
             }
             d.Y = Y.p; d.ldy = Y.ld;
             d.row_perm = row_perm;
+            if (row_perm && ti && tm) { d.tile_idx = ti; d.tile_mask = tm; d.tile_bm = t.tile_bm; }
+            if (prof) d.clock_probe = pl.clock_probe;
             if (M * op.N <= SPLITK_ELEMS) { d.ws = splitk; d.ws_bytes = SPLITK_WS_BYTES; }
             bracket(prof, false);
             const int r = hpl_gconv_forward(&d, hs);
@@ -207,19 +217,19 @@ struct Runner {
         if (ngroups >= 2) {
             for (int g = 0; g < ngroups; ++g) {
                 rc = pass(t.up_group_cut[g], t.up_group_cut[g + 1] - t.up_group_cut[g], t.up_group_perm[g], g == 0,
-                          g == ngroups - 1);
+                          g == ngroups - 1, t.up_group_tidx[g], t.up_group_tmask[g]);
                 if (rc) return rc;
             }
             return HPL_OK;
         }
         if ((nbr || reg) && op.F > 15) {            // radius-2 stencils: accumulating passes over tap ranges
             for (int f0 = 0; f0 < op.F; f0 += 15) {
-                rc = pass(f0, (int)imin(15, op.F - f0), nullptr, f0 == 0, f0 + 15 >= op.F);
+                rc = pass(f0, (int)imin(15, op.F - f0), nullptr, f0 == 0, f0 + 15 >= op.F, nullptr, nullptr);
                 if (rc) return rc;
             }
             return HPL_OK;
         }
-        return pass(0, op.F, perm, true, true);
+        return pass(0, op.F, perm, true, true, tidx, tmask);
     }
 
     int run_op(const hpl_op &op) {
@@ -370,6 +380,12 @@ extern "C" int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels, int 
 extern "C" int hpl_plan_profile(hpl_plan *plan, int tag) {
     HPL_REQUIRE(plan, "hpl_plan_profile: null plan");
     plan->profile_tag = tag;
+    return HPL_OK;
+}
+
+extern "C" int hpl_plan_clock_probe(hpl_plan *plan, int64_t *clock_probe) {
+    HPL_REQUIRE(plan, "hpl_plan_clock_probe: null plan");
+    plan->clock_probe = clock_probe;
     return HPL_OK;
 }
 

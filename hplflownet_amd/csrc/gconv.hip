@@ -33,6 +33,35 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 __device__ float4_t buffer_load_f32x4(int32x4_t srsrc, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
+#ifdef HPL_TIMING
+// Diagnostic build only (tools/tile_timing.py, -DHPL_TIMING): per-wave cycle stamps of the first workgroups of the
+// last k_gconv launch.  Record layout per (workgroup, wave): [0] start, [1] main loop entered, [2] main loop left,
+// [3] end, [4] slices, [5] cycles parked at the end-of-step waitcnt + barrier, [6] wall clock (100 MHz) at start, [7] (wall clock at end << 4) | XCC id.
+#define HPL_TIMING_WGS 8192
+__device__ long long g_timing[HPL_TIMING_WGS * 8 * 8];
+extern "C" int hpl_timing_read(long long *dst_host) {
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_timing), sizeof(long long) * HPL_TIMING_WGS * 8 * 8) == hipSuccess ? 0 : -2;
+}
+// ablation switch of the diagnostic build: 1 = every gathered row / weight row load hits a small resident set of
+// cache lines (no L2 misses), 2 = no global loads in the main loop at all (LDS keeps stale data)
+__device__ int g_abl;
+extern "C" int hpl_timing_ablate(int mode) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_abl), &mode, sizeof(int)) == hipSuccess ? 0 : -2;
+}
+extern "C" int hpl_timing_reset(void) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_timing)) != hipSuccess) return -2;
+    return hipMemset(p, 0, sizeof(long long) * HPL_TIMING_WGS * 8 * 8) == hipSuccess ? 0 : -2;
+}
+#define HPL_T(slot, val)                                                                            \
+    do {                                                                                            \
+        if (lane == 0 && blockIdx.x < HPL_TIMING_WGS && wave < 8)                                   \
+            g_timing[((size_t)blockIdx.x * 8 + wave) * 8 + (slot)] = (long long)(val);              \
+    } while (0)
+#else
+#define HPL_T(slot, val) do { } while (0)
+#endif
+
 namespace {
 
 // raw buffer descriptor: base pointer, stride 0, extent in bytes, gfx9 dword-3 flags (32-bit data format)
@@ -60,6 +89,10 @@ struct GParams {
     int tiles_m; int tiles_n;
     int64_t a_bytes; int64_t w_bytes;   // extents of A and Wt for the buffer descriptors
     const int32_t *row_perm;            // optional permutation of the output rows (tile row -> vertex)
+    const int32_t *tile_idx;            // optional precomputed [tiles_m][F][BM] source rows + [tiles_m][8] masks
+    const int32_t *tile_mask;           //   (hpl_tile_index; only when its BM is this launch's BM)
+    int tile_bm;
+    long long *clock_probe;             // optional: sampled workgroups add their residence in shader cycles / 100 MHz wall ticks
     int perm_chunk;                     // tile-rows per XCD chunk in permuted launches
     int col_share;                      // > 0: column-major XCD order, XCDs per column tile (see tile_coords)
     int col_rows;                       // tile-rows per virtual column in that order
@@ -178,6 +211,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // clock probe: every 64th workgroup adds its residence in shader cycles and in 100 MHz wall ticks
+    const bool probe = p.clock_probe && (blockIdx.x & 63) == 0 && t == 0;
+    long long probe_c = 0, probe_w = 0;
+    if (probe) {
+        probe_c = (long long)__builtin_readcyclecounter();
+        probe_w = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+#ifdef HPL_TIMING
+    HPL_T(0, __builtin_readcyclecounter());
+    HPL_T(6, __builtin_amdgcn_s_memrealtime());                                   // 100 MHz wall clock at start
+    long long parked = 0;
+#endif
     const int wm = wave / WGN, wn = wave % WGN;
     const int li = lane & 31, hi = lane >> 5;
 
@@ -199,6 +244,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     // With a row permutation (vertices sorted by tap mask, hpl_tap_order) tile row r is vertex
     // row_perm[m0 + r]: rows of one tile then miss the same taps, and a whole 32-wide slice whose
     // taps are absent for all BM rows is skipped (no loads, no MFMAs, no barrier).
+    if (p.tile_idx) {
+        // Indices and tap masks of this tile were computed once per lattice (hpl_tile_index): three independent,
+        // coalesced loads and ONE barrier instead of the dependent chain row_perm -> nbr -> masks.
+        const int32_t *ti = p.tile_idx + (int64_t)tile_m * p.F * BM;
+        if (t < 8) tapmask_s[t] = p.tile_mask[(int64_t)tile_m * 8 + t];
+        for (int r = t; r < BM; r += NT) {
+            const int64_t m = m0 + r;
+            Vs[r] = (m < p.M) ? (p.row_perm ? p.row_perm[m] : (int)m) : -1;
+        }
+        for (int i = t; i < F_LDS * BM; i += NT) Is[i] = (i < p.F * BM) ? ti[i] : -1;
+    } else {
     if (t < 8) tapmask_s[t] = 0;
     for (int r = t; r < BM; r += NT) {
         const int64_t m = m0 + r;
@@ -218,6 +274,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
             atomicOr(tapmask_s, mybits);
             atomicOr(tapmask_s + 2 + ((t % BM) >> 5), mybits);      // NT % BM == 0: r = t % BM for every i of this thread
         }
+    }
     }
     __syncthreads();
     const int tapmask = __builtin_amdgcn_readfirstlane(*tapmask_s);
@@ -260,10 +317,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
             for (int i = 0; i < A_PASSES; ++i) rows_n[i] = Is[fi * BM + arow0 + i * A_ROWS_PER_PASS];
         }
     };
+#ifdef HPL_TIMING
+    const int abl = g_abl;
+#endif
     auto load_a = [&](int set, int i) {
         if (AVEC) {
             const bool ok = (f_t < p.F) && (rows_n[i] >= 0);
+#ifdef HPL_TIMING
+            if (abl == 2) { ra[set][i] = make_float4(1.f, 2.f, 3.f, 4.f); return; }
+            const unsigned off = ok ? (unsigned)(abl == 1 ? (rows_n[i] & 63) : rows_n[i]) * lda_b + (unsigned)c_t * 4u : OOB;
+#else
             const unsigned off = ok ? (unsigned)rows_n[i] * lda_b + (unsigned)c_t * 4u : OOB;
+#endif
             const float4_t v = buffer_load_f32x4(rsrc_a, (int)off, 0, 0);
             ra[set][i] = make_float4(v.x, v.y, v.z, v.w);
         } else {   // generic path: any C / alignment, element by element
@@ -288,7 +353,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     (void)rsrc_b;
     const int wave_brow0 = (wave * 64) / B_F4_PER_ROW;         // first tile row of this wave's 64 lanes
     auto load_b_lds = [&](int buf, int k0, int i) {
+#ifdef HPL_TIMING
+        if (abl == 2) return;
+        const unsigned off = bvalid ? boff0 + (unsigned)((abl == 1 ? (k0 & 255) : k0) + i * B_ROWS_PER_PASS) * ldw_b : OOB;
+#else
         const unsigned off = bvalid ? boff0 + (unsigned)(k0 + i * B_ROWS_PER_PASS) * ldw_b : OOB;
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             lrsrc_b,
             (__attribute__((address_space(3))) void *)(Bs + buf * BK * LDB_S + (wave_brow0 + i * B_ROWS_PER_PASS) * LDB_S),
@@ -362,7 +432,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
         store_lds(0, 0);
         if (nsl > 1) load_regs(1, (int)(Ks[lo + 1] & 1023) * BK);      // slice 1 stays in flight in set 1
     }
-    __builtin_amdgcn_s_waitcnt(0);          // everything landed, including the LDS-direct weight rows
+    // the LDS-direct weight rows and the staged slice have landed; the register loads of slice 1 (issued last,
+    // loads complete in order) stay in flight across the barrier
+    if (nsl > 1) {
+        constexpr int inflight = A_PASSES;
+        __builtin_amdgcn_s_waitcnt((inflight & 0xF) | ((inflight >> 4) << 14) | (0x7 << 4) | (0x0 << 8));
+    } else {
+        __builtin_amdgcn_s_waitcnt(0);
+    }
     __syncthreads();
     int cur = 0;
     // One contraction step t (compile-time flags).  P = t & 1.  LOAD: issue the loads of slice t+2
@@ -437,11 +514,24 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef HPL_TIMING
+            if (kk == BK / 2 - 1) {
+                const long long t0_ = __builtin_readcyclecounter();
+                pieces(kk);
+                __syncthreads();
+                parked += __builtin_readcyclecounter() - t0_;
+                continue;
+            }
+#endif
             pieces(kk);
         }
+#ifndef HPL_TIMING
         __syncthreads();
+#endif
         cur ^= 1;
     };
+    HPL_T(1, __builtin_readcyclecounter());
+    HPL_T(4, nsl);
     {
         using T = std::true_type;
         using F = std::false_type;
@@ -463,6 +553,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
         if (t < nsl) step((int)Ks[lo + t], -1, -1, F{}, F{}, P0{});
     }
 
+    HPL_T(2, __builtin_readcyclecounter());
+#ifdef HPL_TIMING
+    HPL_T(5, parked);
+#endif
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -491,6 +585,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
                 }
             }
         }
+    if (probe) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe),
+                  (unsigned long long)((long long)__builtin_readcyclecounter() - probe_c));
+        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 1,
+                  (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - probe_w));
+    }
+    HPL_T(3, __builtin_readcyclecounter());
+#ifdef HPL_TIMING
+    HPL_T(7, (__builtin_amdgcn_s_memrealtime() << 4) | (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15));   // wall clock at end | XCC id
+#endif
 }
 
 // split-K epilogue: Y = act(bias + res + sum_s partial[s]) in fixed split order
@@ -563,6 +667,10 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.Y = d->Y; p.ldy = d->ldy;
     p.scat = d->scat; p.scat_stride = d->scat_stride; p.scat_c = d->scat_c;
     p.row_perm = d->row_perm;
+    p.tile_idx = (d->tile_idx && d->tile_mask && d->row_perm) ? d->tile_idx : nullptr;
+    p.tile_mask = d->tile_mask;
+    p.tile_bm = d->tile_bm;
+    p.clock_probe = reinterpret_cast<long long *>(d->clock_probe);
     {
         const char *e = getenv("HPL_PERM_CHUNK");
         p.perm_chunk = e ? atoi(e) : 4;      // measured on bcn1_/bcn2_ (64-row tiles): 1: 2.61/1.33 ms, 2: 2.73/1.31, 4: 2.62/1.26, 8: 2.66/1.26, 16: 2.96/1.27
@@ -584,6 +692,7 @@ template <int BM, int BN, int WGM, int WGN>
 void launch_cfg(GParams &p, bool avec, hipStream_t s) {
     p.tiles_m = (int)cdiv(p.M, BM);
     p.tiles_n = (int)cdiv(p.N, BN);
+    if (p.tile_bm != BM || p.F == 1) p.tile_idx = nullptr;      // the table was cut for another tile height
     // Small M: too few tiles to fill 256 CUs and a long serial slice loop (one exposed memory
     // latency per slice).  Split the slice list over up to 16 workgroups per tile, partial tiles
     // go to the caller's workspace and are summed in fixed order by k_gconv_finish.
@@ -663,6 +772,46 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
         k_gconv_finish<<<g, 256, 0, s>>>(p);
     }
     HPL_CHECK_LAUNCH("hpl_gconv_forward");
+    return HPL_OK;
+}
+
+namespace {
+// hpl_tile_index: per 64-row (BM) tile of a tap-ordered launch, the source row of every (tap, tile row) -- what the
+// prologue of k_gconv would gather through row_perm and nbr -- and the tile's tap-presence masks.
+__global__ void k_tile_index(const int32_t *__restrict__ nbr, int64_t stride, int F, int64_t M,
+                             const int32_t *__restrict__ perm, int BM, int32_t *__restrict__ tile_idx,
+                             int32_t *__restrict__ tile_mask) {
+    __shared__ int masks[8];
+    const int t = threadIdx.x;
+    if (t < 8) masks[t] = 0;
+    __syncthreads();
+    const int64_t tile = blockIdx.x, m0 = tile * BM;
+    int32_t *out = tile_idx + tile * F * BM;
+    for (int i = t; i < F * BM; i += blockDim.x) {
+        const int f = i / BM, r = i - f * BM;
+        const int64_t m = m0 + r;
+        int row = -1;
+        if (m < M) {
+            const int v = perm ? perm[m] : (int)m;
+            row = nbr[(int64_t)f * stride + v];
+        }
+        out[i] = row;
+        if (row >= 0) {
+            atomicOr(&masks[0], 1 << f);
+            atomicOr(&masks[2 + (r >> 5)], 1 << f);
+        }
+    }
+    __syncthreads();
+    if (t < 8) tile_mask[tile * 8 + t] = masks[t];
+}
+}  // namespace
+
+extern "C" int hpl_tile_index(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, const int32_t *row_perm,
+                              int BM, int32_t *tile_idx, int32_t *tile_mask, hplStream stream) {
+    HPL_REQUIRE(nbr && tile_idx && tile_mask && F >= 1 && F <= 15 && M > 0 && (BM == 64 || BM == 128),
+                "hpl_tile_index: bad arguments");
+    k_tile_index<<<(int)cdiv(M, BM), 256, 0, to_stream(stream)>>>(nbr, nbr_stride, F, M, row_perm, BM, tile_idx, tile_mask);
+    HPL_CHECK_LAUNCH("hpl_tile_index");
     return HPL_OK;
 }
 
@@ -1148,6 +1297,71 @@ __global__ void __launch_bounds__(256) k_mfma_probe_chain(float *out, int iters)
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 }  // namespace
+
+namespace {
+// The same MFMA stream on operands that CHANGE from instruction to instruction (eight pseudo-random values per lane
+// and operand, rotated): the matrix pipe's switching activity -- hence power, hence the clock the chip sustains --
+// is that of real data, not of the constant operands of k_mfma_probe.  mode 2 adds the LDS fragment traffic of the
+// gather-GEMM loop (two ds_read_b32 per MFMA).
+template <int MODE>
+__global__ void __launch_bounds__(256) k_mfma_probe_data(float *out, int iters, long long *clk) {
+    __shared__ float lds[2 * 32 * 130];
+    floatx16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a[8], b[8];
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h = h * 1664525u + 1013904223u;
+        a[i] = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+        h = h * 1664525u + 1013904223u;
+        b[i] = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    }
+    for (int i = threadIdx.x; i < 2 * 32 * 130; i += 256) lds[i] = a[i & 7] * 0.5f + b[(i >> 3) & 7];
+    __syncthreads();
+    long long c0 = 0, w0 = 0;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); w0 = __builtin_amdgcn_s_memrealtime(); }
+    const int lane = threadIdx.x & 63;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (MODE == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float av = lds[((u * 4 + i) & 31) * 130 + lane + ((it & 1) ? 4160 : 0)];
+                    const float bv = lds[((u * 4 + i + 7) & 31) * 130 + 64 + (lane & 31) + ((it & 1) ? 0 : 4160)];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(u + i) & 7], b[(u * 3 + i) & 7], acc[i], 0, 0, 0);
+            }
+        }
+    }
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_readcyclecounter() - c0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - w0;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int hpl_mfma_probe_data(float *out, int blocks, int iters, int mode, long long *clk, hplStream stream) {
+    HPL_REQUIRE(out && blocks > 0 && iters > 0 && (mode == 1 || mode == 2), "hpl_mfma_probe_data: bad arguments");
+    if (mode == 1) k_mfma_probe_data<1><<<blocks, 256, 0, to_stream(stream)>>>(out, iters, clk);
+    else k_mfma_probe_data<2><<<blocks, 256, 0, to_stream(stream)>>>(out, iters, clk);
+    HPL_CHECK_LAUNCH("hpl_mfma_probe_data");
+    return HPL_OK;
+}
 
 extern "C" int hpl_mfma_probe(float *out, int blocks, int iters, hplStream stream) {
     HPL_REQUIRE(out && blocks > 0 && iters != 0, "hpl_mfma_probe: bad arguments");

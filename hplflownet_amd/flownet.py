@@ -100,9 +100,11 @@ class DeviceLattice(object):
             up = lv.blur[0] if isinstance(lv.blur, PairBlur) else None
             wide = self.wide_up[L] if isinstance(self.wide_up, (list, tuple)) else self.wide_up
             grouped = up is not None and wide is not False and up.groups() is not None   # multi-pass row orders
+            if grouped:
+                up.group_tiles()
             for tbl in tables:
                 if tbl is not None and not (tbl is up and grouped and wide and tbl is not lv.corr1):
-                    tbl.perm
+                    tbl.perm_tiles          # (builds the row order first)
         return self
 
     def symmetry_begin(self):

@@ -141,6 +141,21 @@ def tap_order(nbr):
     return perm
 
 
+TILE_BM = 64        # tile height of the gather-GEMM classes that take a row order (csrc/gconv.hip: 64x128, 64x64)
+
+
+def tile_index(nbr, perm, BM=TILE_BM):
+    """int32 [F<=15, M] table + row order (or None) -> (tile_idx int32 [tiles, F, BM], tile_mask int32 [tiles, 8]):
+    the gather indices and tap masks of every BM-row tile, precomputed once per lattice (hpl_tile_index)."""
+    F, M = nbr.shape
+    tiles = (M + BM - 1) // BM
+    idx = torch.empty((tiles, F, BM), dtype=torch.int32, device=nbr.device)
+    mask = torch.empty((tiles, 8), dtype=torch.int32, device=nbr.device)
+    check(_lib.load().hpl_tile_index(ptr(nbr), nbr.stride(0), F, M, ptr(perm), BM, ptr(idx), ptr(mask), stream()),
+          'hpl_tile_index')
+    return idx, mask
+
+
 def tap_lists(nbr):
     """int32 [F, M] table -> (list_m, list_row int32 [F*M], tap_ptr int32 [F+1]): the present vertices of
     every tap and their source rows."""
@@ -228,7 +243,7 @@ def _mat(x, what):
 
 
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
-              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True, reg_stride=0):
+              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True, reg_stride=0, tiles=None):
     """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
     row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged.
     nbr None and reg_stride > 0: tap f of row m reads row f*reg_stride + m (no table: the displacement
@@ -271,6 +286,10 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
         if row_perm.dtype is not torch.int32 or row_perm.numel() != M or not row_perm.is_contiguous():
             raise _lib.HplError('row_perm must be a contiguous int32 tensor of M=%d entries' % M)
         d.row_perm = ptr(row_perm)
+        if tiles is not None:         # (tile_idx, tile_mask) of THIS table and row order (tile_index)
+            d.tile_idx, d.tile_mask, d.tile_bm = ptr(tiles[0]), ptr(tiles[1]), tiles[0].shape[2]
+        if CLOCK_PROBE is not None and N > 64 and M >= 16384:
+            d.clock_probe = CLOCK_PROBE.data_ptr()
     st = stream()
     if split_k and not _NO_SPLITK and scat is None and M * N <= _SPLITK_MAX_ELEMS:
         ws = _splitk_workspace(A.device, st)
@@ -281,6 +300,11 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
         check(rc, 'hpl_gconv_forward')
     return out
 
+
+#: diagnostic (bench.py): a zeroed int64 device tensor (>= 2 entries); sampled workgroups of the wide row-ordered
+#: launches add their residence in shader cycles to [0] and in 100 MHz wall ticks to [1] -- the clock the chip
+#: sustains under that kernel
+CLOCK_PROBE = None
 
 _SPLITK_MAX_ELEMS = 1 << 20          # split-K only pays for small outputs (M*N <= 1M elements; measured)
 _SPLITK_WS = {}
@@ -453,7 +477,7 @@ MAX_TAPS_PER_PASS = 15      # hpl_gconv_forward: F <= 15 (LDS-staged index table
 
 
 def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
-                 slope=LEAKY_RATE, row_perm=None, reg_stride=0):
+                 slope=LEAKY_RATE, row_perm=None, reg_stride=0, tiles=None):
     """gconv_raw, run as one pass per tap group when `groups` = [(f0, f1, perm), ...] is given: pass i
     contracts taps [f0, f1) (rows f0*C.. of Wt, rows f0.. of the table) in its own row order and adds
     to the output of the passes before it; bias / residual enter the first pass, the activation the last."""
@@ -464,15 +488,16 @@ def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, r
         groups = [(f0, min(F, f0 + MAX_TAPS_PER_PASS), None) for f0 in range(0, F, MAX_TAPS_PER_PASS)]
     if not groups or not (nbr is not None or regular) or len(groups) < 2:
         return gconv_raw(A, nbr, M, C, F, Wt, N, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope,
-                         row_perm=row_perm, reg_stride=reg_stride)
+                         row_perm=row_perm, reg_stride=reg_stride, tiles=tiles if not isinstance(tiles, list) else None)
     y = out
+    gt = tiles if isinstance(tiles, list) and len(tiles) == len(groups) else [None] * len(groups)
     for i, (f0, f1, perm) in enumerate(groups):
         first, last = i == 0, i == len(groups) - 1
         # a tap range of a regular pattern is the same pattern over the rows from f0*reg_stride on
         y = gconv_raw(A[f0 * reg_stride:] if regular else A, None if regular else nbr[f0:f1], M, C, f1 - f0,
                       Wt[f0 * C:], N, bias=bias if first else None,
                       act=act if last else ACT_NONE, res=res if first else y, res_mod=res_mod if first else 0,
-                      out=y, slope=slope, row_perm=perm, reg_stride=reg_stride)
+                      out=y, slope=slope, row_perm=perm, reg_stride=reg_stride, tiles=gt[i] if perm is not None else None)
     return y
 
 
@@ -485,13 +510,14 @@ class GConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm=None,
-                taps=None, groups=None, reg_stride=0):
+                taps=None, groups=None, reg_stride=0, tiles=None):
         O = weight.shape[0]
         Ctot = weight.numel() // (O * F)
         Wt = _train_relayout(weight, C, O, F, F, Ctot * F, 1, base=c0 * F)
         Y = gconv_passes(A, nbr, M, C, F, Wt, O, groups, bias=bias, act=act, res=res, res_mod=res_mod, slope=slope,
-                         row_perm=row_perm, reg_stride=reg_stride)
+                         row_perm=row_perm, reg_stride=reg_stride, tiles=tiles)
         ctx.reg_stride = reg_stride
+        ctx.tiles = tiles            # the mirror backward gathers through the same table in the same row orders
         ctx.groups = groups          # the mirror backward gathers through the same table: same groups
         ctx.slope = slope
         ctx.row_perm = row_perm      # same table in the mirror backward -> same tap masks -> same order
@@ -518,7 +544,7 @@ class GConvFn(torch.autograd.Function):
                 if rows != M:
                     raise _lib.HplError('mirror backward needs a table over the same vertex set')
                 WtT = _train_relayout(weight, O, C, F, Ctot * F, F, 1, base=c0 * F, mirror=True)
-                gA_c = gconv_passes(g, nbr, M, O, F, WtT, C, ctx.groups, row_perm=ctx.row_perm)
+                gA_c = gconv_passes(g, nbr, M, O, F, WtT, C, ctx.groups, row_perm=ctx.row_perm, tiles=ctx.tiles)
             else:   # scatter: G[m, (f, c)] = g[m] . W[:, c, f], added into row nbr[f, m]
                 # columns ordered (f, c): source element (o, f*C + c) = W[o, c0 + c, f]
                 Wcols = weight.view(O, Ctot, F)[:, c0:c0 + C, :].permute(0, 2, 1).reshape(O, F * C).contiguous()
@@ -558,11 +584,11 @@ class GConvFn(torch.autograd.Function):
                 gres = g.view(M // res_mod, res_mod, O).sum(dim=0)
             else:
                 gres = g
-        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None, None, None, None, None
+        return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None, None, None, None, None, None
 
 
 def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_mod=0, bwd_mode='scatter',
-          out=None, slope=LEAKY_RATE, row_perm=None, taps=None, tap_groups=None, reg_stride=0):
+          out=None, slope=LEAKY_RATE, row_perm=None, taps=None, tap_groups=None, reg_stride=0, tiles=None):
     """Autograd-aware gathered convolution; with grad disabled it can write into `out`.
 
     tap_groups: [(f0, f1, perm), ...] -- the contraction is run as one pass per group of
@@ -577,7 +603,8 @@ def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_
                                     (res is not None and res.requires_grad)):
         y = GConvFn.apply(A, weight, bias, nbr, M, c0, C, F, act, res, res_mod, bwd_mode, slope, row_perm,
                           taps() if callable(taps) else taps,
-                          tap_groups() if callable(tap_groups) else tap_groups, reg_stride)
+                          tap_groups() if callable(tap_groups) else tap_groups, reg_stride,
+                          tiles() if callable(tiles) else tiles)
         if out is not None:
             out.copy_(y)
             return out
@@ -585,7 +612,7 @@ def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_
     Wt = _cached_relayout(weight, C, O, F, Ctot, c0)
     groups = tap_groups() if callable(tap_groups) else tap_groups
     return gconv_passes(A, nbr, M, C, F, Wt, O, groups, bias=bias, act=act, res=res, res_mod=res_mod, out=out,
-                        slope=slope, row_perm=row_perm, reg_stride=reg_stride)
+                        slope=slope, row_perm=row_perm, reg_stride=reg_stride, tiles=tiles() if callable(tiles) else tiles)
 
 
 _WT_CACHE = collections.OrderedDict()

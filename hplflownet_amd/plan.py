@@ -301,25 +301,38 @@ def level_tables(lat, hint):
         t.bary0, t.off0 = c0.bary.data_ptr(), c0.off.data_ptr()
         pb = lv.blur.pair
         t.blur, t.blur_stride = pb.t.data_ptr(), pb.t.stride(0)
+        t.tile_bm = ops.TILE_BM
         perm = pb.perm
-        t.blur_perm = perm.data_ptr() if perm is not None else None
+        if perm is not None:
+            t.blur_perm = perm.data_ptr()
+            if pb.perm_tiles is not None:
+                t.blur_perm_tidx, t.blur_perm_tmask = [x.data_ptr() for x in pb.perm_tiles]
         up = lv.blur[0]
         wide = hint[L] if isinstance(hint, (list, tuple)) else hint
         groups = up.groups() if wide else None
         if groups:
             t.n_up_groups = len(groups)
+            tiles = up.group_tiles()
             for g, (f0, f1, pm) in enumerate(groups):
                 t.up_group_cut[g], t.up_group_cut[g + 1] = f0, f1
                 t.up_group_perm[g] = pm.data_ptr()
+                if tiles is not None:
+                    t.up_group_tidx[g], t.up_group_tmask[g] = tiles[g][0].data_ptr(), tiles[g][1].data_ptr()
                 keep.append(pm)
         else:
             t.n_up_groups = 0
             pm = up.perm
-            t.up_perm = pm.data_ptr() if pm is not None else None
+            if pm is not None:
+                t.up_perm = pm.data_ptr()
+                if up.perm_tiles is not None:
+                    t.up_perm_tidx, t.up_perm_tmask = [x.data_ptr() for x in up.perm_tiles]
         if lv.corr1 is not None:
             t.corr1, t.corr1_stride = lv.corr1.t.data_ptr(), lv.corr1.t.stride(0)
             pm = lv.corr1.perm
-            t.corr1_perm = pm.data_ptr() if pm is not None else None
+            if pm is not None:
+                t.corr1_perm = pm.data_ptr()
+                if lv.corr1.perm_tiles is not None:
+                    t.corr1_perm_tidx, t.corr1_perm_tmask = [x.data_ptr() for x in lv.corr1.perm_tiles]
             t.corr2 = lv.corr2.t.data_ptr()
     lat._native_tables = (arr, n, keep)
     return lat._native_tables
@@ -428,6 +441,12 @@ class ForwardPlan(object):
     # ---- profiling of the dominant launches (bench.py)
     def profile(self, tag):
         check(self._lib.hpl_plan_profile(self.handle, tag), 'hpl_plan_profile')
+
+    def clock_probe(self, tensor):
+        """int64[4] device tensor (or None) the profiled launches stamp their first workgroup's clocks into."""
+        self._clk = tensor
+        check(self._lib.hpl_plan_clock_probe(self.handle, tensor.data_ptr() if tensor is not None else None),
+              'hpl_plan_clock_probe')
 
     def profile_read(self):
         n, ms = ctypes.c_int(0), ctypes.c_float(0.0)

@@ -177,6 +177,16 @@ typedef struct hpl_gconv_desc {
      * NULL = never split.  Partial tiles are summed in a fixed order: results stay deterministic. */
     float *ws;
     int64_t ws_bytes;
+    /* optional, with row_perm: per-tile gather indices and tap masks precomputed by hpl_tile_index for tiles of
+     * tile_bm rows.  Used when the launch picks that tile height (ignored otherwise): the tile prologue is then
+     * one round of coalesced loads instead of the dependent chain row_perm -> nbr -> masks. */
+    const int32_t *tile_idx;
+    const int32_t *tile_mask;
+    int32_t tile_bm;
+    /* optional diagnostic (DEVICE, 2 x int64, zeroed by the caller): every 64th workgroup adds its residence time in
+     * shader cycles to [0] and in 100 MHz wall ticks to [1] -- [0] / [1] * 100 MHz is the clock the chip sustains
+     * under this kernel (it clocks to its power budget). */
+    int64_t *clock_probe;
 } hpl_gconv_desc;
 
 /* Row order for tap skipping: perm = the M vertices grouped by their F-bit tap-presence mask
@@ -184,6 +194,14 @@ typedef struct hpl_gconv_desc {
  * does not affect results).  scratch: M + 2 * 524288 + 1100 int32. */
 int hpl_tap_order(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *perm,
                   int32_t *scratch, hplStream stream);
+
+/* Per-tile gather indices of a row-ordered launch: tile j covers output rows row_perm[j*BM .. j*BM+BM) (identity
+ * when row_perm is NULL); tile_idx[j][f][r] = nbr[f][row_perm[j*BM + r]] (-1 past M), tile_mask[j][0] = taps present
+ * in the tile, [2 + b] = taps present in its b-th block of 32 rows ([1] and the rest 0).  Sizes: ceil(M/BM)*F*BM and
+ * ceil(M/BM)*8 int32.  Built once per lattice and row order (models/bilateralNN.py:215-217 gathers through the same
+ * table in every layer call). */
+int hpl_tile_index(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, const int32_t *row_perm, int BM,
+                   int32_t *tile_idx, int32_t *tile_mask, hplStream stream);
 
 /* Y[m, n] = act(bias[n] + res[...] + sum_{f<F, c<C} A[nbr[f][m], c] * Wt[f*C + c, n]).
  * One call covers: the blur Conv2d((15,1)) over gathered neighbours
@@ -213,6 +231,12 @@ int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, const int32_t *
  * iters > 0: four independent accumulators per wave; iters < 0: ONE accumulator (every MFMA
  * depends on the previous one, as in the 32x32-per-wave tiles of the gather-GEMM). */
 int hpl_mfma_probe(float *out, int blocks, int iters, hplStream stream);
+/* The same instruction stream (four accumulators per wave) on operands that change with every MFMA: mode 1 = eight
+ * pseudo-random register values per lane and operand, rotated; mode 2 = operands read from LDS with two ds_read_b32
+ * per MFMA, as in the gather-GEMM loop.  The chip clocks to its power budget: real data toggles the multipliers and
+ * lowers the sustained clock below what hpl_mfma_probe's constant operands reach.  clk (DEVICE, optional):
+ * clk[0] = shader cycles, clk[1] = 100 MHz wall ticks spent by workgroup 0 in the MFMA loop. */
+int hpl_mfma_probe_data(float *out, int blocks, int iters, int mode, long long *clk, hplStream stream);
 
 /* out[n] = sum_m X[m*ld + n]   (bias gradients) */
 int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStream stream);
@@ -410,6 +434,12 @@ typedef struct hpl_level_tables {
     int64_t corr1_stride;
     const int32_t *corr1_perm;
     const int32_t *corr2;             /* [15][15*H0] or NULL */
+    /* optional per-tile index tables (hpl_tile_index, tiles of tile_bm rows) of the row orders above; NULL = none */
+    int32_t tile_bm;
+    const int32_t *blur_perm_tidx, *blur_perm_tmask;
+    const int32_t *up_perm_tidx, *up_perm_tmask;
+    const int32_t *up_group_tidx[4], *up_group_tmask[4];
+    const int32_t *corr1_perm_tidx, *corr1_perm_tmask;
 } hpl_level_tables;
 
 typedef struct hpl_plan hpl_plan;
@@ -428,6 +458,9 @@ int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels /* HOST */, int 
  * (tag < 0: off).  hpl_plan_profile_read waits for the recorded events and returns the number of bracketed
  * launches, their total duration in ms, and resets the record. */
 int hpl_plan_profile(hpl_plan *plan, int tag);
+/* clock_probe (DEVICE, 2 x int64, or NULL) is handed to the gather-GEMM launches of the profiled tag
+ * (hpl_gconv_desc.clock_probe): they accumulate their samples there. */
+int hpl_plan_clock_probe(hpl_plan *plan, int64_t *clock_probe);
 int hpl_plan_profile_read(hpl_plan *plan, int *launches, float *total_ms);
 
 #ifdef __cplusplus

@@ -309,3 +309,45 @@ def test_full_size_properties(ops):
     rhs = float((x.double() * ops.slice_raw(z, ct.bary, ct.off, N, vscale=ct.csr()[3]).double()).sum())
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
     assert torch.equal(Sx, ops.splat_raw(x, ct.csr(), H))                       # deterministic
+
+
+def test_tile_index_tables_and_gconv_with_them(ops):
+    """hpl_tile_index: per-tile gather indices / tap masks of a row-ordered launch == what the kernel's prologue
+    computes itself; a launch that is handed the tables gives bit-identical results (single order and tap groups)."""
+    from hplflownet_amd.bcl import NbrTable
+    rng = np.random.RandomState(11)
+    M, F, C, O = 20000, 15, 96, 160
+    nbr_np = rng.randint(0, M, (F, M)).astype(np.int32)
+    nbr_np[rng.rand(F, M) < 0.55] = -1
+    nbr_np[0] = np.arange(M)
+    nbr = torch.from_numpy(nbr_np).to(DEV)
+    tbl = NbrTable(nbr)
+    tbl.vertices_per_point = 3.0
+    perm = tbl.perm
+    idx, mask = ops.tile_index(nbr, perm)
+    tiles = (M + 63) // 64
+    assert tuple(idx.shape) == (tiles, F, 64) and tuple(mask.shape) == (tiles, 8)
+    pm = torch.full((tiles * 64,), -1, dtype=torch.long, device=DEV)
+    pm[:M] = perm.long()
+    want = torch.where(pm[None, :] >= 0, nbr[:, pm.clamp(min=0)], torch.full_like(nbr[:, :1], -1)).view(F, tiles, 64)
+    assert torch.equal(idx, want.permute(1, 0, 2).contiguous())
+    present = (want >= 0)                                           # (F, tiles, 64)
+    bits = (2 ** torch.arange(F, device=DEV))[:, None]
+    assert torch.equal(mask[:, 0].long(), (present.any(2).long() * bits).sum(0))
+    assert torch.equal(mask[:, 3].long(), (present[:, :, 32:].any(2).long() * bits).sum(0))
+    A = torch.from_numpy(rng.randn(M, C).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rng.randn(O, C, F) / np.sqrt(C * F)).astype(np.float32)).to(DEV)
+    Wt = ops.weight_relayout(W, C, O, F, F, C * F, 1)
+    bias = torch.from_numpy(rng.randn(O).astype(np.float32)).to(DEV)
+    y0 = ops.gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=ops.ACT_LEAKY, row_perm=perm)
+    y1 = ops.gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=ops.ACT_LEAKY, row_perm=perm, tiles=(idx, mask))
+    assert torch.equal(y0, y1)
+    groups, gt = tbl.groups(), tbl.group_tiles()
+    assert groups is not None and len(gt) == len(groups)
+    z0 = ops.gconv_passes(A, nbr, M, C, F, Wt, O, groups, bias=bias, act=ops.ACT_LEAKY)
+    z1 = ops.gconv_passes(A, nbr, M, C, F, Wt, O, groups, bias=bias, act=ops.ACT_LEAKY, tiles=gt)
+    assert torch.equal(z0, z1)
+    # N <= 32 picks 128-row tiles: the 64-row tables are ignored, not misread
+    Wt8 = ops.weight_relayout(W[:24].contiguous(), C, 24, F, F, C * F, 1)
+    assert torch.equal(ops.gconv_raw(A, nbr, M, C, F, Wt8, 24, row_perm=perm),
+                       ops.gconv_raw(A, nbr, M, C, F, Wt8, 24, row_perm=perm, tiles=(idx, mask)))
