@@ -203,6 +203,8 @@ def main():
     ap.add_argument('--data', default='frustum', choices=['frustum', 'surface'],
                     help='frustum: the uniform FT3D-like frustum of SURVEY.md 8(d1) (the headline workload); surface: points on '
                          'smooth patches, the dense extreme (few lattice vertices per point)')
+    ap.add_argument('--python-lattice', action='store_true',
+                    help='drive the lattice build stage by stage from Python instead of the native builder')
     ap.add_argument('--python-forward', action='store_true',
                     help='issue the forward launch by launch from Python instead of one native hpl_plan_run per pair')
     ap.add_argument('--train', action='store_true',
@@ -309,7 +311,7 @@ def main():
         from hplflownet_amd.lattice import LatticePipeline
 
         pipe = LatticePipeline(gen, lambda i: pairs[i % a.pool], first, count, depth=a.lattice_depth, stream=side,
-                               for_training=a.train)
+                               for_training=a.train, native=native and not a.python_lattice)
 
         def build():
             t = time.perf_counter()
@@ -524,6 +526,7 @@ def main():
                            'lattices_under_construction': a.lattice_depth if overlap else 1,
                            'forward_streams': n_fwd if overlap else 1,
                            'forward_issue': 'one native hpl_plan_run per pair' if native else 'python, launch by launch',
+                           'lattice_issue': 'native builder (hpl_lattice_*)' if (native and not a.python_lattice and overlap) else 'python, stage by stage',
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,

@@ -74,6 +74,13 @@ class LevelTables(ctypes.Structure):
                 ('corr1_perm_tmask', c_vp)]
 
 
+class LatticeSpec(ctypes.Structure):
+    """Mirror of `hpl_lattice_spec`."""
+    _fields_ = [('n_levels', c_i32), ('scale', c_f32 * 8), ('bcn_radius', c_i32 * 8), ('corr_filter_radius', c_i32 * 8),
+                ('corr_corr_radius', c_i32 * 8), ('next_divisor', c_f32 * 8), ('wide_up', c_i32 * 8), ('n_groups', c_i32),
+                ('group_cut', c_i32 * 5), ('groups_min_sparsity', c_f32), ('perm_min_rows', c_i64)]
+
+
 _SIGNATURES = {
     'hpl_version': (ctypes.c_int, []),
     'hpl_last_error': (ctypes.c_char_p, []),
@@ -113,6 +120,13 @@ _SIGNATURES = {
     'hpl_lattice_neighbors': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'hpl_lattice_next_points': (ctypes.c_int, [c_vp, c_i64, c_i64, c_f32, c_vp, c_vp]),
+    'hpl_lattice_create': (c_vp, [ctypes.POINTER(LatticeSpec)]),
+    'hpl_lattice_destroy': (None, [c_vp]),
+    'hpl_lattice_begin': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    'hpl_lattice_ready': (ctypes.c_int, [c_vp]),
+    'hpl_lattice_advance': (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int)]),
+    'hpl_lattice_tables': (ctypes.POINTER(LevelTables), [c_vp]),
+    'hpl_lattice_extras': (ctypes.c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64)]),
     'hpl_plan_create': (c_vp, [ctypes.POINTER(Op), ctypes.c_int, ctypes.POINTER(Buf), ctypes.c_int,
                                ctypes.POINTER(Weight), ctypes.c_int, ctypes.POINTER(c_vp), ctypes.c_int]),
     'hpl_plan_destroy': (None, [c_vp]),

@@ -311,13 +311,17 @@ class _FlowNetBase(nn.Module):
         dev = pc1.device
         if not pc1.is_cuda:
             raise _lib.HplError('the HIP path needs device tensors (no CPU fallback)')
+        native_lat = getattr(generated_data, 'device_lattice', None)       # lattice.NativeLattice
+        if self.native_forward and self.pair_batched and not torch.is_grad_enabled() and \
+                (native_lat is not None or isinstance(generated_data, DeviceLattice)):
+            plan = self.forward_plan()
+            if plan.accepts(generated_data):
+                return plan(pc1, pc2, generated_data)
+        if native_lat is not None:
+            generated_data = native_lat()
         lat = generated_data if isinstance(generated_data, DeviceLattice) else \
             DeviceLattice.from_generated_data(generated_data[:self.NLEV], dev)
         nlev = self.NLEV
-        if self.native_forward and self.pair_batched and not torch.is_grad_enabled():
-            plan = self.forward_plan()
-            if plan.accepts(lat):
-                return plan(pc1, pc2, lat)
         if torch.is_grad_enabled():
             lat.resolve_symmetry()
             if ops.BANK is not None:

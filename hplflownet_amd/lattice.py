@@ -16,6 +16,7 @@ resume a pair once its counts have landed in pinned memory, so the host thread n
 them in steady state (bench.py and engine.Trainer feed the forward this way).
 """
 import collections
+import ctypes
 import math
 
 import numpy as np
@@ -41,6 +42,15 @@ class GenerateDataUnsymmetric(object):
         self.scales_filter_map = args.scales_filter_map
         self.expected_std = (self.d + 1) * math.sqrt(2 / 3)        # transforms.py:275
         self.device = torch.device(device)
+
+    def native_builder(self):
+        if getattr(self, '_native', None) is None:
+            self._native = NativeBuilder(self)
+        return self._native
+
+    def build_native(self, pc1, pc2):
+        """The same lattice from the native builder (one arena, one C call per level half): -> NativeLattice."""
+        return NativeLatticeBuild(self, pc1, pc2).finish()
 
     def build(self, pc1, pc2):
         """pc1, pc2: (3, N) float32 device tensors -> DeviceLattice (blocks on every read-back)."""
@@ -200,7 +210,8 @@ class LatticePipeline(object):
     pair whose counts have already landed until the oldest is complete, and blocks only when no pair can
     move."""
 
-    def __init__(self, gen, source, first, count, depth=2, stream=None, for_training=False):
+    def __init__(self, gen, source, first, count, depth=2, stream=None, for_training=False, native=False):
+        self.native = native            # builds driven by csrc/lattice_builder.hip (NativeLatticeBuild)
         self.gen, self.source, self.depth = gen, source, max(1, int(depth))
         self.stream, self.for_training = stream, for_training
         self._next, self._end = first, first + count
@@ -210,8 +221,10 @@ class LatticePipeline(object):
         while len(self._inflight) < self.depth and self._next < self._end:
             with torch.cuda.stream(self.stream):        # a reader's host-to-device copies belong to this stream too
                 item = self.source(self._next)
-            b = LatticeBuild(self.gen, item[0], item[1], self.stream, self.for_training, tag=(self._next, item))
-            b.advance()
+            cls = NativeLatticeBuild if self.native else LatticeBuild
+            b = cls(self.gen, item[0], item[1], self.stream, self.for_training, tag=(self._next, item))
+            if not self.native:
+                b.advance()
             self._inflight.append(b)
             self._next += 1
 
@@ -262,3 +275,224 @@ def to_reference_format(lat):
             d['pc2_corr_indices'] = z.clone()
         out.append(d)
     return out
+
+
+# ----------------------------------------------------------------------------- native builder
+HPL_ENOMEM = -4
+
+
+class NativeLattice(object):
+    """A lattice built by the native builder (csrc/lattice_builder.hip): the kernel-ready hpl_level_tables of every
+    level, all pointing into ONE device arena.  The native forward (plan.ForwardPlan) consumes `tables` as is;
+    `.levels` / `.prepare()` materialise the DeviceLattice view of the same memory (zero-copy tensors over the
+    arena) for everything else -- training, the reference wire format, the parity tests."""
+
+    def __init__(self, arena, tables, n_levels, extras, wide_up):
+        self.arena, self.tables, self.n_levels, self.extras, self.wide_up = arena, tables, n_levels, extras, wide_up
+        self._native_tables = (tables, n_levels, [arena])
+        self._view = None
+
+    @property
+    def H(self):
+        return [(int(t.H0), int(t.H1)) for t in self.tables[:self.n_levels]]
+
+    def _t(self, ptr_, dtype, shape):
+        if not ptr_:
+            return None
+        off = ptr_ - self.arena.data_ptr()
+        n = int(np.prod(shape)) * 4
+        return self.arena[off:off + n].view(dtype).view(shape)
+
+    def device_lattice(self):
+        """DeviceLattice over the arena (no copies, no launches)."""
+        if self._view is not None:
+            return self._view
+        levels = []
+        for L in range(self.n_levels):
+            t = self.tables[L]
+            n0, n1, H0, H1 = int(t.n0), int(t.n1), int(t.H0), int(t.H1)
+            Hp, Np = H0 + H1, n0 + n1
+            lv = _Level()
+            lv.H = (H0, H1)
+            emg_p = self._t(t.emg_pair, torch.float32, (Np, 4))
+            c0 = ops.CloudTables(self._t(t.bary0, torch.float32, (4, n0)), self._t(t.off0, torch.int32, (4, n0)), H0)
+            c1 = ops.CloudTables(self._t(self.extras[2 * L], torch.float32, (4, n1)),
+                                 self._t(self.extras[2 * L + 1], torch.int32, (4, n1)), H1)
+            lv.clouds = [c0, c1]
+            lv.emg_pair, lv.emg = emg_p, [emg_p[:n0], emg_p[n0:]]
+            lv.pair = ops.PairTables(c0, c1)
+            csr = (self._t(t.csr_ptr, torch.int32, (Hp + 1,)), self._t(t.csr_pt, torch.int32, (4 * Np,)),
+                   self._t(t.csr_w, torch.float32, (4 * Np,)), self._t(t.csr_norm, torch.float32, (Hp,)))
+            lv.pair._csr = csr
+            c0._csr = (csr[0][:H0 + 1], csr[1][:4 * n0], csr[2][:4 * n0], csr[3][:H0])
+            c1._csr_src = (lv.pair, n0, H0)
+            if t.blur:
+                F = 15
+                blur_p = self._t(t.blur, torch.int32, (F, Hp))
+                lv.blur = PairBlur(blur_p, H0)
+                lv.blur[0].vertices_per_point = H0 / float(n0)
+                pb, up = lv.blur.pair, lv.blur[0]
+                if t.blur_perm:
+                    tiles = (Hp + 63) // 64
+                    pb._perm = self._t(t.blur_perm, torch.int32, (Hp,))
+                    pb._perm_tiles = (self._t(t.blur_perm_tidx, torch.int32, (tiles, F, 64)),
+                                      self._t(t.blur_perm_tmask, torch.int32, (tiles, 8)))
+                elif Hp < NbrTable.PERM_MIN_ROWS:
+                    pb._perm = None
+                tiles0 = (H0 + 63) // 64
+                if t.n_up_groups >= 2:
+                    cuts = list(t.up_group_cut[:t.n_up_groups + 1])
+                    up._groups = [(cuts[g], cuts[g + 1], self._t(t.up_group_perm[g], torch.int32, (H0,)))
+                                  for g in range(t.n_up_groups)]
+                    up._group_tiles = [(self._t(t.up_group_tidx[g], torch.int32, (tiles0, cuts[g + 1] - cuts[g], 64)),
+                                       self._t(t.up_group_tmask[g], torch.int32, (tiles0, 8))) for g in range(t.n_up_groups)]
+                if t.up_perm:
+                    up._perm = self._t(t.up_perm, torch.int32, (H0,))
+                    up._perm_tiles = (self._t(t.up_perm_tidx, torch.int32, (tiles0, F, 64)),
+                                      self._t(t.up_perm_tmask, torch.int32, (tiles0, 8)))
+                elif H0 < NbrTable.PERM_MIN_ROWS:
+                    up._perm = None
+            else:
+                lv.blur = [None, None]
+            if t.corr2:
+                K = 15
+                if t.corr1 == t.blur:
+                    lv.corr1 = lv.blur[0]
+                else:
+                    lv.corr1 = NbrTable(self._t(t.corr1, torch.int32, (K, H0)))
+                lv.corr2 = NbrTable(self._t(t.corr2, torch.int32, (K, 15 * H0)))
+                lv.corr2._sym = False
+            else:
+                lv.corr1 = lv.corr2 = None
+            levels.append(lv)
+        self._view = DeviceLattice(levels, wide_up=self.wide_up)
+        self._view._native_tables = self._native_tables
+        self._view._arena = self.arena
+        return self._view
+
+    @property
+    def levels(self):
+        return self.device_lattice().levels
+
+    def prepare(self, for_training=False):
+        return self.device_lattice().prepare(for_training)
+
+
+class NativeBuilder(object):
+    """Pool of native builder handles for one GenerateDataUnsymmetric configuration (one handle per pair under
+    construction).  radius-1 stencils only (what the shipped configs use); anything else keeps the Python driver."""
+
+    def __init__(self, gen):
+        from ._lib import LatticeSpec
+        self.gen = gen
+        self.lib = _lib.load()
+        sfm = gen.scales_filter_map
+        n = len(sfm)
+        if n > 8 or any(int(r) not in (-1, 1) for lvl in sfm for r in lvl[1:]):
+            raise _lib.HplError('the native lattice builder handles radius 1 (or -1) and at most 8 levels')
+        sp = LatticeSpec()
+        sp.n_levels = n
+        hint = gen.wide_up
+        for L, (scale, b_r, cf_r, cc_r) in enumerate(sfm):
+            sp.scale[L], sp.bcn_radius[L] = float(scale), int(b_r)
+            sp.corr_filter_radius[L], sp.corr_corr_radius[L] = int(cf_r), int(cc_r)
+            sp.next_divisor[L] = float(np.float32(gen.expected_std * scale))
+            w = hint[L] if isinstance(hint, (list, tuple)) else hint
+            sp.wide_up[L] = -1 if w is None else int(bool(w))
+        G = NbrTable.TAP_GROUPS
+        F = 15
+        sp.n_groups = G if G >= 2 else 0
+        for i in range(G + 1 if G >= 2 else 0):
+            sp.group_cut[i] = round(i * F / G)
+        sp.groups_min_sparsity = NbrTable.GROUPS_MIN_SPARSITY
+        sp.perm_min_rows = NbrTable.PERM_MIN_ROWS
+        self.spec = sp
+        self.free = []
+        self.bytes_per_point = 6000            # arena hint, doubled on HPL_ENOMEM
+        self.n_levels = n
+
+    def acquire(self):
+        if self.free:
+            return self.free.pop()
+        h = self.lib.hpl_lattice_create(ctypes.byref(self.spec))
+        if not h:
+            raise _lib.HplError('hpl_lattice_create: %s' % self.lib.hpl_last_error().decode())
+        return h
+
+    def release(self, h):
+        self.free.append(h)
+
+    def __del__(self):
+        try:
+            for h in self.free:
+                self.lib.hpl_lattice_destroy(h)
+        except Exception:
+            pass
+
+
+class NativeLatticeBuild(object):
+    """LatticeBuild driven by the native builder: same ready() / advance() / finish() protocol, `result` is a
+    NativeLattice.  Host cost of a pair's 7 levels: the launches themselves, no per-stage Python."""
+
+    def __init__(self, gen, pc1, pc2, stream=None, for_training=False, prepare=True, tag=None):
+        self.gen, self.tag = gen, tag
+        self.nb = gen.native_builder()
+        self.stream = stream if stream is not None else torch.cuda.current_stream(pc1.device)
+        self.pc = (pc1.contiguous().float(), pc2.contiguous().float())
+        self.for_training = for_training
+        self.done = False
+        self.result = self.event = None
+        self.handle = self.nb.acquire()
+        self._begin()
+
+    def _begin(self):
+        n0, n1 = int(self.pc[0].shape[1]), int(self.pc[1].shape[1])
+        while True:
+            nbytes = (32 << 20) + self.nb.bytes_per_point * (n0 + n1)
+            with torch.cuda.stream(self.stream):
+                self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.pc[0].device)
+                rc = self.nb.lib.hpl_lattice_begin(self.handle, ptr(self.pc[0]), ptr(self.pc[1]), n0, n1,
+                                                   self.arena.data_ptr(), nbytes, stream())
+            if rc != HPL_ENOMEM:
+                check(rc, 'hpl_lattice_begin')
+                return
+            self.nb.bytes_per_point *= 2
+
+    def ready(self):
+        return self.done or bool(self.nb.lib.hpl_lattice_ready(self.handle))
+
+    def advance(self):
+        if self.done:
+            return True
+        d = ctypes.c_int(0)
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            rc = self.nb.lib.hpl_lattice_advance(self.handle, ctypes.byref(d))
+            if rc == HPL_ENOMEM:               # the arena overflowed at this level: start over with a bigger one
+                self.nb.bytes_per_point *= 2
+                self._begin()
+                return False
+            check(rc, 'hpl_lattice_advance')
+            if d.value:
+                from ._lib import LevelTables
+                n = self.nb.n_levels
+                src = self.nb.lib.hpl_lattice_tables(self.handle)
+                arr = (LevelTables * n)()
+                ctypes.memmove(arr, src, ctypes.sizeof(LevelTables) * n)
+                extras = (ctypes.c_void_p * (2 * n))()
+                used = ctypes.c_int64(0)
+                check(self.nb.lib.hpl_lattice_extras(self.handle, extras, ctypes.byref(used)), 'hpl_lattice_extras')
+                self.nb.release(self.handle)
+                self.handle = None
+                lat = NativeLattice(self.arena, arr, n, [int(e or 0) for e in extras], self.gen.wide_up)
+                lat.arena_used = used.value
+                if self.for_training:
+                    lat = lat.device_lattice().prepare(True)        # tap lists, symmetry verdicts: the Python tables
+                self.result, self.done = lat, True
+                self.event = torch.cuda.Event()
+                self.event.record(self.stream)
+        return self.done
+
+    def finish(self):
+        while not self.advance():
+            pass
+        return self.result

@@ -395,6 +395,8 @@ class ForwardPlan(object):
         return True
 
     def accepts(self, lat):
+        if getattr(lat, 'tables', None) is not None and getattr(lat, 'n_levels', 0) >= self.model.NLEV:
+            return True                                    # lattice.NativeLattice
         if not isinstance(lat, DeviceLattice) or len(lat.levels) < self.model.NLEV:
             return False
         for lv in lat.levels[:self.model.NLEV]:

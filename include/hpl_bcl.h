@@ -463,6 +463,49 @@ int hpl_plan_profile(hpl_plan *plan, int tag);
 int hpl_plan_clock_probe(hpl_plan *plan, int64_t *clock_probe);
 int hpl_plan_profile_read(hpl_plan *plan, int *launches, float *total_ms);
 
+
+/* ------------------------------------------------------------------------ *
+ * Native lattice builder: GenerateDataUnsymmetric.__call__ (transforms/transforms.py:358-485) as a state machine
+ * over the stage functions above.  One builder = one pair under construction: hpl_lattice_begin launches level 0
+ * up to the read-back of its vertex counts (they size the next arrays); hpl_lattice_advance launches the rest of
+ * that level (neighbour tables, splat CSR, row orders, per-tile index tables) and the next level up to ITS
+ * read-back, and so on.  Every table is carved out of the caller's `arena` (DEVICE, 256-byte aligned); the
+ * finished hpl_level_tables point into it.  The host never blocks unless it calls advance before ready.
+ * ------------------------------------------------------------------------ */
+#define HPL_ENOMEM (-4)   /* the arena is too small: retry with a bigger one */
+
+typedef struct hpl_lattice_spec {
+    int32_t n_levels;
+    float scale[HPL_MAX_LEVELS];                 /* scales_filter_map[k][0] */
+    int32_t bcn_radius[HPL_MAX_LEVELS];          /* [k][1] */
+    int32_t corr_filter_radius[HPL_MAX_LEVELS];  /* [k][2], -1 = no correlation at this level */
+    int32_t corr_corr_radius[HPL_MAX_LEVELS];    /* [k][3] */
+    float next_divisor[HPL_MAX_LEVELS];          /* (float)(expected_std * scale), transforms.py:462-463 */
+    int32_t wide_up[HPL_MAX_LEVELS];             /* 1: the level's Up conv runs as tap-group passes, 0: single pass, -1: both */
+    int32_t n_groups;                            /* tap groups (>= 2) and their cuts, e.g. {0, 8, 15} */
+    int32_t group_cut[5];
+    float groups_min_sparsity;                   /* groups only where H0 / n0 >= this */
+    int64_t perm_min_rows;                       /* row orders only for tables with at least this many rows */
+} hpl_lattice_spec;
+
+typedef struct hpl_lattice hpl_lattice;
+
+hpl_lattice *hpl_lattice_create(const hpl_lattice_spec *spec /* HOST */);
+void hpl_lattice_destroy(hpl_lattice *b);
+/* pc1 (3, n0), pc2 (3, n1) float32 DEVICE, must stay valid until the build is complete */
+int hpl_lattice_begin(hpl_lattice *b, const float *pc1, const float *pc2, int64_t n0, int64_t n1, void *arena,
+                      int64_t arena_bytes, hplStream stream);
+/* 1 if hpl_lattice_advance would not block (the pending read-back has landed, or the build is done), else 0 */
+int hpl_lattice_ready(hpl_lattice *b);
+/* *done = 1 once every launch of the build has been enqueued (the tables are valid for work ordered behind them
+ * on the same stream).  HPL_ENOMEM: the arena overflowed, the build is abandoned. */
+int hpl_lattice_advance(hpl_lattice *b, int *done);
+/* tables of the finished build (n_levels entries, owned by the builder, valid until its next begin) */
+const hpl_level_tables *hpl_lattice_tables(const hpl_lattice *b);
+/* extra per-level pointers the forward does not need (cloud 2's barycentric / offsets): out[2*L] = bary1,
+ * out[2*L+1] = off1; and the bytes of the arena in use */
+int hpl_lattice_extras(const hpl_lattice *b, const void **out /* HOST, 2 * n_levels */, int64_t *arena_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,64 @@ def test_reference_format_lattice_still_takes_the_python_path():
         a = m(t1[None], t2[None], lat)
         b = m(t1[None], t2[None], H.to_reference_format(lat))
     assert float((a - b).abs().max()) < 1e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize('cls,nsc,kind,n1,n2', [('HPLFlowNet', 7, 'frustum', 8192, 8192), ('HPLFlowNet', 7, 'surface', 8192, 8000),
+                                                ('HPLFlowNetShallow', 5, 'frustum', 4096, 4096), ('HPLFlowNet', 7, 'frustum', 50, 37)])
+def test_native_lattice_builder_equals_python_driver(cls, nsc, kind, n1, n2):
+    """csrc/lattice_builder.hip issues the stage calls of lattice.GenerateDataUnsymmetric.build_steps: every table of
+    every level is bit-identical (the row orders are filled with atomics and compared as permutations of equal tap
+    masks), and the forward on the native lattice equals the forward on the Python-built one."""
+    import hplflownet_amd as H
+    m, gen = make(cls, nsc)
+    pc1, pc2, sf = (surface_pair if kind == 'surface' else synthetic_pair)(max(n1, n2), 6)
+    t1 = torch.from_numpy(pc1[:n1].T.copy()).to(DEV)
+    t2 = torch.from_numpy(pc2[:n2].T.copy()).to(DEV)
+    lat_py = gen.build(t1, t2).prepare()
+    lat_nv = gen.build_native(t1, t2)
+    torch.cuda.synchronize()
+    assert lat_nv.H == [lv.H for lv in lat_py.levels]
+    a, b = H.to_reference_format(lat_nv), H.to_reference_format(lat_py)
+    for L, (x, y) in enumerate(zip(a, b)):
+        for k in y:
+            assert (torch.equal(x[k], y[k]) if torch.is_tensor(y[k]) else x[k] == y[k]), (L, k)
+    for L, (x, y) in enumerate(zip(lat_nv.levels, lat_py.levels)):
+        assert all(torch.equal(p, q) for p, q in zip(x.pair.csr(), y.pair.csr())), L
+        assert torch.equal(x.emg_pair, y.emg_pair)
+        for tx, ty in ((x.blur.pair, y.blur.pair), (x.blur[0], y.blur[0])):
+            assert (tx._perm is None) == (ty.perm is None) if tx._perm is not False else True
+            if tx._perm is not None and tx._perm is not False:
+                # same multiset of rows, and rows at the same position have the same tap mask
+                assert torch.equal(torch.sort(tx._perm)[0], torch.arange(tx.t.shape[1], device=DEV, dtype=torch.int32))
+                mask = lambda t, p: ((t.t[:, p.long()] >= 0).long() * (2 ** torch.arange(t.t.shape[0], device=DEV))[:, None]).sum(0)
+                assert torch.equal(mask(tx, tx._perm), mask(ty, ty.perm))
+    with torch.no_grad():
+        y_nv = m(t1[None], t2[None], lat_nv).clone()
+        y_py = m(t1[None], t2[None], lat_py).clone()
+        m.native_forward = False
+        y_nv_python_path = m(t1[None], t2[None], lat_nv).clone()
+        m.native_forward = True
+    assert torch.equal(y_nv, y_py) and torch.equal(y_nv_python_path, y_py)
+
+
+def test_native_lattice_pipeline_and_arena_growth():
+    import hplflownet_amd as H
+    from hplflownet_amd.lattice import LatticePipeline
+    m, gen = make('HPLFlowNetShallow', 5)
+    gen.native_builder().bytes_per_point = 40          # far too small: the builder reports HPL_ENOMEM, the arena doubles
+    sizes = [700, 64, 2000, 17]
+    pairs = []
+    for s, n in enumerate(sizes):
+        p1, p2, _ = synthetic_pair(n, 30 + s)
+        pairs.append((torch.from_numpy(p1.T.copy()).to(DEV), torch.from_numpy(p2.T.copy()).to(DEV)))
+    side = torch.cuda.Stream()
+    pipe = LatticePipeline(gen, lambda i: pairs[i], 0, len(pairs), depth=3, stream=side, native=True)
+    for want in range(len(pairs)):
+        (i, item), lat, ev = pipe.get()
+        assert i == want
+        ev.synchronize()
+        ref = H.to_reference_format(gen.build(*pairs[i]))
+        for L, (x, y) in enumerate(zip(H.to_reference_format(lat), ref)):
+            for k in y:
+                assert (torch.equal(x[k], y[k]) if torch.is_tensor(y[k]) else x[k] == y[k]), (i, L, k)
+    assert gen.native_builder().bytes_per_point > 40
