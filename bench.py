@@ -154,6 +154,43 @@ def needed_slice_fraction(tbl, C, BM=64, BK=32):
     return float(need.float().mean().item())
 
 
+def _lattice_worker(job):
+    from oracle import lattice_oracle
+    pc1, pc2, sfm = job
+    lattice_oracle.generate_data(pc1, pc2, sfm)
+    return 1
+
+
+def lattice_worker_rates(sample, sfm, workers=(8, 16)):
+    """Lattice builds per second of the C oracle with P worker PROCESSES, one build per worker at a time -- how the
+    reference parallelises this stage (DataLoader workers: configs/train_ours.yaml:61 `workers: 16`,
+    test_ours_*.yaml `workers: 8`; each Numba build is single-threaded)."""
+    import multiprocessing as mp
+    out = {}
+    pc1, pc2, _ = sample
+    ctx = mp.get_context('fork')
+    for P in workers:
+        try:
+            with ctx.Pool(P) as pool:
+                pool.map(_lattice_worker, [(pc1, pc2, sfm)] * P)            # warm: library load, page-in
+                t0 = time.time()
+                n = sum(pool.map(_lattice_worker, [(pc1, pc2, sfm)] * (4 * P)))
+                out[str(P)] = n / (time.time() - t0)
+        except Exception as e:      # (no fork, no /dev/shm ...): report, do not fail the bench
+            out[str(P)] = 'failed: %s' % e
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(samples, sfm, state_dict, shallow=False):
     """The CPU oracle on a bounded sample of the same workload (`samples`: [(pc1, pc2, sf)], about 10-30 s of CPU
     work); returns (dict, flow of the first pair, its EPE3D)."""
@@ -178,7 +215,9 @@ def cpu_baseline(samples, sfm, state_dict, shallow=False):
          'sample': '%d pairs, N=%d, %d-level lattice build (C oracle, 1 thread) + %s forward '
                    '(numpy oracle, BLAS threads = cores)' % (n, samples[0][0].shape[0], len(sfm),
                                                              'HPLFlowNetShallow' if shallow else 'full HPLFlowNet'),
-         'lattice_s': t_lat / n, 'forward_s': t_fwd / n, 'host_cpus': os.cpu_count()}
+         'lattice_s': t_lat / n, 'forward_s': t_fwd / n, 'host_cpus': os.cpu_count(), 'cpu_model': cpu_model(),
+         # the lattice stage alone with P worker processes, as the reference's DataLoader runs it
+         'lattice_pairs_per_s_by_workers': dict({'1': n / t_lat}, **lattice_worker_rates(samples[0], sfm))}
     return d, flow0, bcl_oracle.epe3d(flow0, samples[0][2].T)
 
 

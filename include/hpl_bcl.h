@@ -197,7 +197,8 @@ int hpl_tap_order(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int3
 
 /* Per-tile gather indices of a row-ordered launch: tile j covers output rows row_perm[j*BM .. j*BM+BM) (identity
  * when row_perm is NULL); tile_idx[j][f][r] = nbr[f][row_perm[j*BM + r]] (-1 past M), tile_mask[j][0] = taps present
- * in the tile, [2 + b] = taps present in its b-th block of 32 rows ([1] and the rest 0).  Sizes: ceil(M/BM)*F*BM and
+ * in the tile, [2 + b] = taps present in its b-th block of 32 rows, [j][6] = the tile that is scheduled j-th (most taps
+ * first: a launch's workgroups then finish within one light tile of each other), the rest 0.  Sizes: ceil(M/BM)*F*BM and
  * ceil(M/BM)*8 int32.  Built once per lattice and row order (models/bilateralNN.py:215-217 gathers through the same
  * table in every layer call). */
 int hpl_tile_index(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, const int32_t *row_perm, int BM,
@@ -211,6 +212,12 @@ int hpl_tile_index(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, con
  * (bnn_flow.py:189-202) and the displacement filter Conv2d((15,1))
  * (bnn_flow.py:205).  The gathered tensor is never materialised. */
 int hpl_gconv_forward(const hpl_gconv_desc *desc /* HOST */, hplStream stream);
+/* Tuning knob: how the big row-ordered launches (row_perm + tile tables, 64 x 128 tiles) are scheduled.  0 (default;
+ * env HPL_PERSISTENT) = one tile per workgroup, heaviest tiles first; 1 = persistent workgroups pulling tiles from one
+ * queue per XCD, the next tile's prologue overlapped with the current tile's main loop (measured slower, see
+ * csrc/gconv.hip); 2 = persistent for every launch that can.  Results are identical in all modes.  Returns the
+ * previous mode. */
+int hpl_set_persistent(int mode);
 /* same contract, one thread per output element, no MFMA: test/debug reference only */
 int hpl_gconv_forward_naive(const hpl_gconv_desc *desc /* HOST */, hplStream stream);
 

@@ -26,7 +26,8 @@ for name, lvl, C, O in (('bcn1_ blur', 0, 580, 1024), ('bcn2_ blur', 1, 324, 512
         groups = tbl.groups()
         y = torch.empty(M, O, device=dev)
         with torch.no_grad():
-            fn = lambda: ops.gconv(A, W, None, tbl.t, M, F, row_perm=tbl.perm, tap_groups=groups, out=y)
+            fn = lambda: ops.gconv(A, W, None, tbl.t, M, F, row_perm=tbl.perm if not groups else None, tap_groups=groups, out=y,
+                                   tiles=tbl.group_tiles() if groups else tbl.perm_tiles)
             fn(); torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
