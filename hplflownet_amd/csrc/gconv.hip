@@ -1182,28 +1182,31 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
 namespace {
 // hpl_tile_index: per 64-row (BM) tile of a tap-ordered launch, the source row of every (tap, tile row) -- what the
 // prologue of k_gconv would gather through row_perm and nbr -- and the tile's tap-presence masks.
-__global__ void k_tile_index(const int32_t *__restrict__ nbr, int64_t stride, int F, int64_t M,
-                             const int32_t *__restrict__ perm, int BM, int32_t *__restrict__ tile_idx,
-                             int32_t *__restrict__ tile_mask) {
+__global__ void __launch_bounds__(256) k_tile_index(const int32_t *__restrict__ nbr, int64_t stride, int F, int64_t M,
+                                                    const int32_t *__restrict__ perm, int BM, int32_t *__restrict__ tile_idx,
+                                                    int32_t *__restrict__ tile_mask) {
     __shared__ int masks[8];
     const int t = threadIdx.x;
     if (t < 8) masks[t] = 0;
     __syncthreads();
     const int64_t tile = blockIdx.x, m0 = tile * BM;
     int32_t *out = tile_idx + tile * F * BM;
-    for (int i = t; i < F * BM; i += blockDim.x) {
-        const int f = i / BM, r = i - f * BM;
-        const int64_t m = m0 + r;
-        int row = -1;
-        if (m < M) {
-            const int v = perm ? perm[m] : (int)m;
-            row = nbr[(int64_t)f * stride + v];
-        }
-        out[i] = row;
-        if (row >= 0) {
-            atomicOr(&masks[0], 1 << f);
-            atomicOr(&masks[2 + (r >> 5)], 1 << f);
-        }
+    // 256 threads, BM = 64 or 128: a thread keeps its tile row r = t % BM for every tap it handles (256 % BM == 0), so
+    // it collects its taps in a register; the 32 lanes of a half-wave are the 32 rows of one block
+    const int r = t % BM;
+    const int64_t m = m0 + r;
+    const int v = (m < M) ? (perm ? perm[m] : (int)m) : -1;
+    int mybits = 0;
+    for (int f = t / BM; f < F; f += 256 / BM) {
+        const int row = (v >= 0) ? nbr[(int64_t)f * stride + v] : -1;
+        out[f * BM + r] = row;
+        mybits |= (row >= 0) ? (1 << f) : 0;
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) mybits |= __shfl_xor(mybits, o, 64);       // OR over the 32 lanes of each half-wave
+    if ((t & 31) == 0 && mybits) {
+        atomicOr(&masks[0], mybits);
+        atomicOr(&masks[2 + (r >> 5)], mybits);
     }
     __syncthreads();
     if (t < 8) tile_mask[tile * 8 + t] = masks[t];

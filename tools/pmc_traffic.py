@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""HBM-side traffic of the dominant gather-GEMM from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd .db):
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_write/w_results.db profiles/pmc_traffic.json
+Per MI355X_MICROARCH.md (HBM section): the counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide
+coalesced reads, so the read side is doubled; WRITE_SIZE is taken as is."""
+import json
+import sqlite3
+import sys
+
+DOMINANT = 'k_gconv<64, 128, 2, 4, true, 15>'
+
+
+def per_launch(db, ctr):
+    c = sqlite3.connect(db)
+    rows = c.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by 1",
+                     (ctr,)).fetchall()
+    return {k: (n, v) for k, n, v in rows}
+
+
+def main():
+    fdb, wdb, out = sys.argv[1:4]
+    f, w = per_launch(fdb, 'FETCH_SIZE'), per_launch(wdb, 'WRITE_SIZE')
+    fk = [k for k in f if DOMINANT in k][0]
+    wk = [k for k in w if DOMINANT in k][0]
+    fetch_kib, write_kib = f[fk][1], w[wk][1]
+    total = int((2 * fetch_kib + write_kib) * 1024)
+    try:
+        old = json.load(open(out))
+    except Exception:
+        old = {}
+    hist = old.get('history', {})
+    if 'k_gconv_64x128_bytes_per_launch' in old:
+        hist['round_1_final'] = old['k_gconv_64x128_bytes_per_launch']
+    d = {'_comment': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `python bench.py '
+                     '--steps 3 --warmup 1 --no-cpu-baseline --no-overlap` (tools/pmc_traffic.py). Per launch of '
+                     'k_gconv<64,128,2,4,true,15>, averaged over its four launches per step. Counter unit KiB; FETCH_SIZE '
+                     'doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane reads), WRITE_SIZE as is.',
+         'fetch_size_kib_per_launch_raw': fetch_kib, 'write_size_kib_per_launch': write_kib, 'launches_fetch_pass': f[fk][0],
+         'k_gconv_64x128_bytes_per_launch': total, 'algorithmic_bytes_per_launch': 82000000, 'history': hist,
+         'note': 'fetch >> algorithmic: L2-miss traffic of the gathered activation rows (every column tile re-gathers its '
+                 'tile-row from the 60 MB matrix, which lives in the 256 MB Infinity Cache); the weight panels are shared in '
+                 'L2 by the column-major XCD order. The kernel is matrix-pipe bound at the clock the chip sustains; see '
+                 'DESIGN.md section 4.'}
+    json.dump(d, open(out, 'w'), indent=1)
+    print(json.dumps({k: d[k] for k in ('fetch_size_kib_per_launch_raw', 'write_size_kib_per_launch', 'k_gconv_64x128_bytes_per_launch')}))
+    for name, tab in (('FETCH_SIZE', f), ('WRITE_SIZE', w)):
+        for k, (n, v) in sorted(tab.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:8]:
+            print('%-90s %-11s %6d %14.1f' % (k[:90], name, n, v))
+
+
+if __name__ == '__main__':
+    main()
