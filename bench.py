@@ -234,6 +234,8 @@ def main():
                     help='build each lattice on the main stream instead of a second stream overlapping the previous forward')
     ap.add_argument('--streams', type=int, default=3,
                     help='HIP streams the forwards of consecutive pairs alternate over (pairs in flight)')
+    ap.add_argument('--lattice-streams', type=int, default=1,
+                    help='HIP streams the lattice builds of consecutive pairs alternate over')
     ap.add_argument('--lattice-depth', type=int, default=2,
                     help='pairs whose lattice is under construction at once on the lattice stream (1: block on every '
                          'read-back of vertex counts)')
@@ -242,6 +244,8 @@ def main():
     ap.add_argument('--data', default='frustum', choices=['frustum', 'surface'],
                     help='frustum: the uniform FT3D-like frustum of SURVEY.md 8(d1) (the headline workload); surface: points on '
                          'smooth patches, the dense extreme (few lattice vertices per point)')
+    ap.add_argument('--no-lattice-thread', action='store_true',
+                    help='run the native lattice builds on the main host thread instead of a producer thread')
     ap.add_argument('--python-lattice', action='store_true',
                     help='drive the lattice build stage by stage from Python instead of the native builder')
     ap.add_argument('--python-forward', action='store_true',
@@ -333,7 +337,8 @@ def main():
     overlap = not (a.no_lattice or a.no_overlap)
     # HPL_PRIO: which stream gets the high hardware-queue priority ('lattice' | 'forward' | 'none')
     prio = os.environ.get('HPL_PRIO', 'lattice')
-    side = torch.cuda.Stream(device=dev, priority=-1 if prio == 'lattice' else 0) if overlap else None
+    side = [torch.cuda.Stream(device=dev, priority=-1 if prio == 'lattice' else 0) for _ in range(max(1, a.lattice_streams))] \
+        if overlap else None
     # forwards of consecutive pairs alternate over a.streams HIP streams: the launch-bound deep levels of
     # one pair run in the shadow of the big GEMMs of another (measured: 1: 144, 2: 163, 3: 173, 4: 160 pairs/s)
     n_fwd = max(1, a.streams) if not a.train else 1
@@ -350,7 +355,8 @@ def main():
         from hplflownet_amd.lattice import LatticePipeline
 
         pipe = LatticePipeline(gen, lambda i: pairs[i % a.pool], first, count, depth=a.lattice_depth, stream=side,
-                               for_training=a.train, native=native and not a.python_lattice)
+                               for_training=a.train, native=native and not a.python_lattice,
+                               threaded=native and not a.python_lattice and not a.no_lattice_thread)
 
         def build():
             t = time.perf_counter()
@@ -565,7 +571,8 @@ def main():
                            'lattices_under_construction': a.lattice_depth if overlap else 1,
                            'forward_streams': n_fwd if overlap else 1,
                            'forward_issue': 'one native hpl_plan_run per pair' if native else 'python, launch by launch',
-                           'lattice_issue': 'native builder (hpl_lattice_*)' if (native and not a.python_lattice and overlap) else 'python, stage by stage',
+                           'lattice_issue': ('native builder (hpl_lattice_*)' + ('' if a.no_lattice_thread else ' on a producer thread'))
+                           if (native and not a.python_lattice and overlap) else 'python, stage by stage',
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,

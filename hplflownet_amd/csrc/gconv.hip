@@ -1149,6 +1149,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
         const std::string f(force);
         if (f == "128x128") launch_cfg<128, 128, 2, 4>(p, avec, s);
         else if (f == "128x128w4") launch_cfg<128, 128, 2, 2>(p, avec, s);
+        else if (f == "128x128w16") launch_cfg<128, 128, 4, 4>(p, avec, s);
         else if (f == "64x128") launch_cfg<64, 128, 2, 2>(p, avec, s);
         else if (f == "64x128w8") launch_cfg<64, 128, 2, 4>(p, avec, s);
         else if (f == "128x64") launch_cfg<128, 64, 2, 2>(p, avec, s);

@@ -143,7 +143,7 @@ class Trainer(object):
         current one is consumed, and the host never blocks on their vertex-count read-backs."""
         main = torch.cuda.current_stream(self.device)
         pipe = LatticePipeline(self.gen, lambda k: data[order[k]], 0, len(order), depth=depth, stream=self._side,
-                               for_training=training)
+                               for_training=training, native=not training)      # inference: native builder + native forward
         keep = collections.deque()
         for _ in range(len(order)):
             (_, sample), lat, ev = pipe.get()

@@ -210,25 +210,60 @@ class LatticePipeline(object):
     pair whose counts have already landed until the oldest is complete, and blocks only when no pair can
     move."""
 
-    def __init__(self, gen, source, first, count, depth=2, stream=None, for_training=False, native=False):
+    def __init__(self, gen, source, first, count, depth=2, stream=None, for_training=False, native=False, threaded=False):
         self.native = native            # builds driven by csrc/lattice_builder.hip (NativeLatticeBuild)
         self.gen, self.source, self.depth = gen, source, max(1, int(depth))
-        self.stream, self.for_training = stream, for_training
+        # `stream` may be a list: consecutive pairs are built on alternating streams, so the launch-latency chains of
+        # two builds (each ~1 ms of dependent small kernels) overlap on the GPU instead of queueing on one stream
+        self.streams = list(stream) if isinstance(stream, (list, tuple)) else [stream]
+        self.stream, self.for_training = self.streams[0], for_training
         self._next, self._end = first, first + count
+        self._first, self._handed = first, 0
         self._inflight = collections.deque()
+        # threaded: a producer thread runs the builds (the reference runs them in DataLoader worker processes,
+        # main.py:85-92).  The native builder spends its time inside C calls, which ctypes makes with the GIL released, so
+        # the consumer's forward enqueue (also one C call) overlaps it on a second core.
+        self._thread = self._queue = None
+        if threaded and count > 0:
+            import queue
+            import threading
+            self._queue = queue.Queue(maxsize=self.depth)
+            dev = torch.cuda.current_device()
+
+            def produce():
+                try:
+                    torch.cuda.set_device(dev)
+                    for _ in range(count):
+                        self._queue.put(self._get())
+                except BaseException as e:          # noqa: B902 -- handed to the consumer
+                    self._queue.put(e)
+            self._thread = threading.Thread(target=produce, name='hpl-lattice', daemon=True)
+            self._thread.start()
 
     def _top_up(self):
         while len(self._inflight) < self.depth and self._next < self._end:
-            with torch.cuda.stream(self.stream):        # a reader's host-to-device copies belong to this stream too
+            st = self.streams[self._next % len(self.streams)]
+            with torch.cuda.stream(st):                 # a reader's host-to-device copies belong to this stream too
                 item = self.source(self._next)
             cls = NativeLatticeBuild if self.native else LatticeBuild
-            b = cls(self.gen, item[0], item[1], self.stream, self.for_training, tag=(self._next, item))
+            b = cls(self.gen, item[0], item[1], st, self.for_training, tag=(self._next, item))
             if not self.native:
                 b.advance()
             self._inflight.append(b)
             self._next += 1
 
     def get(self):
+        if self._queue is not None:
+            if self._handed >= self._end - self._first:
+                raise StopIteration('all %d lattices were handed out' % self._end)
+            item = self._queue.get()
+            if isinstance(item, BaseException):
+                raise item
+            self._handed += 1
+            return item
+        return self._get()
+
+    def _get(self):
         self._top_up()
         if not self._inflight:
             raise StopIteration('all %d lattices were handed out' % self._end)

@@ -166,3 +166,34 @@ def test_native_lattice_pipeline_and_arena_growth():
             for k in y:
                 assert (torch.equal(x[k], y[k]) if torch.is_tensor(y[k]) else x[k] == y[k]), (i, L, k)
     assert gen.native_builder().bytes_per_point > 40
+
+
+def test_threaded_native_lattice_pipeline():
+    """The producer-thread form of the pipeline hands out the same lattices, in order, and surfaces errors."""
+    import hplflownet_amd as H
+    from hplflownet_amd.lattice import LatticePipeline
+    m, gen = make('HPLFlowNetShallow', 5)
+    pairs = []
+    for s_, n in enumerate([900, 300, 1500, 64, 700]):
+        p1, p2, _ = synthetic_pair(n, 50 + s_)
+        pairs.append((torch.from_numpy(p1.T.copy()).to(DEV), torch.from_numpy(p2.T.copy()).to(DEV)))
+    side = torch.cuda.Stream()
+    pipe = LatticePipeline(gen, lambda i: pairs[i], 0, len(pairs), depth=2, stream=side, native=True, threaded=True)
+    outs = []
+    with torch.no_grad():
+        for want in range(len(pairs)):
+            (i, item), lat, ev = pipe.get()
+            assert i == want and item is pairs[i]
+            torch.cuda.current_stream().wait_event(ev)
+            outs.append(m(item[0][None], item[1][None], lat).clone())
+    with pytest.raises(StopIteration):
+        pipe.get()
+    with torch.no_grad():
+        for i, (a, b) in enumerate(pairs):
+            assert torch.equal(outs[i], m(a[None], b[None], gen.build(a, b)))
+
+    def bad(i):
+        raise ValueError('no such pair')
+    pipe = LatticePipeline(gen, bad, 0, 2, depth=2, stream=side, native=True, threaded=True)
+    with pytest.raises(ValueError):
+        pipe.get()
