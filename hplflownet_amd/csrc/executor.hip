@@ -129,6 +129,7 @@ struct Runner {
 
     void bracket(bool on, bool stop) {
         if (!on) return;
+        if (pl.pool_used >= (size_t)1 << 16) return;          // a profile nobody reads: stop recording (pairs stay aligned: even cap)
         if (pl.pool_used == pl.pool.size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return;

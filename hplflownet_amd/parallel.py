@@ -28,7 +28,8 @@ def init_distributed(backend=None, device=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        # HPL_DIST_BACKEND: override (e.g. gloo for a functional run of several ranks on ONE GPU, which RCCL refuses)
+        backend = os.environ.get('HPL_DIST_BACKEND') or backend or ('nccl' if torch.cuda.is_available() else 'gloo')
         kw = {}
         if backend == 'nccl' and device is not None:
             kw['device_id'] = device

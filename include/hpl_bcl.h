@@ -449,7 +449,7 @@ typedef struct hpl_level_tables {
     const int32_t *corr1_perm_tidx, *corr1_perm_tmask;
 } hpl_level_tables;
 
-typedef struct hpl_plan hpl_plan;
+typedef struct hpl_plan hpl_plan;   /* not thread-safe: one thread runs a given plan at a time (any number of streams) */
 
 /* HOST arrays, copied.  The weight images and biases must stay alive (and may be refreshed in place). */
 hpl_plan *hpl_plan_create(const hpl_op *ops, int n_ops, const hpl_buf *bufs, int n_bufs,
@@ -495,7 +495,7 @@ typedef struct hpl_lattice_spec {
     int64_t perm_min_rows;                       /* row orders only for tables with at least this many rows */
 } hpl_lattice_spec;
 
-typedef struct hpl_lattice hpl_lattice;
+typedef struct hpl_lattice hpl_lattice;   /* one pair under construction per builder; use several builders to overlap pairs */
 
 hpl_lattice *hpl_lattice_create(const hpl_lattice_spec *spec /* HOST */);
 void hpl_lattice_destroy(hpl_lattice *b);
