@@ -82,13 +82,15 @@ class KernelTimers(object):
             # suffix: g = gathered (15-tap stencil, template F_LDS=15), d = dense (F_LDS=1)
             return ('gconv_%s_%s' % (gconv_class(M, N, F * C), 'g' if F > 1 else 'd'), 2.0 * M * F * C * N, 0.0)
 
+        # the HBM-bound gathers by lattice size: levels 0-2 of the N=8192 frustum move 10-140 MB per launch, the deeper
+        # levels < 1 MB (pure launch latency) -- one class each, so that the big ones are not averaged away
         def d_splat(feat, csr, H, use_norm=True, out=None):
             N, C = feat.shape
-            return ('splat', 0.0, 4.0 * C * N + 32.0 * N + 4.0 * (C + 1) * (H + 1))
+            return ('splat' if H >= 8192 else 'splat_deep', 0.0, 4.0 * C * N + 32.0 * N + 4.0 * (C + 1) * (H + 1))
 
         def d_slice(Y, bary, off, N, vscale=None, bias=None, out=None):
             H, C = Y.shape
-            return ('slice', 0.0, 4.0 * C * H + 32.0 * N + 4.0 * C * N)
+            return ('slice' if H >= 8192 else 'slice_deep', 0.0, 4.0 * C * H + 32.0 * N + 4.0 * C * N)
 
         ops.gconv_raw = wrap(ops.gconv_raw, d_gconv)
         ops.splat_raw = wrap(ops.splat_raw, d_splat)
@@ -244,8 +246,10 @@ def main():
     ap.add_argument('--data', default='frustum', choices=['frustum', 'surface'],
                     help='frustum: the uniform FT3D-like frustum of SURVEY.md 8(d1) (the headline workload); surface: points on '
                          'smooth patches, the dense extreme (few lattice vertices per point)')
-    ap.add_argument('--no-lattice-thread', action='store_true',
-                    help='run the native lattice builds on the main host thread instead of a producer thread')
+    ap.add_argument('--lattice-thread', action='store_true',
+                    help='run the native lattice builds on a producer host thread (the builder spends its time in C calls made '
+                         'with the GIL released): pays when the step is host-bound (shallow model N=4096: 896 -> 942 pairs/s), '
+                         'costs ~2 %% of jitter when it is GPU-bound (the default workload)')
     ap.add_argument('--python-lattice', action='store_true',
                     help='drive the lattice build stage by stage from Python instead of the native builder')
     ap.add_argument('--python-forward', action='store_true',
@@ -356,7 +360,7 @@ def main():
 
         pipe = LatticePipeline(gen, lambda i: pairs[i % a.pool], first, count, depth=a.lattice_depth, stream=side,
                                for_training=a.train, native=native and not a.python_lattice,
-                               threaded=native and not a.python_lattice and not a.no_lattice_thread)
+                               threaded=native and not a.python_lattice and a.lattice_thread)
 
         def build():
             t = time.perf_counter()
@@ -555,6 +559,13 @@ def main():
                 roofline['traffic'] = json.load(open(prof)).get('k_gconv_64x128_bytes_per_launch')
             except Exception:
                 pass
+        try:        # measured HBM-side bytes per launch of the splat / slice kernels (profiles/pmc_traffic.json, PMC passes)
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            for nm in ('splat', 'slice'):
+                if nm in kernels and full and pj.get('k_%s_bytes_per_launch_all_levels' % nm):
+                    kernels[nm]['traffic_all_levels_avg'] = pj['k_%s_bytes_per_launch_all_levels' % nm]
+        except Exception:
+            pass
         if dominant in kernels and roofline.get('executed_fraction') is not None and kernels[dominant].get('achieved'):
             kd = kernels[dominant]           # same convention in the per-class table: frac = executed, <= 1
             kd['achieved_algorithmic'], kd['frac_algorithmic'] = kd['achieved'], kd['frac']
@@ -571,7 +582,7 @@ def main():
                            'lattices_under_construction': a.lattice_depth if overlap else 1,
                            'forward_streams': n_fwd if overlap else 1,
                            'forward_issue': 'one native hpl_plan_run per pair' if native else 'python, launch by launch',
-                           'lattice_issue': ('native builder (hpl_lattice_*)' + ('' if a.no_lattice_thread else ' on a producer thread'))
+                           'lattice_issue': ('native builder (hpl_lattice_*)' + (' on a producer thread' if a.lattice_thread else ''))
                            if (native and not a.python_lattice and overlap) else 'python, stage by stage',
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},

@@ -41,6 +41,12 @@ def main():
                  'tile-row from the 60 MB matrix, which lives in the 256 MB Infinity Cache); the weight panels are shared in '
                  'L2 by the column-major XCD order. The kernel is matrix-pipe bound at the clock the chip sustains; see '
                  'DESIGN.md section 4.'}
+    for nm in ('k_splat', 'k_slice'):       # the HBM-bound gathers: average over all their launches of a step (all levels)
+        fk2 = [k for k in f if nm in k]
+        wk2 = [k for k in w if nm in k]
+        if fk2 and wk2:
+            d['%s_bytes_per_launch_all_levels' % nm] = int((2 * f[fk2[0]][1] + w[wk2[0]][1]) * 1024)
+            d['%s_launches' % nm] = f[fk2[0]][0]
     json.dump(d, open(out, 'w'), indent=1)
     print(json.dumps({k: d[k] for k in ('fetch_size_kib_per_launch_raw', 'write_size_kib_per_launch', 'k_gconv_64x128_bytes_per_launch')}))
     for name, tab in (('FETCH_SIZE', f), ('WRITE_SIZE', w)):
