@@ -77,6 +77,13 @@ __device__ __forceinline__ int32x4_t make_rsrc(const void *base, int bytes) {
 }
 
 constexpr int BK = 32;   // contraction slice per step (floats) = one 128-byte line per gathered row
+// -DHPL_PROLOGUE_PRIO=1: s_setprio(3) over the tile prologue.  Measured (profiles/r02w_prologue_prio.txt): the prologue
+// shrinks 21 k -> 15 k cycles and the co-resident workgroup's loop slows by the same amount (the matrix pipe is shared:
+// zero-sum), kernel time unchanged -> off.
+#ifndef HPL_PROLOGUE_PRIO
+#define HPL_PROLOGUE_PRIO 0
+#endif
+constexpr bool PROLOGUE_PRIO = HPL_PROLOGUE_PRIO != 0;
 
 struct GParams {
     const float *A; int64_t lda; int64_t rows_a;
@@ -218,6 +225,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
         probe_c = (long long)__builtin_readcyclecounter();
         probe_w = (long long)__builtin_amdgcn_s_memrealtime();
     }
+    // the few hundred instructions of the prologue compete for issue slots with the co-resident workgroup's main loop
+    // (older waves win the arbitration): run them at raised priority, back to 0 before the main loop
+    if (PROLOGUE_PRIO) __builtin_amdgcn_s_setprio(3);
 #ifdef HPL_TIMING
     HPL_T(0, __builtin_readcyclecounter());
     HPL_T(6, __builtin_amdgcn_s_memrealtime());                                   // 100 MHz wall clock at start
@@ -530,6 +540,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
 #endif
         cur ^= 1;
     };
+    if (PROLOGUE_PRIO) __builtin_amdgcn_s_setprio(0);
     HPL_T(1, __builtin_readcyclecounter());
     HPL_T(4, nsl);
     {
