@@ -182,12 +182,14 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
     tn = in_band / rows_in_band;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool AVEC, int F_LDS>
-__global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
+// COMPACT: the LDS budget of a third workgroup per CU (160 KiB / 3 = 54 613 B): A rows padded by 1 instead of 2 floats
+// (the transposing store stays conflict-free: bank = 4*kq + r over kq < 8, r < 4), slice list of 512 entries (K <= 16 384).
+template <int BM, int BN, int WGM, int WGN, bool AVEC, int F_LDS, bool COMPACT = false>
+__global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const GParams p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int LDA_S = BM + 2;   // +2: the transposing ds_write_b32 of 8 lanes x 4 k stay <= 2-way
+    constexpr int LDA_S = COMPACT ? BM + 1 : BM + 2;   // +2: the transposing ds_write_b32 of 8 lanes x 4 k stay <= 2-way
     constexpr int LDB_S = BN;
     constexpr int A_ROWS_PER_PASS = NT / 8;              // 8 float4 per gathered row slice
     constexpr int A_PASSES = BM / A_ROWS_PER_PASS;
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_gconv(const GParams p) {
     // one LDS array (A ring | B ring | neighbour indices of this tile, [F][BM] ints)
     // + output row of every tile row [BM] + the tile's tap mask [1])
     // + list of the contraction slices this tile needs [KLIST ushort])
-    constexpr int KLIST = 1024;
+    constexpr int KLIST = COMPACT ? 512 : 1024;
     static_assert(NT % BM == 0 && BM / 32 <= 4, "a thread stages indices of one 32-row block only");
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA_S + 2 * BK * LDB_S + F_LDS * BM + BM + 8 + KLIST / 2];
     float *As = smem;
@@ -1132,6 +1134,17 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
         if (pers && avec && p.F > 1 && p.tile_idx && p.col_share > 0 && p.splits == 1 && !p.scat &&
             (tiles >= 1024 || pers == 2) && launch_persistent(p, s))
             return;
+    }
+    if constexpr (BM == 64 && BN == 128 && WGM == 2 && WGN == 4) {
+        // three workgroups per CU (COMPACT LDS budget, 52.8 KB) for the tap-group passes of the big stencil launches: a
+        // third workgroup covers the dispatch gaps and prologues of the other two -- slots occupied 0.91 -> 0.93 of 768,
+        // dominant launch 816 -> 789 us alone (profiles/r02y_wg3.txt); in the three-stream pipeline the throughput is
+        // unchanged (the GPU is matrix-pipe bound there).  HPL_WG3=0 switches it off.
+        static const int wg3 = getenv("HPL_WG3") ? atoi(getenv("HPL_WG3")) : 1;
+        if (wg3 && avec && p.F > 1 && p.F <= 8 && nk <= 512 && p.splits == 1) {      // (a tap group: <= 8 taps staged)
+            k_gconv<BM, BN, WGM, WGN, true, 8, true><<<grid, 64 * WGM * WGN, 0, s>>>(p);
+            return;
+        }
     }
     // F_LDS = taps whose indices are staged in LDS: 1 for dense GEMMs, 15 for the radius-1 stencil
     if (p.F == 1) {
