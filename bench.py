@@ -472,8 +472,8 @@ def main():
     if rank == 0:
         roofline = {'bound': 'mfma', 'achieved': dom.get('achieved'), 'peak': MFMA_F32_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': dom.get('frac'), 'traffic': None,
-                    'kernel': ('k_gconv<64,128,2,4,true,15> (fp32-MFMA gather-GEMM, 15-tap stencil: blur convs of '
-                               'bcn1_/bcn2_)') if full else 'k_gconv, class %s (fp32-MFMA gather-GEMM)' % dominant,
+                    'kernel': ('k_gconv<64,128,2,4,true,8,COMPACT> (fp32-MFMA gather-GEMM, 64x128 tiles, 8 waves, 3 workgroups per CU: '
+                               'blur convs of bcn1_/bcn2_ as two tap-group passes each)') if full else 'k_gconv, class %s (fp32-MFMA gather-GEMM)' % dominant,
                     'measured_mfma_ceiling': ceiling,
                     'launches_per_step': dom.get('launches_per_step'), 'avg_launch_us': dom.get('avg_launch_us'),
                     'gflop_per_step': dom.get('gflop_per_step')}

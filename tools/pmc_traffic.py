@@ -7,7 +7,8 @@ import json
 import sqlite3
 import sys
 
-DOMINANT = 'k_gconv<64, 128, 2, 4, true, 15>'
+import re
+DOMINANT = re.compile(r'k_gconv<64, 128, 2, 4, true, (8|15)\b')      # the stencil instances of the 64 x 128 class
 
 
 def per_launch(db, ctr):
@@ -20,8 +21,8 @@ def per_launch(db, ctr):
 def main():
     fdb, wdb, out = sys.argv[1:4]
     f, w = per_launch(fdb, 'FETCH_SIZE'), per_launch(wdb, 'WRITE_SIZE')
-    fk = [k for k in f if DOMINANT in k][0]
-    wk = [k for k in w if DOMINANT in k][0]
+    fk = max((k for k in f if DOMINANT.search(k)), key=lambda k: f[k][0] * f[k][1])
+    wk = max((k for k in w if DOMINANT.search(k)), key=lambda k: w[k][0] * w[k][1])
     fetch_kib, write_kib = f[fk][1], w[wk][1]
     total = int((2 * fetch_kib + write_kib) * 1024)
     try:
@@ -33,7 +34,7 @@ def main():
         hist['round_1_final'] = old['k_gconv_64x128_bytes_per_launch']
     d = {'_comment': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `python bench.py '
                      '--steps 3 --warmup 1 --no-cpu-baseline --no-overlap` (tools/pmc_traffic.py). Per launch of '
-                     'k_gconv<64,128,2,4,true,15>, averaged over its four launches per step. Counter unit KiB; FETCH_SIZE '
+                     'the dominant k_gconv<64,128,2,4,true,...> stencil instance, averaged over its four launches per step. Counter unit KiB; FETCH_SIZE '
                      'doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane reads), WRITE_SIZE as is.',
          'fetch_size_kib_per_launch_raw': fetch_kib, 'write_size_kib_per_launch': write_kib, 'launches_fetch_pass': f[fk][0],
          'k_gconv_64x128_bytes_per_launch': total, 'algorithmic_bytes_per_launch': 82000000, 'history': hist,
