@@ -223,6 +223,18 @@ def cpu_baseline(samples, sfm, state_dict, shallow=False):
     return d, flow0, bcl_oracle.epe3d(flow0, samples[0][2].T)
 
 
+def host_report(host, steps):
+    """Host wall time per step inside the timed loop, and how much of it was the thread sitting idle because the
+    GPU is the limiter (waiting for a lattice's vertex counts / for a free workspace slot): busy_ms is what the
+    host would need per step if the GPU were infinitely fast."""
+    from hplflownet_amd import lattice as lat_mod, plan as plan_mod
+    d = {k: v / steps for k, v in host.items()}
+    d['lattice_wait_ms'] = lat_mod.WAIT['s'] * 1e3 / steps
+    d['forward_wait_ms'] = plan_mod.WAIT['s'] * 1e3 / steps
+    d['busy_ms'] = d['lattice_build_ms'] + d['forward_enqueue_ms'] - d['lattice_wait_ms'] - d['forward_wait_ms']
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -412,6 +424,8 @@ def main():
         timers.enabled = True
         timers.only = {dominant}
         host = dict.fromkeys(host, 0.0)
+        from hplflownet_amd import lattice as _lat_mod, plan as _plan_mod
+        _lat_mod.WAIT['s'] = _plan_mod.WAIT['s'] = 0.0
         plan = model.forward_plan() if native else None
         if plan is not None:
             from hplflownet_amd.plan import TAG_WIDE_BLUR
@@ -528,6 +542,12 @@ def main():
                         % pj['dominant_executed_gflop_per_launch']
                     roofline['executed_fraction_host_mirror'] = roofline.get('executed_fraction')
                     roofline['executed_fraction'] = share
+                    if pj.get('executed_gflop_per_step') and not a.train:
+                        # the whole step against the same roofline: every kernel's executed MFMA flops (PMC) / step time
+                        tf = pj['executed_gflop_per_step'] / (elapsed / a.steps * 1e3)        # GF / ms, per GPU
+                        roofline['whole_step'] = {'executed_gflop': pj['executed_gflop_per_step'], 'achieved': tf,
+                                                  'frac': tf / MFMA_F32_PEAK_TFLOPS,
+                                                  'note': 'all MFMA kernels of one pair (PMC) / ms_per_step, per GPU'}
                 except Exception:
                     pass
             if not full:
@@ -587,7 +607,7 @@ def main():
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,
-                'host_ms_per_step': {k: v / a.steps for k, v in host.items()} if overlap else None,
+                'host_ms_per_step': host_report(host, a.steps) if overlap else None,
                 'pipelined_output_check': pipe_check}
         if world == 1 and not a.no_cpu_baseline and not a.train:
             p1, p2, sf = pairs_np[0]

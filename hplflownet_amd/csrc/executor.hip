@@ -14,8 +14,8 @@ using namespace hpl;
 
 namespace {
 
-constexpr int64_t SPLITK_ELEMS = 1 << 20;          // ops.py: split-K only for outputs of <= 1 M elements
-constexpr int64_t SPLITK_WS_BYTES = 64ll << 20;    // 16 splits x 1 M floats
+constexpr int64_t SPLITK_ELEMS = 8 << 20;          // ops.py: split-K only for outputs of <= 8 M elements
+constexpr int64_t SPLITK_WS_BYTES = 256ll << 20;   // 64 M floats of partial tiles (the launch fits its split count)
 constexpr int MAX_SYMS = HPL_SYM_LEVEL0 + 8 * HPL_MAX_LEVELS;
 
 __global__ void k_copy_cols(const float *__restrict__ src, int64_t lds, float *__restrict__ dst, int64_t ldd,

@@ -17,6 +17,7 @@
 // Roofline: MFMA fp32 (157.3 TFLOP/s); flops = 2*M*F*C*N.
 #include "common.h"
 #include <cstdlib>
+#include <cmath>
 #include <string>
 
 #include <stdlib.h>
@@ -435,7 +436,23 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
     const int nlist = __builtin_amdgcn_readfirstlane(tapmask_s[1]);
     // split-K (small M): this workgroup handles slices [lo, hi) of the list and writes a partial tile
     const int split = p.splits > 1 ? blockIdx.x / (p.tiles_m * p.tiles_n) : 0;    // (a rounded-up grid has splits == 1)
-    const int lo = (int)((int64_t)nlist * split / p.splits), hi_i = (int)((int64_t)nlist * (split + 1) / p.splits);
+    // The cut points are slice INDICES (split s owns slices s*nk/splits .. (s+1)*nk/splits of the full K range, whatever
+    // this tile's list keeps of them): a row's partial sums then cover the same k ranges in every tile it can land in,
+    // so the result does not depend on the row order (which the lattice build fills with atomics).
+    int lo = 0, hi_i = nlist;
+    if (p.splits > 1) {
+        const int k_lo = (int)((int64_t)nk * split / p.splits), k_hi = (int)((int64_t)nk * (split + 1) / p.splits);
+        auto below = [&](int kt) {           // list entries with slice index < kt (the list is ascending)
+            int a = 0, b = nlist;
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if ((int)(Ks[mid] & 1023) < kt) a = mid + 1; else b = mid;
+            }
+            return a;
+        };
+        lo = below(k_lo);
+        hi_i = below(k_hi);
+    }
     const int nsl = hi_i - lo;        // slices of this workgroup: list entries lo .. hi_i-1
     if (nsl > 0) {
 #pragma unroll
@@ -1115,6 +1132,27 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
         while (sp > 1 && (int64_t)sp * p.M * p.N * 4 > p.ws_bytes) --sp;
         p.splits = sp;
         p.partial = p.ws;
+    } else if (p.ws && !p.scat && nk >= 32) {
+        // Mid-size launches: a few hundred tiles on 256 CUs leave the chip unevenly loaded (544 tiles of a level-0 conv
+        // on dense data = 2.1 per CU: the CUs holding three set the time, 71 %).  Splitting K multiplies the work items;
+        // pick the split count with the best (load balance) x (1 - cost of writing and re-reading the partial tiles).
+        static const int mid = getenv("HPL_SPLIT_MID") ? atoi(getenv("HPL_SPLIT_MID")) : 1;
+        constexpr int WG_PER_CU = 16 / (WGM * WGN);                    // four waves per SIMD fill a CU
+        const double slots = 256.0 * WG_PER_CU;
+        if (mid && tiles < 6 * slots) {
+            double best = 0.0;
+            int best_sp = 1;
+            for (int sp = 1; sp <= 16 && sp * 8 <= nk; ++sp) {
+                if (sp > 1 && (int64_t)sp * p.M * p.N * 4 > p.ws_bytes) break;
+                const double rounds = tiles * sp / slots;
+                const double eff = rounds / std::ceil(rounds);
+                // partial tiles: 8 B per element and split through HBM (~4 TB/s) against 2*K flop per element (~100 TF)
+                const double cost = sp == 1 ? 0.0 : 100.0 * sp / (double)p.K;
+                const double score = eff * (1.0 - cost);
+                if (score > best * 1.03) { best = score; best_sp = sp; }      // (a larger split must pay for itself)
+            }
+            if (best_sp > 1) { p.splits = best_sp; p.partial = p.ws; }
+        }
     }
     int grid = tiles * p.splits;
     p.col_share = 0; p.col_rows = 0;

@@ -20,6 +20,8 @@ import ctypes
 import math
 
 import numpy as np
+import time
+
 import torch
 
 from . import _lib, ops
@@ -31,6 +33,9 @@ from .flownet import DeviceLattice, PairBlur, _Level
 def _filter_size(radius, d1=4):
     return (radius + 1) ** d1 - radius ** d1
 
+
+#: seconds the pipeline's host thread spent idle, waiting for vertex counts from the GPU (bench.py reports it)
+WAIT = {'s': 0.0}
 
 class GenerateDataUnsymmetric(object):
     def __init__(self, args, device='cuda', wide_up=None):
@@ -277,6 +282,10 @@ class LatticePipeline(object):
                     b.advance()
                     moved = True
             if not moved:
+                t = time.perf_counter()
+                while not head.ready():          # the GPU has not delivered the head's vertex counts yet: idle host time
+                    pass
+                WAIT['s'] += time.perf_counter() - t
                 head.advance()
         self._inflight.popleft()
         self._top_up()

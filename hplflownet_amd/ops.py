@@ -306,17 +306,17 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
 #: sustains under that kernel
 CLOCK_PROBE = None
 
-_SPLITK_MAX_ELEMS = 1 << 20          # split-K only pays for small outputs (M*N <= 1M elements; measured)
+_SPLITK_MAX_ELEMS = 8 << 20          # split-K is offered for outputs of <= 8 M elements (the launch picks the count)
 _SPLITK_WS = {}
 _NO_SPLITK = bool(os.environ.get('HPL_NO_SPLITK'))      # A/B switch for benchmarking
 
 
 def _splitk_workspace(device, st):
-    """Per-(device, stream) scratch for split-K partial tiles: 16 splits x 1M floats = 64 MB."""
+    """Per-(device, stream) scratch for split-K partial tiles: 64 M floats = 256 MB (csrc/executor.hip: same)."""
     key = (device, st)
     ws = _SPLITK_WS.get(key)
     if ws is None:
-        ws = _SPLITK_WS[key] = torch.empty(16 << 20, dtype=torch.float32, device=device)
+        ws = _SPLITK_WS[key] = torch.empty(64 << 20, dtype=torch.float32, device=device)
     return ws
 
 

@@ -13,6 +13,8 @@ autograd -- takes the Python path of the model.
 """
 import ctypes
 
+import time
+
 import torch
 
 from . import _lib, ops
@@ -30,6 +32,9 @@ BUF_OUT = -2
 #: profiling classes (hpl_op.tag): the wide stencil convs that dominate the step, everything else
 TAG_OTHER, TAG_WIDE_BLUR = 0, 1
 
+
+#: seconds the caller's thread spent waiting for a free workspace slot (bench.py reports it)
+WAIT = {'s': 0.0}
 
 def lsym(L, k):
     return SYM_LEVEL0 + 8 * L + k
@@ -410,8 +415,10 @@ class ForwardPlan(object):
         slot = self._slot
         self._slot = (slot + 1) % self.slots
         ev = self._fence.get(slot)
-        if ev is not None:
-            ev.synchronize()
+        if ev is not None and not ev.query():
+            t = time.perf_counter()
+            ev.synchronize()                     # every workspace is still in use: the GPU is the limiter, idle host time
+            WAIT['s'] += time.perf_counter() - t
         ws = self._ws.get(slot)
         if ws is None or ws.numel() < nbytes:
             ws = self._ws[slot] = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=dev)

@@ -161,7 +161,7 @@ def test_config4_train_step_n8192_vs_oracle():
 def test_lattice_rebuild_determinism_n8192():
     """Two independent builds of the same pair's lattice (row orders are filled with atomics, so tile membership
     differs between builds) give bit-identical tables and a bit-identical flow: absent taps multiply zeros, and
-    split-K never meets a row order (ops / gconv.hip)."""
+    split-K cuts the contraction at slice indices, not at positions of a tile's slice list (gconv.hip)."""
     import hplflownet_amd as H
     pc1, pc2, sf = synthetic_pair(8192, 3)
     m, _ = full_model()

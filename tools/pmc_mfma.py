@@ -55,6 +55,12 @@ def main():
             if busy and gui and gui[1] > 0:
                 # busy cycles are summed over the SIMDs that report (per-XCD sampling): quote the ratio only
                 out['dominant_mfma_busy_cycles_per_gui_cycle'] = busy[1] / gui[1]
+    if out.get('dominant_launches'):
+        # whole step: every MFMA kernel's executed flops, per step (the dominant class is launched 4 times per step)
+        steps = out['dominant_launches'] / 4.0
+        out['executed_gflop_per_step'] = sum(k['launches'] * k['executed_gflop_per_launch'] for n_, k in out['kernels'].items()
+                                             if 'k_mfma_probe' not in n_) / steps
+        lines.append('# executed MFMA work of the whole step (all kernels): %.1f GF' % out['executed_gflop_per_step'])
     open(prefix + '.txt', 'w').write('\n'.join(lines) + '\n')
     json.dump(out, open(prefix + '.json', 'w'), indent=1)
     print('\n'.join(lines[:14]))
