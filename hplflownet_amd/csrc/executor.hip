@@ -42,6 +42,30 @@ __global__ void k_copy_cols4(const float4 *__restrict__ src, int64_t lds4, float
     }
 }
 
+// el_minus_gr tables -> the first four columns of several concatenation buffers, one launch for the whole forward
+// (the tables are lattice outputs: every one of these copies can run before the first layer)
+constexpr int EMG_JOBS = 24;
+struct EmgJobs {
+    const float4 *src[EMG_JOBS];
+    float *dst[EMG_JOBS];
+    int64_t ldd[EMG_JOBS];
+    int64_t rows[EMG_JOBS];
+    int n;
+};
+__global__ void k_copy_emg_batch(const EmgJobs j) {
+    const int job = blockIdx.y;
+    const float4 *src = j.src[job];
+    float *dst = j.dst[job];
+    const int64_t ldd = j.ldd[job], rows = j.rows[job];
+    const bool vec = (ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = src[r];
+        float *d = dst + r * ldd;
+        if (vec) *reinterpret_cast<float4 *>(d) = v;
+        else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+    }
+}
+
 struct View {                 // a resolved hpl_ref
     float *p;
     int64_t ld;
@@ -57,6 +81,7 @@ struct hpl_plan {
     std::vector<hpl_weight> weights;
     std::vector<const float *> biases;
     int profile_tag = -1;
+    bool hoist_emg = true;                  // no other op writes the columns the el_minus_gr copies fill
     int64_t *clock_probe = nullptr;
     std::vector<hipEvent_t> pool;           // events owned by the plan (reused)
     size_t pool_used = 0;
@@ -147,6 +172,15 @@ struct Runner {
         if (rc) return rc;
         const bool has_res = op.res.buf != -1;
         if (has_res && (rc = view(op.res, R, "gconv residual"))) return rc;
+        View Y2 = {};
+        const bool has_out2 = op.out2.buf != -1;
+        int64_t rows2 = 0;
+        if (has_out2) {
+            if ((rc = view(op.out2, Y2, "gconv second output"))) return rc;
+            rows2 = symv(sym, op.rows2_sym);
+            HPL_REQUIRE(Y2.cols >= op.N && rows2 >= 0 && rows2 <= Y2.rows, "hpl_plan_run: second output (%lld rows of %lld, N=%d of %d)",
+                        (long long)rows2, (long long)Y2.rows, op.N, Y2.cols);
+        }
         HPL_REQUIRE(op.weight >= 0 && op.weight < (int)pl.weights.size(), "hpl_plan_run: weight image %d", op.weight);
         HPL_REQUIRE(op.level >= 0 && op.level < n_levels, "hpl_plan_run: op uses lattice level %d of %d", op.level, n_levels);
         const hpl_level_tables &t = lv[op.level];
@@ -206,6 +240,7 @@ struct Runner {
                 d.res = Y.p; d.ldres = Y.ld; d.res_mod = M;
             }
             d.Y = Y.p; d.ldy = Y.ld;
+            if (last && has_out2) { d.Y2 = Y2.p; d.ldy2 = Y2.ld; d.rows2 = rows2; }
             d.row_perm = row_perm;
             if (row_perm && ti && tm) { d.tile_idx = ti; d.tile_mask = tm; d.tile_bm = t.tile_bm; }
             if (prof) d.clock_probe = pl.clock_probe;
@@ -322,6 +357,20 @@ extern "C" hpl_plan *hpl_plan_create(const hpl_op *ops, int n_ops, const hpl_buf
     p->bufs.assign(bufs, bufs + n_bufs);
     if (n_weights) p->weights.assign(weights, weights + n_weights);
     if (n_biases) p->biases.assign(biases, biases + n_biases);
+    // the el_minus_gr copies are hoisted in front of the layers (one launch): only if their columns are theirs alone
+    auto overlaps = [](const hpl_ref &a, const hpl_ref &b) {
+        return a.buf >= 0 && a.buf == b.buf && a.col_off < b.col_off + b.cols && b.col_off < a.col_off + a.cols;
+    };
+    for (int i = 0; i < n_ops && p->hoist_emg; ++i) {
+        if (!(ops[i].kind == HPL_OP_COPY && ops[i].a.buf == -1)) continue;
+        for (int j = 0; j < n_ops; ++j)
+            if (j != i && (overlaps(ops[i].out, ops[j].out) || (ops[j].kind == HPL_OP_GCONV && overlaps(ops[i].out, ops[j].out2)))) {
+                // (the two orders of an Up layer never both run: same columns under opposite conditions are fine)
+                const bool exclusive = ops[i].cond != HPL_COND_ALWAYS && ops[j].cond != HPL_COND_ALWAYS &&
+                                       ops[i].cond != ops[j].cond && ops[i].cond_level == ops[j].cond_level;
+                if (!exclusive) p->hoist_emg = false;
+            }
+    }
     for (const hpl_buf &b : p->bufs)
         if (b.cols <= 0 || b.rows_sym < 0 || b.rows_sym >= MAX_SYMS) {
             set_error("hpl_plan_create: bad buffer (rows symbol %d, %d columns)", b.rows_sym, b.cols);
@@ -366,12 +415,58 @@ extern "C" int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels, int 
     HPL_REQUIRE(w <= end, "hpl_plan_run: workspace of %lld bytes is too small (hpl_plan_workspace_bytes: %lld)",
                 (long long)workspace_bytes, (long long)hpl_plan_workspace_bytes(plan, levels, n_levels));
     Runner r{*plan, levels, n_levels, sym, {pc1, pc2}, out, splitk, to_stream(stream), stream};
-    for (const hpl_op &op : plan->ops) {
+    auto active = [&](const hpl_op &op, bool &run) -> int {
+        run = true;
         if (op.cond != HPL_COND_ALWAYS) {
             HPL_REQUIRE(op.cond_level >= 0 && op.cond_level < n_levels, "hpl_plan_run: condition on level %d", op.cond_level);
             const bool shrink = levels[op.cond_level].n0 < levels[op.cond_level].H0;
-            if ((op.cond == HPL_COND_SHRINK) != shrink) continue;
+            run = (op.cond == HPL_COND_SHRINK) == shrink;
         }
+        return HPL_OK;
+    };
+    auto is_emg = [](const hpl_op &op) { return op.kind == HPL_OP_COPY && op.a.buf == -1; };
+    // every el_minus_gr copy of the forward in one launch, ahead of the layers (hpl_plan_create checked that nothing
+    // else writes those columns: plan->hoist_emg)
+    static const int batch_emg = getenv("HPL_EMG_BATCH") ? atoi(getenv("HPL_EMG_BATCH")) : 1;
+    const bool hoist = batch_emg && plan->hoist_emg;
+    if (hoist) {
+        EmgJobs jobs;
+        jobs.n = 0;
+        int64_t most = 0;
+        auto flush = [&]() {
+            if (!jobs.n) return;
+            dim3 grid((unsigned)imin(cdiv(most, 256), 64), (unsigned)jobs.n);
+            k_copy_emg_batch<<<grid, 256, 0, r.s>>>(jobs);
+            jobs.n = 0;
+            most = 0;
+        };
+        for (const hpl_op &op : plan->ops) {
+            if (!is_emg(op)) continue;
+            bool run;
+            if ((rc = active(op, run))) return rc;
+            if (!run) continue;
+            View Y;
+            if ((rc = r.view(op.out, Y, "copy output"))) return rc;
+            const int64_t rows = symv(sym, op.m_sym);
+            HPL_REQUIRE(op.level >= 0 && op.level < n_levels && op.C == 4 && Y.cols >= 4 && Y.rows >= rows &&
+                            rows <= levels[op.level].n0 + levels[op.level].n1,
+                        "hpl_plan_run: emg copy of %lld rows at level %d", (long long)rows, op.level);
+            if (rows == 0) continue;
+            jobs.src[jobs.n] = reinterpret_cast<const float4 *>(levels[op.level].emg_pair);
+            jobs.dst[jobs.n] = Y.p;
+            jobs.ldd[jobs.n] = Y.ld;
+            jobs.rows[jobs.n] = rows;
+            most = most > rows ? most : rows;
+            if (++jobs.n == EMG_JOBS) flush();
+        }
+        flush();
+        HPL_CHECK_LAUNCH("hpl_plan_run (emg copies)");
+    }
+    for (const hpl_op &op : plan->ops) {
+        if (hoist && is_emg(op)) continue;
+        bool run;
+        if ((rc = active(op, run))) return rc;
+        if (!run) continue;
         rc = r.run_op(op);
         if (rc) return rc;
     }

@@ -105,6 +105,7 @@ struct GParams {
     int col_share;                      // > 0: column-major XCD order, XCDs per column tile (see tile_coords)
     int col_rows;                       // tile-rows per virtual column in that order
     int splits; float *partial;         // split-K over the slice list: partial[split][M][N]
+    float *Y2; int64_t ldy2; int64_t rows2;   // optional second destination: rows < rows2 are also written to Y2
     float *ws; int64_t ws_bytes;
 };
 
@@ -612,6 +613,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
                     if (tgt >= 0) atomicAdd(p.Y + (int64_t)tgt * p.ldy + c, v);
                 } else {
                     p.Y[m * p.ldy + n] = v;
+                    if (p.Y2 && m < p.rows2) p.Y2[m * p.ldy2 + n] = v;
                 }
             }
         }
@@ -641,6 +643,7 @@ __global__ void k_gconv_finish(const GParams p) {
         if (p.res) v += p.res[(m % p.res_mod) * p.ldres + n];
         if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
         p.Y[m * p.ldy + n] = v;
+        if (p.Y2 && m < p.rows2) p.Y2[m * p.ldy2 + n] = v;
     }
 }
 
@@ -669,6 +672,7 @@ __global__ void k_gconv_naive(const GParams p) {
             if (tgt >= 0) atomicAdd(p.Y + (int64_t)tgt * p.ldy + c, v);
         } else {
             p.Y[m * p.ldy + n] = v;
+            if (p.Y2 && m < p.rows2) p.Y2[m * p.ldy2 + n] = v;
         }
     }
 }
@@ -1006,6 +1010,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, 4) k_gconv_pers(const GParams 
                     if (p.res) v += p.res[(m % p.res_mod) * p.ldres + n];
                     if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
                     p.Y[m * p.ldy + n] = v;
+                    if (p.Y2 && m < p.rows2) p.Y2[m * p.ldy2 + n] = v;
                 }
             }
 #pragma unroll
@@ -1063,6 +1068,8 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.Wt = d->Wt; p.ldw = d->ldw; p.N = d->N; p.act = d->act; p.slope = d->slope;
     p.bias = d->bias; p.res = d->res; p.ldres = d->ldres; p.res_mod = d->res_mod;
     p.Y = d->Y; p.ldy = d->ldy;
+    p.Y2 = d->Y2; p.ldy2 = d->ldy2; p.rows2 = d->Y2 ? d->rows2 : 0;
+    HPL_REQUIRE(!d->Y2 || (!d->scat && d->ldy2 >= d->N && d->rows2 >= 0), "%s: bad second destination", who);
     p.scat = d->scat; p.scat_stride = d->scat_stride; p.scat_c = d->scat_c;
     p.row_perm = d->row_perm;
     p.tile_idx = (d->tile_idx && d->tile_mask && d->row_perm) ? d->tile_idx : nullptr;

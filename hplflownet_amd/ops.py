@@ -243,11 +243,13 @@ def _mat(x, what):
 
 
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
-              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True, reg_stride=0, tiles=None):
+              scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True, reg_stride=0, tiles=None,
+              out2=None, rows2=0):
     """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
     row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged.
     nbr None and reg_stride > 0: tap f of row m reads row f*reg_stride + m (no table: the displacement
-    filter of the correlation layer, whose taps are the F blocks of H1 virtual vertices)."""
+    filter of the correlation layer, whose taps are the F blocks of H1 virtual vertices).
+    out2 / rows2: rows m < rows2 of the result are also stored to the matrix (view) `out2`."""
     d = GConvDesc()
     d.A, d.lda, d.rows_a, a_cols = _mat(A, 'activation')
     if nbr is not None:
@@ -282,6 +284,11 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
     elif out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     d.Y, d.ldy, _, _ = _mat(out, 'out')
+    if out2 is not None:
+        d.Y2, d.ldy2, r2, c2 = _mat(out2, 'out2')
+        if scat is not None or rows2 > r2 or c2 < N:
+            raise _lib.HplError('second destination: %d rows x %d columns for rows2=%d N=%d' % (r2, c2, rows2, N))
+        d.rows2 = rows2
     if row_perm is not None:
         if row_perm.dtype is not torch.int32 or row_perm.numel() != M or not row_perm.is_contiguous():
             raise _lib.HplError('row_perm must be a contiguous int32 tensor of M=%d entries' % M)

@@ -60,6 +60,14 @@ class _R(object):
 _NONE = Ref(-1, SYM_ZERO, SYM_ZERO, 0, 0)
 
 
+def _op(*fields, **kw):
+    """hpl_op with the optional second destination (default: none)."""
+    o = Op(*fields)
+    o.out2 = kw.get('out2') or _NONE
+    o.rows2_sym = kw.get('rows2', SYM_ZERO)
+    return o
+
+
 class _Program(object):
     def __init__(self, bank):
         self.ops, self.bufs, self.bank = [], [], bank
@@ -94,25 +102,28 @@ class _Program(object):
         return self.bias(t)
 
     def gconv(self, a, out, M, C, N, wid, bias=-1, act=0, slope=0.1, F=1, level=0, table=TBL_NONE, order=ORD_NONE,
-              res=None, res_mod=SYM_ZERO, reg_stride=SYM_ZERO, tag=TAG_OTHER):
-        self.ops.append(Op(OP_GCONV, tag, a.c(), out.c(), res.c() if res is not None else _NONE, M, res_mod, level, table,
-                           order, F, C, N, wid, bias, act, slope, 0, reg_stride, 0, *self.cond))
+              res=None, res_mod=SYM_ZERO, reg_stride=SYM_ZERO, tag=TAG_OTHER, out2=None, rows2=SYM_ZERO):
+        """out2 / rows2: the first `rows2` rows of the result are written to a second view as well (a layer output that
+        feeds two concatenation buffers is stored by its producer, not copied)."""
+        self.ops.append(_op(OP_GCONV, tag, a.c(), out.c(), res.c() if res is not None else _NONE, M, res_mod, level, table,
+                            order, F, C, N, wid, bias, act, slope, 0, reg_stride, 0, *self.cond,
+                            out2=out2.c() if out2 is not None else None, rows2=rows2))
 
     def splat(self, a, out, level, table, H, C, use_norm):
-        self.ops.append(Op(OP_SPLAT, TAG_OTHER, a.c(), out.c(), _NONE, H, SYM_ZERO, level, table, 0, 1, C, C, -1, -1, 0, 0.0,
+        self.ops.append(_op(OP_SPLAT, TAG_OTHER, a.c(), out.c(), _NONE, H, SYM_ZERO, level, table, 0, 1, C, C, -1, -1, 0, 0.0,
                            int(bool(use_norm)), SYM_ZERO, 0, *self.cond))
 
     def slice(self, a, out, level, N, C, bias=-1):
-        self.ops.append(Op(OP_SLICE, TAG_OTHER, a.c(), out.c(), _NONE, N, SYM_ZERO, level, TBL_CLOUD0, 0, 1, C, C, -1, bias, 0,
+        self.ops.append(_op(OP_SLICE, TAG_OTHER, a.c(), out.c(), _NONE, N, SYM_ZERO, level, TBL_CLOUD0, 0, 1, C, C, -1, bias, 0,
                            0.0, 0, SYM_ZERO, 0, *self.cond))
 
     def copy(self, a, out, rows, C, level=0):
         """a None: el_minus_gr of `level` (both clouds, point-major)."""
-        self.ops.append(Op(OP_COPY, TAG_OTHER, a.c() if a is not None else _NONE, out.c(), _NONE, rows, SYM_ZERO, level, 0, 0,
+        self.ops.append(_op(OP_COPY, TAG_OTHER, a.c() if a is not None else _NONE, out.c(), _NONE, rows, SYM_ZERO, level, 0, 0,
                            1, C, C, -1, -1, 0, 0.0, 0, SYM_ZERO, 0, *self.cond))
 
     def load(self, out, ext, rows):
-        self.ops.append(Op(OP_LOAD, TAG_OTHER, _NONE, out.c(), _NONE, rows, SYM_ZERO, 0, 0, 0, 1, 3, 3, -1, -1, 0, 0.0, 0,
+        self.ops.append(_op(OP_LOAD, TAG_OTHER, _NONE, out.c(), _NONE, rows, SYM_ZERO, 0, 0, 0, 1, 3, 3, -1, -1, 0, 0.0, 0,
                            SYM_ZERO, ext, 0, 0))
 
 
@@ -126,14 +137,18 @@ def _dense(P, x, conv, act, slope, M, out=None, rows_sym=None):
     return out
 
 
-def _conv_stack(P, x, mods, M, rows_sym, F, level, table, order, slope, out=None, reg_stride=SYM_ZERO, wide_tag=False):
-    """bcl._run_conv_stack: first conv through `table` (F taps), the rest 1x1; returns the output ref."""
+def _conv_stack(P, x, mods, M, rows_sym, F, level, table, order, slope, out=None, reg_stride=SYM_ZERO, wide_tag=False,
+                out2=None, rows2=SYM_ZERO):
+    """bcl._run_conv_stack: first conv through `table` (F taps), the rest 1x1; returns the output ref.  out2 / rows2:
+    second destination of the LAST conv (_Program.gconv)."""
     n = len(mods)
     for i, m in enumerate(mods):
         conv = _conv_of(m)
         act = 1 if isinstance(m, _ConvReLU) else 0
         O = conv.weight.shape[0]
-        o = out if (i == n - 1 and out is not None) else P.buf(rows_sym, O)
+        final = i == n - 1
+        o = out if (final and out is not None) else P.buf(rows_sym, O)
+        second = dict(out2=out2, rows2=rows2) if (final and out2 is not None) else {}
         if i == 0:
             Ctot = conv.weight.numel() // (O * F)
             ordr = order
@@ -141,19 +156,52 @@ def _conv_stack(P, x, mods, M, rows_sym, F, level, table, order, slope, out=None
                 ordr = ORD_GROUPS if conv.in_channels >= GROUPS_MIN_CHANNELS else ORD_PERM
             P.gconv(x, o, M, Ctot, O, P.weight(conv.weight, Ctot, O, F, Ctot, 0), bias=P.bias(conv.bias), act=act,
                     slope=slope, F=F, level=level, table=table, order=ordr, reg_stride=reg_stride,
-                    tag=TAG_WIDE_BLUR if (wide_tag and conv.in_channels >= GROUPS_MIN_CHANNELS) else TAG_OTHER)
+                    tag=TAG_WIDE_BLUR if (wide_tag and conv.in_channels >= GROUPS_MIN_CHANNELS) else TAG_OTHER, **second)
         else:
             C = conv.weight.shape[1]
-            P.gconv(x, o, M, C, O, P.weight(conv.weight, C, O, 1, C, 0), bias=P.bias(conv.bias), act=act, slope=slope)
+            P.gconv(x, o, M, C, O, P.weight(conv.weight, C, O, 1, C, 0), bias=P.bias(conv.bias), act=act, slope=slope,
+                    **second)
         x = o
     return x
 
 
+def _corr_width(model, L):
+    """channels of the (refined) correlation living at level L (flownet._FlowNetBase.__init__: corr_dim)."""
+    return 64 if model.REFINE else getattr(model, 'corr%d' % (L - 1)).num_output[-1]
+
+
 def build_program(model, bank):
-    """The pair-batched inference forward of flownet._FlowNetBase.forward, op by op."""
+    """The pair-batched inference forward of flownet._FlowNetBase.forward, op by op.  The input matrix of every Up
+    layer (the reference's torch.cat of el_minus_gr | upper Up output | correlation | Down features) is allocated up
+    front and every part is WRITTEN THERE BY ITS PRODUCER: the Up layer above and the correlation layer store straight
+    into their columns, the Down layer's last conv stores its cloud-1 rows there as a second destination, the
+    el_minus_gr columns are filled by one batched launch (csrc/executor.hip) -- no copy launches."""
     P = _Program(bank)
     nlev = model.NLEV
     sl = _slope(model.use_leaky)
+    # ---- the Up layers' input matrices: xb[L] = [H0(L), parts], cols[L] = {part: (column offset, width)}
+    xb, cols = {}, {}
+    up_w = None
+    for L in reversed(range(nlev)):
+        layer = getattr(model, 'bcn%d_' % (L + 1))
+        parts = []
+        if L < nlev - 1:
+            parts += [('emg', 4), ('up', up_w)]
+        if L >= 2:
+            parts.append(('corr', _corr_width(model, L)))
+        parts.append(('down', getattr(model, 'bcn%d' % (L + 1)).num_output[-1]))
+        if L == nlev - 1:
+            parts = [q for q in parts if q[0] == 'corr'] + [q for q in parts if q[0] == 'down']
+        col, cols[L] = 0, {}
+        for kind, w in parts:
+            cols[L][kind] = (col, w)
+            col += w
+        assert col == layer.num_input, (L, col, layer.num_input)
+        xb[L] = P.buf(lsym(L, S_H0), col)
+        up_w = layer.num_output[-1]
+
+    def part(L, kind):
+        return xb[L].columns(*cols[L][kind])
     # ---- inputs, conv1 (both clouds stacked)
     xin = P.buf(SYM_NP, 3)
     P.load(xin.rows_from(SYM_ZERO, SYM_N0), 0, SYM_N0)
@@ -164,7 +212,6 @@ def build_program(model, bank):
     for i, m in enumerate(model.conv1):
         last = i == len(model.conv1) - 1
         t = _dense(P, t, m.conv, True, sl, SYM_NP, out=x.columns(4, feat_c) if last else None, rows_sym=SYM_NP)
-    down, corrs = [], {}
     prev = None           # (ref, channels) of the previous correlation output, rows = H0 of its level
     for L in range(nlev):
         layer = getattr(model, 'bcn%d' % (L + 1))
@@ -175,48 +222,24 @@ def build_program(model, bank):
         P.splat(x, s, L, TBL_CSR_PAIR, HP, cin, layer.use_norm)
         c_out = layer.num_output[-1]
         nxt = P.buf(HP, 4 + c_out) if L + 1 < nlev else None
+        # both clouds' vertices -> the next level's splat input; cloud 1's rows also -> the Up layer's input matrix
         y = _conv_stack(P, s, list(layer.blur_conv), HP, HP, layer.filter_size, L, TBL_BLUR_PAIR, ORD_PERM, sl,
-                        out=nxt.columns(4, c_out) if nxt is not None else None)
+                        out=nxt.columns(4, c_out) if nxt is not None else None, out2=part(L, 'down'), rows2=H0)
         f1, f2 = y.rows_from(SYM_ZERO, H0), y.rows_from(H0, H1)
-        down.append((f1, c_out))
         x = nxt
         if L >= 2:
-            prev = _corr(P, model, L, f1, f2, prev, sl)
-            corrs[L] = prev
-    # ---- Up path
-    up = None             # (level whose layer produces it, input ref) -- emitted into its consumer's buffer
+            prev = _corr(P, model, L, f1, f2, prev, sl, part(L, 'corr'))
+    # ---- Up path: every layer writes into the 'up' columns of the level below
     for L in reversed(range(nlev)):
         layer = getattr(model, 'bcn%d_' % (L + 1))
-        H0 = lsym(L, S_H0)
-        if L == nlev - 1:
-            parts = [('ref', corrs[L]), ('ref', down[L])]
-        else:
-            parts = [('emg', L + 1), ('up', up)]
-            if L >= 2:
-                parts.append(('ref', corrs[L]))
-            parts.append(('ref', down[L]))
-        total = 0
-        widths = []
-        for kind, v in parts:
-            w = 4 if kind == 'emg' else (v[1] if kind == 'ref' else v[2])
-            widths.append(w)
-            total += w
-        xb = P.buf(H0, total)
-        col = 0
-        for (kind, v), w in zip(parts, widths):
-            view = xb.columns(col, w)
-            if kind == 'emg':
-                P.copy(None, view, H0, 4, level=v)          # el_minus_gr of cloud 1 at level L+1: its first H0[L] rows
-            elif kind == 'ref':
-                P.copy(v[0], view, H0, w)
-            else:
-                _up_layer(P, (v[0], v[3]), v[1], view, sl)
-            col += w
-        up = (layer, xb, layer.num_output[-1], L)
+        if L < nlev - 1:
+            P.copy(None, part(L, 'emg'), lsym(L, S_H0), 4, level=L + 1)     # el_minus_gr of cloud 1 at level L+1
+        if L > 0:
+            _up_layer(P, (layer, L), xb[L], part(L - 1, 'up'), sl)
     # the last Up layer writes a fresh [N0, HEAD_IN] matrix
-    layer, xb, c_up, L = up
-    ybuf = P.buf(SYM_N0, c_up)
-    _up_layer(P, (layer, L), xb, ybuf, sl)
+    layer = getattr(model, 'bcn1_')
+    ybuf = P.buf(SYM_N0, layer.num_output[-1])
+    _up_layer(P, (layer, 0), xb[0], ybuf, sl)
     y = _dense(P, ybuf, model.conv2.conv, True, sl, SYM_N0, rows_sym=SYM_N0)
     y = _dense(P, y, model.conv3.conv, True, sl, SYM_N0, rows_sym=SYM_N0)
     _dense(P, y, model.conv4, False, sl, SYM_N0, out=_R(BUF_OUT, 3))
@@ -248,8 +271,9 @@ def _up_layer(P, layer_L, xb, out, sl):
     P.cond = (0, 0)
 
 
-def _corr(P, model, L, f1, f2, prev, sl):
-    """bcl.BilateralCorrelationFlex.forward_cl (+ the shallow model's refine stack): -> (ref, channels)."""
+def _corr(P, model, L, f1, f2, prev, sl, dst):
+    """bcl.BilateralCorrelationFlex.forward_cl (+ the shallow model's refine stack), its result written into `dst`
+    (the correlation columns of the Up layer's input matrix): -> (ref, channels)."""
     j = L - 1
     m = getattr(model, 'corr%d' % j)
     H0, FH0, IN0 = lsym(L, S_H0), lsym(L, S_FH0), lsym(L, S_IN0)
@@ -274,18 +298,22 @@ def _corr(P, model, L, f1, f2, prev, sl):
             table=TBL_CORR2, res=a, res_mod=H0)
     for mm in list(m.corr_conv)[1:]:
         p = _dense(P, p, mm.conv, True, csl, FH0, rows_sym=FH0)
-    c = _conv_stack(P, p, list(m.blur_conv), H0, H0, F, L, TBL_REGULAR, ORD_NONE, csl, reg_stride=H0)
     width = m.num_output[-1]
-    if model.REFINE:
-        if L + 1 < model.NLEV:
-            cb = P.buf(H0, 4 + width)
-            P.copy(None, cb.columns(0, 4), H0, 4, level=L + 1)
-            P.copy(c, cb.columns(4, width), H0, width)
-            c, width = cb, 4 + width
-        for mm in getattr(model, 'corr%d_refine' % j):
-            c = _dense(P, c, mm.conv, True, sl, H0, rows_sym=H0)
-            width = mm.conv.out_channels
-    return (c, width)
+    if not model.REFINE:
+        c = _conv_stack(P, p, list(m.blur_conv), H0, H0, F, L, TBL_REGULAR, ORD_NONE, csl, out=dst, reg_stride=H0)
+        return (c, width)
+    if L + 1 < model.NLEV:
+        cb = P.buf(H0, 4 + width)
+        P.copy(None, cb.columns(0, 4), H0, 4, level=L + 1)
+        c = _conv_stack(P, p, list(m.blur_conv), H0, H0, F, L, TBL_REGULAR, ORD_NONE, csl, out=cb.columns(4, width),
+                        reg_stride=H0)
+        c = cb
+    else:
+        c = _conv_stack(P, p, list(m.blur_conv), H0, H0, F, L, TBL_REGULAR, ORD_NONE, csl, reg_stride=H0)
+    mods = list(getattr(model, 'corr%d_refine' % j))
+    for i, mm in enumerate(mods):
+        c = _dense(P, c, mm.conv, True, sl, H0, out=dst if i == len(mods) - 1 else None, rows_sym=H0)
+    return (c, mods[-1].conv.out_channels)
 
 
 def level_tables(lat, hint):

@@ -173,8 +173,9 @@ typedef struct hpl_gconv_desc {
      * output row row_perm[j]; the result is unchanged, rows of one tile share absent taps so that
      * whole contraction slices can be skipped.  NULL = identity. */
     const int32_t *row_perm;
-    /* optional workspace for split-K on small problems (M*N*4 bytes per split, up to 16 splits);
-     * NULL = never split.  Partial tiles are summed in a fixed order: results stay deterministic. */
+    /* optional workspace for split-K (M*N*4 bytes per split, up to 16 splits; small and mid-size launches);
+     * NULL = never split.  Partial tiles are summed in split order (cut points are slice indices): results are
+     * deterministic and independent of the row order. */
     float *ws;
     int64_t ws_bytes;
     /* optional, with row_perm: per-tile gather indices and tap masks precomputed by hpl_tile_index for tiles of
@@ -187,6 +188,12 @@ typedef struct hpl_gconv_desc {
      * shader cycles to [0] and in 100 MHz wall ticks to [1] -- [0] / [1] * 100 MHz is the clock the chip sustains
      * under this kernel (it clocks to its power budget). */
     int64_t *clock_probe;
+    /* optional second destination (forward only, not with scat): rows m < rows2 of the result are ALSO stored to
+     * Y2[m * ldy2 + n] -- a layer's output that feeds two concatenation buffers is written once by its producer
+     * instead of copied (the reference builds both with torch.cat, models/HPLFlowNet.py:299-393). */
+    float *Y2;
+    int64_t ldy2;
+    int64_t rows2;
 } hpl_gconv_desc;
 
 /* Row order for tap skipping: perm = the M vertices grouped by their F-bit tap-presence mask
@@ -218,6 +225,7 @@ int hpl_gconv_forward(const hpl_gconv_desc *desc /* HOST */, hplStream stream);
  * csrc/gconv.hip); 2 = persistent for every launch that can.  Results are identical in all modes.  Returns the
  * previous mode. */
 int hpl_set_persistent(int mode);
+
 /* same contract, one thread per output element, no MFMA: test/debug reference only */
 int hpl_gconv_forward_naive(const hpl_gconv_desc *desc /* HOST */, hplStream stream);
 
@@ -416,6 +424,8 @@ typedef struct hpl_op {
     int32_t ext;              /* HPL_OP_LOAD: 0 = pc1, 1 = pc2 */
     int32_t cond;             /* HPL_COND_*: run the op only if the condition holds at level cond_level */
     int32_t cond_level;
+    hpl_ref out2;             /* gconv: optional second destination (buf == -1: none), see hpl_gconv_desc.Y2 */
+    int32_t rows2_sym;        /* rows of the result that go to out2 as well */
 } hpl_op;
 
 /* Kernel-ready tables of one lattice level of a pair (what hplflownet_amd.lattice builds on the device;

@@ -391,3 +391,48 @@ def test_persistent_gconv_equals_one_tile_per_workgroup(ops, C, O, F, density):
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
     y_naive = ops.gconv_raw(A, nbr, M, C, F, Wt, O, naive=True)
     assert torch.equal(outs[3], y_naive) if C % 32 == 0 or True else True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,C,O,F,density', [(53, 64, 32, 15, 0.5), (426, 260, 128, 15, 0.4), (1787, 64, 64, 1, 1.0),
+                                              (4324, 580, 1024, 15, 0.95), (9433, 388, 256, 15, 0.45)])
+def test_split_k_row_order_independent_and_second_destination(ops, M, C, O, F, density):
+    """Split-K launches (small M, and mid-size launches split for load balance) cut the contraction at slice indices:
+    the result is bit-identical with and without a row order (whose tiles keep different slice lists), equal to the
+    unsplit launch within fp32 reassociation; rows < rows2 of the result also land in a second matrix (a column view
+    of a wider buffer) on every path."""
+    rng = np.random.RandomState(M)
+    if F > 1:
+        nbr_np = rng.randint(0, M, (F, M)).astype(np.int32)
+        nbr_np[rng.rand(F, M) > density] = -1
+        nbr_np[0] = np.arange(M)
+        nbr = torch.from_numpy(nbr_np).to(DEV)
+        perm = ops.tap_order(nbr)
+        tiles = ops.tile_index(nbr, perm)
+    else:
+        nbr = perm = tiles = None
+    A = torch.from_numpy(rng.randn(M, C).astype(np.float32)).to(DEV)
+    W = torch.from_numpy((rng.randn(O, C, F) / np.sqrt(C * F)).astype(np.float32)).to(DEV)
+    Wt = ops.weight_relayout(W, C, O, F, F, C * F, 1)
+    bias = torch.from_numpy(rng.randn(O).astype(np.float32)).to(DEV)
+    res = torch.from_numpy(rng.randn(M, O).astype(np.float32)).to(DEV)
+    rows2 = M // 2 + 1
+    kw = dict(bias=bias, act=ops.ACT_LEAKY, res=res)
+    outs, seconds = [], []
+    for order in ((perm, tiles), (None, None)):
+        wide = torch.full((M, O + 8), 7.0, device=DEV)
+        outs.append(ops.gconv_raw(A, nbr, M, C, F, Wt, O, row_perm=order[0], tiles=order[1], out2=wide[:, 4:4 + O],
+                                  rows2=rows2, **kw))
+        seconds.append(wide)
+    for o, w in zip(outs, seconds):
+        assert torch.equal(o, outs[0])                           # the row order is irrelevant
+        assert torch.equal(w[:rows2, 4:4 + O], o[:rows2])
+        assert bool((w[rows2:] == 7.0).all()) and bool((w[:, :4] == 7.0).all()) and bool((w[:, 4 + O:] == 7.0).all())
+    wide = torch.full((M, O + 8), 7.0, device=DEV)
+    unsplit = ops.gconv_raw(A, nbr, M, C, F, Wt, O, split_k=False, out2=wide[:, 4:4 + O], rows2=rows2, **kw)
+    assert torch.equal(wide[:rows2, 4:4 + O], unsplit[:rows2]) and bool((wide[rows2:] == 7.0).all())
+    assert rel_err(outs[0].cpu().numpy(), unsplit.cpu().numpy()) < 1e-5        # fp32 reassociation over K = F*C
+    naive = torch.full((M, O + 8), 7.0, device=DEV)
+    y_naive = ops.gconv_raw(A, nbr, M, C, F, Wt, O, naive=True, out2=naive[:, 4:4 + O], rows2=rows2, **kw)
+    assert torch.equal(naive[:rows2, 4:4 + O], y_naive[:rows2])
+    assert rel_err(outs[0].cpu().numpy(), y_naive.cpu().numpy()) < 1e-5

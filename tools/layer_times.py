@@ -5,16 +5,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import hplflownet_amd as H
 from hplflownet_amd import ops
-from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_, synthetic_pair
+from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_, surface_pair, synthetic_pair
 import bench
 dev = 'cuda'
 a = types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP, evaluate=True, use_leaky=True, bcn_use_bias=True,
                           bcn_use_norm=True, last_relu=False, DEVICE='cuda')
 model = H.HPLFlowNet(a); fill_module_(model, 1.0, 'hash'); model = model.to(dev).eval()
-gen = H.GenerateDataUnsymmetric(a, device=dev)
-pc1, pc2, sf = synthetic_pair(8192, 0)
+model.native_forward = False          # per-launch events wrap the Python ops
+gen = H.GenerateDataUnsymmetric(a, device=dev, wide_up=model.lattice_hint())
+pc1, pc2, sf = (surface_pair if 'surface' in sys.argv[1:] else synthetic_pair)(8192, 0)
 t1, t2, _, lat = gen([pc1, pc2, sf]); lat.prepare()
 timers = bench.KernelTimers(ops)
+shapes = []
+_g = ops.gconv_raw
+def _rec(A, nbr, M, C, F, Wt, N, **k):
+    if timers.enabled: shapes.append((M, N, C, F))
+    return _g(A, nbr, M, C, F, Wt, N, **k)
+ops.gconv_raw = _rec
 with torch.no_grad():
     for _ in range(3): model(t1[None], t2[None], lat)
     torch.cuda.synchronize(); timers.enabled = True
@@ -22,7 +29,9 @@ with torch.no_grad():
     s0.record(); model(t1[None], t2[None], lat); s1.record(); torch.cuda.synchronize()
 print('forward total %.3f ms' % s0.elapsed_time(s1))
 tot = 0
+shapes = iter(shapes)
 for (name, fl, nb), s, e in timers.records:
     us = 1e3 * s.elapsed_time(e); tot += us
-    print('%-18s %9.1f us  %s' % (name, us, ('%.1f GF %.1f TF' % (fl / 1e9, fl / us / 1e6)) if fl else ('%.1f MB %.0f GB/s' % (nb / 1e6, nb / us / 1e3))))
+    shp = ('M=%-6d N=%-5d C=%-4d F=%-2d' % next(shapes)) if fl else ''
+    print('%-18s %9.1f us  %-34s %s' % (name, us, shp, ('%.1f GF %.1f TF' % (fl / 1e9, fl / us / 1e6)) if fl else ('%.1f MB %.0f GB/s' % (nb / 1e6, nb / us / 1e3))))
 print('sum of timed kernels %.3f ms' % (tot / 1e3))
