@@ -533,7 +533,9 @@ def main():
             roofline['frac_algorithmic'] = roofline['achieved'] / MFMA_F32_PEAK_TFLOPS
             share, src = roofline.get('executed_fraction', 1.0), 'host mirror of the kernel\'s slice lists (bench.needed_slice_fraction)'
             pmc = os.path.join(ROOT, 'profiles', 'r02_mfma_pmc.json')
-            if full and os.path.exists(pmc):
+            # (the PMC figure is per launch of the default two-tap-group schedule: 4 launches per step, N = 8192)
+            if full and os.path.exists(pmc) and roofline.get('launches_per_step') == 4.0 and a.points == 8192 \
+                    and a.data == 'frustum':
                 try:
                     pj = json.load(open(pmc))
                     alg = roofline['gflop_per_step'] / roofline['launches_per_step']        # GF per launch

@@ -1,0 +1,58 @@
+"""GPU: the N > 1 code path of bench.py on the one GPU this box has -- two ranks (two processes), both on cuda:0, `gloo`
+for the barrier / max-over-ranks timing and, in training, for the gradient all-reduce (RCCL refuses two ranks on one
+device; the 8-GPU run over RCCL is the driver's).  Checks what the contract asks of a multi-rank run: every rank exits
+0, rank 0 prints ONE JSON line with the whole-job throughput over both ranks, rank 1 prints no result line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_two_ranks(extra, timeout=420):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', LOCAL_RANK='0',
+               HPL_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--no-cpu-baseline'] + extra
+    procs = [subprocess.Popen(cmd, cwd=ROOT, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in (1, 0)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                   # the exact processes started above
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    return outs[1][0], outs[0][0]                           # stdout of rank 0, of rank 1
+
+
+@pytest.mark.gpu
+def test_two_ranks_inference_on_one_gpu():
+    out0, out1 = _run_two_ranks(['--steps', '6', '--warmup', '1', '--points', '2048'])
+    assert not [ln for ln in out1.splitlines() if ln.startswith('{')]        # only rank 0 reports (gloo logs a line)
+    lines = [ln for ln in out0.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak' and d['value'] > 0
+    # whole-job throughput: both ranks' pairs over the slowest rank's time
+    assert abs(d['value'] - 2 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert d['pipelined_output_check']['max_abs_diff'] == 0.0
+
+
+@pytest.mark.gpu
+def test_two_ranks_training_step_on_one_gpu():
+    """bench.py --train with two ranks: one pair per rank, GradAllReducer hooks + bucketed all-reduce (gloo here), Adam."""
+    out0, out1 = _run_two_ranks(['--train', '--steps', '2', '--warmup', '1', '--points', '2048'])
+    assert not [ln for ln in out1.splitlines() if ln.startswith('{')]        # only rank 0 reports (gloo logs a line)
+    d = json.loads([ln for ln in out0.strip().splitlines() if ln.startswith('{')][0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['workload'].lower().find('train') >= 0
