@@ -610,7 +610,9 @@ def main():
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,
                 'host_ms_per_step': host_report(host, a.steps) if overlap else None,
-                'pipelined_output_check': pipe_check}
+                'pipelined_output_check': pipe_check,
+                'device_memory_mb': {'max_allocated': torch.cuda.max_memory_allocated(dev) / 2 ** 20,
+                                     'reserved': torch.cuda.memory_reserved(dev) / 2 ** 20}}
         if world == 1 and not a.no_cpu_baseline and not a.train:
             p1, p2, sf = pairs_np[0]
             base, flow_cpu, epe_cpu = cpu_baseline(pairs_np[:2], sfm, state, shallow=not full)
