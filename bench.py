@@ -533,11 +533,12 @@ def main():
             roofline['frac_algorithmic'] = roofline['achieved'] / MFMA_F32_PEAK_TFLOPS
             share, src = roofline.get('executed_fraction', 1.0), 'host mirror of the kernel\'s slice lists (bench.needed_slice_fraction)'
             pmc = os.path.join(ROOT, 'profiles', 'r02_mfma_pmc.json')
-            # (the PMC figure is per launch of the default two-tap-group schedule: 4 launches per step, N = 8192)
-            if full and os.path.exists(pmc) and roofline.get('launches_per_step') == 4.0 and a.points == 8192 \
-                    and a.data == 'frustum':
+            # (the PMC figure is per launch of the default tap-group schedule at N = 8192)
+            if full and os.path.exists(pmc) and a.points == 8192 and a.data == 'frustum':
                 try:
                     pj = json.load(open(pmc))
+                    if abs(pj.get('dominant_launches_per_step', 4.0) - roofline.get('launches_per_step', 0.0)) > 1e-6:
+                        raise ValueError('the PMC run used another tap-group schedule')
                     alg = roofline['gflop_per_step'] / roofline['launches_per_step']        # GF per launch
                     share = pj['dominant_executed_gflop_per_launch'] / alg
                     src = 'rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 (profiles/r02_mfma_pmc.json: %.1f GF executed per launch)' \

@@ -56,8 +56,11 @@ def main():
                 # busy cycles are summed over the SIMDs that report (per-XCD sampling): quote the ratio only
                 out['dominant_mfma_busy_cycles_per_gui_cycle'] = busy[1] / gui[1]
     if out.get('dominant_launches'):
-        # whole step: every MFMA kernel's executed flops, per step (the dominant class is launched 4 times per step)
-        steps = out['dominant_launches'] / 4.0
+        # whole step: every MFMA kernel's executed flops, per step.  Forwards in the run = launches of the one kernel
+        # instance that runs exactly once per forward (the first conv1 layer: C = 3, not vectorisable)
+        once = [k['launches'] for n_, k in out['kernels'].items() if re.search(r'k_gconv<64, 32, 2, 1, false, 1\b', n_)]
+        steps = float(once[0]) if once else out['dominant_launches'] / 4.0
+        out['dominant_launches_per_step'] = out['dominant_launches'] / steps
         out['executed_gflop_per_step'] = sum(k['launches'] * k['executed_gflop_per_launch'] for n_, k in out['kernels'].items()
                                              if 'k_mfma_probe' not in n_) / steps
         lines.append('# executed MFMA work of the whole step (all kernels): %.1f GF' % out['executed_gflop_per_step'])
