@@ -467,6 +467,24 @@ def main():
     # per-kernel detail: a separate, untimed, non-overlapped pass (an event pair around each of the
     # ~130 launches costs ~1.5 ms of host time per step, which the timed loop does not pay)
     detail_steps = min(a.steps, 10)
+    # one pair at a time on one stream, as a bs = 1 caller sees it: lattice build, then the forward (native path)
+    latency = None
+    if not a.train and native and not a.no_lattice:
+        lb = fw = 0.0
+        with torch.no_grad():
+            for i in range(6):
+                p1, p2 = pairs[i % a.pool]
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                lat_ = gen.build_native(p1, p2) if not a.python_lattice else gen.build(p1, p2)
+                torch.cuda.synchronize()
+                t1_ = time.perf_counter()
+                model(p1[None], p2[None], lat_)
+                torch.cuda.synchronize()
+                if i >= 2:
+                    lb, fw = lb + (t1_ - t0_), fw + (time.perf_counter() - t1_)
+        latency = {'lattice_build_ms': lb / 4 * 1e3, 'forward_ms': fw / 4 * 1e3,
+                   'note': 'host wall clock around one pair alone on the GPU, single stream (no overlap with other pairs)'}
     timers.records = []
     timers.only = None
     timers.enabled = True
@@ -611,7 +629,7 @@ def main():
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,
                 'host_ms_per_step': host_report(host, a.steps) if overlap else None,
-                'pipelined_output_check': pipe_check,
+                'pipelined_output_check': pipe_check, 'single_pair_latency_ms': latency,
                 'device_memory_mb': {'max_allocated': torch.cuda.max_memory_allocated(dev) / 2 ** 20,
                                      'reserved': torch.cuda.memory_reserved(dev) / 2 ** 20}}
         if world == 1 and not a.no_cpu_baseline and not a.train:
