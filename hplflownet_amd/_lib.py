@@ -101,7 +101,10 @@ _SIGNATURES = {
     'hpl_weight_relayout_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp, c_vp]),
     'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,
                                            c_i64, c_i64, c_i64, ctypes.c_int, c_vp]),
+    'hpl_tap_order_scratch_ints': (c_i64, [c_i64]),
     'hpl_tap_order': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
+    'hpl_tap_order_keyed': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp,
+                                           c_vp]),
     'hpl_tile_index': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_vp, c_vp, c_vp]),
     'hpl_gconv_forward': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
     'hpl_set_persistent': (ctypes.c_int, [ctypes.c_int]),

@@ -123,17 +123,21 @@ class NbrTable(object):
         #: points per vertex -> most neighbour slots empty) is where the multi-pass contraction pays
         #: (bcn1_, 42 % of the taps present: 2.62 -> 2.08 ms; bcn2_, 72 %: no gain)
         self.vertices_per_point = None
+        #: set by the lattice builder: (vkeys0, H0, vkeys1) lattice keys of the table's rows (ops.tap_order): the row
+        #: orders then keep spatially close vertices together inside a mask group
+        self.keys = None
 
     @property
     def perm(self):
         """Row order grouping vertices by tap-presence mask (see gconv row_perm)."""
         if self._perm is False:
             F, M = self.t.shape
-            self._perm = ops.tap_order(self.t) if (1 < F <= 15 and M >= self.PERM_MIN_ROWS) else None
+            self._perm = ops.tap_order(self.t, self.keys) if (1 < F <= 15 and M >= self.PERM_MIN_ROWS) else None
         return self._perm
 
     #: number of tap groups of the multi-pass contraction (ops.gconv tap_groups); env for A/B runs
-    TAP_GROUPS = int(os.environ.get('HPL_TAP_GROUPS', '2'))      # swept 1 / 2 / 3 / 5 end to end: 193 / 205 / 204 / 173 pairs/s
+    #: (hpl_level_tables carries at most 4 groups: larger values are clamped)
+    TAP_GROUPS = min(4, int(os.environ.get('HPL_TAP_GROUPS', '2')))      # swept 1 / 2 / 3 / 5 end to end: 193 / 205 / 204 / 173 pairs/s
     #: levels with at least this many lattice vertices per input point get the passes (level 0: 3.2, level 1:
     #: 1.34 -- bcn1_ and bcn2_; measured end to end 2.0 -> 1.2: 212.5 -> 218.5 pairs/s)
     GROUPS_MIN_SPARSITY = float(os.environ.get('HPL_GROUPS_MIN_SPARSITY', '1.2'))
@@ -149,7 +153,7 @@ class NbrTable(object):
                 self._groups = None
             else:
                 cuts = [round(i * F / G) for i in range(G + 1)]
-                self._groups = [(f0, f1, ops.tap_order(self.t[f0:f1])) for f0, f1 in zip(cuts[:-1], cuts[1:])]
+                self._groups = [(f0, f1, ops.tap_order(self.t[f0:f1], self.keys)) for f0, f1 in zip(cuts[:-1], cuts[1:])]
         return self._groups
 
     @property

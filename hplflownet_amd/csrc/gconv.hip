@@ -77,6 +77,7 @@ __device__ __forceinline__ int32x4_t make_rsrc(const void *base, int bytes) {
     return u.v;
 }
 
+constexpr int COL_CHUNK = 4;
 constexpr int BK = 32;   // contraction slice per step (floats) = one 128-byte line per gathered row
 // -DHPL_PROLOGUE_PRIO=1: s_setprio(3) over the tile prologue.  Measured (profiles/r02w_prologue_prio.txt): the prologue
 // shrinks 21 k -> 15 k cycles and the co-resident workgroup's loop slows by the same amount (the matrix pipe is shared:
@@ -136,7 +137,10 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
         const int id2 = (x2 < r2 ? x2 * (q2 + 1) : r2 * (q2 + 1) + (x2 - r2) * q2) + pos2;
         const int v = id2 / p.col_rows, pos = id2 - v * p.col_rows;
         tn = v / p.col_share;
-        const int row = pos * p.col_share + (v - tn * p.col_share);
+        // XCDs sharing a column tile take its scheduled tile-rows in chunks of COL_CHUNK: tiles that are neighbours in
+        // the schedule (= in the row order) run on one XCD and share gathered rows in its L2
+        const int sh = v - tn * p.col_share;
+        const int row = p.col_share == 1 ? pos : (pos / COL_CHUNK) * COL_CHUNK * p.col_share + sh * COL_CHUNK + pos % COL_CHUNK;
         tm = row < p.tiles_m ? (p.tile_idx ? p.tile_mask[(int64_t)row * 8 + 6] : p.tiles_m - 1 - row) : -1;
         return;
     }
@@ -1171,7 +1175,7 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
         int g = 8, b = p.tiles_n % 8;
         while (b) { const int t = g % b; g = b; b = t; }
         p.col_share = 8 / g;
-        p.col_rows = (int)cdiv(p.tiles_m, p.col_share);
+        p.col_rows = p.col_share == 1 ? p.tiles_m : (int)cdiv(p.tiles_m, COL_CHUNK * p.col_share) * COL_CHUNK;
         grid = p.tiles_n * p.col_share * p.col_rows;
     }
     if constexpr (BM == 64 && BN == 128 && WGM == 2 && WGN == 4) {
@@ -1289,21 +1293,30 @@ namespace {
 // the mask's numeric value, which is not their weight; with the heaviest tiles first the workgroups of a launch
 // finish within one light tile of each other instead of one average tile.
 __global__ void __launch_bounds__(1024) k_tile_rank(int32_t *__restrict__ tile_mask, int tiles) {
-    __shared__ int hist[16], cursor[16];
-    const int t = threadIdx.x;
-    if (t < 16) hist[t] = 0;
+    // stable counting sort by tap count, descending: thread (c, seg) owns class c in segment seg of the tile list
+    __shared__ int cnt[16][64];
+    __shared__ int base[16];
+    const int t = threadIdx.x, c = t >> 6, seg = t & 63;
+    const int per = (tiles + 63) / 64;
+    const int j0 = seg * per, j1 = min(tiles, j0 + per);
+    int n = 0;
+    for (int j = j0; j < j1; ++j) n += (__popc(tile_mask[(int64_t)j * 8] & 0x7fff) == c) ? 1 : 0;
+    cnt[c][seg] = n;
     __syncthreads();
-    for (int j = t; j < tiles; j += blockDim.x) atomicAdd(&hist[__popc(tile_mask[(int64_t)j * 8] & 0x7fff)], 1);
+    if (t < 16) {
+        int run = 0;
+        for (int s2 = 0; s2 < 64; ++s2) { const int v = cnt[t][s2]; cnt[t][s2] = run; run += v; }
+        base[t] = run;                      // class total
+    }
     __syncthreads();
     if (t == 0) {
         int off = 0;
-        for (int b = 15; b >= 0; --b) { cursor[b] = off; off += hist[b]; }
+        for (int b = 15; b >= 0; --b) { const int v = base[b]; base[b] = off; off += v; }
     }
     __syncthreads();
-    for (int j = t; j < tiles; j += blockDim.x) {
-        const int r = atomicAdd(&cursor[__popc(tile_mask[(int64_t)j * 8] & 0x7fff)], 1);
-        tile_mask[(int64_t)r * 8 + 6] = j;
-    }
+    int pos = base[c] + cnt[c][seg];
+    for (int j = j0; j < j1; ++j)
+        if (__popc(tile_mask[(int64_t)j * 8] & 0x7fff) == c) tile_mask[(int64_t)(pos++) * 8 + 6] = j;
 }
 }  // namespace
 

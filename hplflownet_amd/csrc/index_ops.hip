@@ -390,51 +390,6 @@ int exclusive_scan_i32(const int32_t *cnt, int64_t n, int32_t *ptr, int32_t *tmp
 }
 }  // namespace hpl
 
-// ---------------------------------------------------------------- tap-mask row order
-// perm = vertices grouped by their tap-presence mask: counting sort over 2^F * 16 bins, key =
-// (mask << 4) | (m & 15).  The 16 sub-bins per mask only spread the atomics (a few masks -- all
-// taps present, centre only -- collect thousands of vertices; one bin per mask serialised them in
-// L2: 135 -> 30 us at M = 70 k); the order inside a mask group comes from atomics and is irrelevant
-// to the results of the consumer.
-constexpr int TAP_SUB_BITS = 4;
-
-__global__ void k_tap_hist(const int32_t *__restrict__ nbr, int64_t stride, int F, int64_t M,
-                           int32_t *__restrict__ key_out, int32_t *__restrict__ hist) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    int mask = 0;
-    for (int f = 0; f < F; ++f) mask |= (nbr[(int64_t)f * stride + m] >= 0) ? (1 << f) : 0;
-    const int key = (mask << TAP_SUB_BITS) | (int)(m & ((1 << TAP_SUB_BITS) - 1));
-    key_out[m] = key;
-    atomicAdd(&hist[key], 1);
-}
-
-__global__ void k_tap_fill(const int32_t *__restrict__ key, int64_t M, const int32_t *__restrict__ ptr,
-                           int32_t *__restrict__ cursor, int32_t *__restrict__ perm) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    const int k = key[m];
-    perm[ptr[k] + atomicAdd(&cursor[k], 1)] = (int32_t)m;
-}
-
-extern "C" int hpl_tap_order(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *perm,
-                             int32_t *scratch, hplStream stream) {
-    HPL_REQUIRE(nbr && perm && scratch && F >= 1 && F <= 15 && M > 0 && M < (int64_t)INT32_MAX,
-                "hpl_tap_order: bad arguments (F=%d M=%lld)", F, (long long)M);
-    hipStream_t s = to_stream(stream);
-    const int64_t bins = (int64_t)1 << (F + TAP_SUB_BITS);
-    const int64_t cap = (int64_t)1 << (15 + TAP_SUB_BITS);
-    int32_t *key = scratch, *hist = key + M, *ptr = hist + cap, *tmp = ptr + cap + 8;
-    k_zero_i32<<<(int)imin(cdiv(bins, 256), 2048), 256, 0, s>>>(hist, bins);
-    k_tap_hist<<<(int)cdiv(M, 256), 256, 0, s>>>(nbr, nbr_stride, F, M, key, hist);
-    int rc = exclusive_scan_i32(hist, bins, ptr, tmp, s);
-    if (rc != HPL_OK) return rc;
-    k_zero_i32<<<(int)imin(cdiv(bins, 256), 2048), 256, 0, s>>>(hist, bins);
-    k_tap_fill<<<(int)cdiv(M, 256), 256, 0, s>>>(key, M, ptr, hist, perm);
-    HPL_CHECK_LAUNCH("hpl_tap_order");
-    return HPL_OK;
-}
-
 // ---------------------------------------------------------------- per-tap vertex lists
 // list_m / list_row[tap_ptr[f] .. tap_ptr[f+1]) = the vertices m with nbr[f][m] >= 0 (ascending,
 // deterministic) and their source rows nbr[f][m].

@@ -6,6 +6,7 @@
 #include "common.h"
 
 #include <new>
+#include <stdlib.h>
 
 using namespace hpl;
 
@@ -26,6 +27,7 @@ struct hpl_lattice {
     int level = 0;                 // level whose counts are pending
     bool active = false, done = false, overflow = false;
     int64_t n[2] = {0, 0};
+    int64_t n_vert[2] = {0, 0};    // vertices of the level being finished
     const float *pc[2] = {nullptr, nullptr};
     // per level scratch kept until its second half
     void *ws = nullptr;
@@ -91,13 +93,17 @@ int level_head(hpl_lattice *b) {
     return HPL_OK;
 }
 
+// M <= H0: rows are cloud-1 vertices; M = H0 + H1: the stacked pair
 int order_of(hpl_lattice *b, const int32_t *nbr, int64_t stride, int F, int64_t M, const int32_t **perm,
              const int32_t **tidx, const int32_t **tmask) {
     int32_t *p = b->take<int32_t>(M);
     const int64_t tiles = cdiv(M, TILE_BM);
     int32_t *ti = b->take<int32_t>(tiles * F * TILE_BM), *tm = b->take<int32_t>(tiles * 8);
     if (b->overflow) return HPL_ENOMEM;
-    int rc = hpl_tap_order(nbr, stride, F, M, p, b->scratch, b->hs);
+    static const bool keyed = !(getenv("HPL_ROW_ORDER") && atoi(getenv("HPL_ROW_ORDER")) == 0);      // A/B switch
+    const int64_t H0 = b->n_vert[0];
+    int rc = keyed ? hpl_tap_order_keyed(nbr, stride, F, M, b->vk[0], 4 * b->n[0], H0, b->vk[1], 4 * b->n[1], p, b->scratch, b->hs)
+                   : hpl_tap_order(nbr, stride, F, M, p, b->scratch, b->hs);
     if (rc) return rc;
     rc = hpl_tile_index(nbr, stride, F, M, p, TILE_BM, ti, tm, b->hs);
     if (rc) return rc;
@@ -115,6 +121,7 @@ int level_tail(hpl_lattice *b) {
     HPL_REQUIRE(H0 > 0 && H1 > 0 && H0 <= 4 * n0 && H1 <= 4 * n1, "hpl_lattice: implausible vertex counts %lld / %lld at level %d",
                 (long long)H0, (long long)H1, L);
     t.H0 = H0; t.H1 = H1;
+    b->n_vert[0] = H0; b->n_vert[1] = H1;
     const int bcn = sp.bcn_radius[L], cf = sp.corr_filter_radius[L], cc = sp.corr_corr_radius[L];
     const int64_t Hp = H0 + H1;
     int32_t *blur = nullptr, *corr1 = nullptr, *corr2 = nullptr;
@@ -130,7 +137,7 @@ int level_tail(hpl_lattice *b) {
     // splat CSR of the pair + the scratch shared by the CSR build and the tap orders
     int32_t *csr_ptr = b->take<int32_t>(Hp + 1), *csr_pt = b->take<int32_t>(4 * (n0 + n1));
     float *csr_w = b->take<float>(4 * (n0 + n1)), *norm = b->take<float>(Hp);
-    const int64_t scratch_ints = imax(Hp + 1 + 4 * (n0 + n1) + 1026, Hp + 2 * 524288 + 1100);
+    const int64_t scratch_ints = imax(Hp + 1 + 4 * (n0 + n1) + 1026, hpl_tap_order_scratch_ints(Hp));
     b->scratch = b->take<int32_t>(scratch_ints);
     if (b->overflow) return HPL_ENOMEM;
     int rc = hpl_lattice_neighbors(b->ws, n0, n1, b->vk[0], b->vk[1], H0, H1, bcn, cf, cc, blur, blur ? blur + H0 : nullptr,

@@ -187,6 +187,7 @@ class Trainer(object):
         # added over the ranks, so all ranks return the metrics of the WHOLE split (and agree on `best` in fit())
         keys = list(agg) if agg else ['EPE3D', 'Acc3DS', 'Acc3DR', 'Outliers']
         tot = parallel.sum_over_ranks([agg.get(k, 0.0) for k in keys] + [float(len(data))], device=self.device)
+        self.val_samples = int(tot[-1])         # over all ranks: 0 = no rank had a validation sample
         return {k: v / max(1.0, tot[-1]) for k, v in zip(keys, tot[:-1])}
 
     # ------------------------------------------------------------------ checkpoints
@@ -219,7 +220,14 @@ class Trainer(object):
     def fit(self, train_data, val_data, epochs, ckpt_dir=None, log=print, shuffle=False):
         for _ in range(self.epoch, epochs):
             tr = self.train_epoch(train_data, self.shuffle.permutation(len(train_data)) if shuffle else None)
-            val = self.validate(val_data)['EPE3D'] if val_data is not None and len(val_data) else tr
+            # validate() ends in a collective: every rank calls it whenever the split exists, also with an empty shard
+            # (fewer validation samples than ranks); the decision to fall back to the train loss is taken on the
+            # globally reduced sample count so that all ranks agree
+            val = tr
+            if val_data is not None:
+                res = self.validate(val_data)
+                if self.val_samples > 0:
+                    val = res['EPE3D']
             best = self.min_loss is None or val < self.min_loss
             if best:
                 self.min_loss = val

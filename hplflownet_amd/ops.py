@@ -132,12 +132,21 @@ class PairTables(object):
         return out
 
 
-def tap_order(nbr):
-    """int32 [F<=15, M] neighbour table -> int32 [M] permutation grouping the rows by tap-presence mask."""
+def tap_order(nbr, keys=None):
+    """int32 [F<=15, M] neighbour table -> int32 [M] permutation sorting the rows by tap-presence mask
+    (deterministic: ties by row id).  keys = (vkeys0 [4, >=H0], H0, vkeys1 [4, >=M-H0] or None): the lattice key of
+    every vertex -- rows of one mask group then follow the Morton code of their key (hpl_tap_order_keyed)."""
     F, M = nbr.shape
+    L = _lib.load()
     perm = torch.empty(M, dtype=torch.int32, device=nbr.device)
-    scratch = torch.empty(M + 2 * 524288 + 1100, dtype=torch.int32, device=nbr.device)
-    check(_lib.load().hpl_tap_order(ptr(nbr), nbr.stride(0), F, M, ptr(perm), ptr(scratch), stream()), 'hpl_tap_order')
+    scratch = torch.empty((int(L.hpl_tap_order_scratch_ints(M)) + 1) // 2, dtype=torch.int64, device=nbr.device)
+    if keys is None:
+        check(L.hpl_tap_order(ptr(nbr), nbr.stride(0), F, M, ptr(perm), ptr(scratch), stream()), 'hpl_tap_order')
+    else:
+        vk0, H0, vk1 = keys
+        check(L.hpl_tap_order_keyed(ptr(nbr), nbr.stride(0), F, M, ptr(vk0), vk0.stride(0), H0, ptr(vk1),
+                                    vk1.stride(0) if vk1 is not None else 0, ptr(perm), ptr(scratch), stream()),
+              'hpl_tap_order_keyed')
     return perm
 
 
@@ -631,8 +640,18 @@ def invalidate_weight_cache():
     version counter and data pointer, which writes through `param.data` (`p.data.copy_(...)`, reference-style
     `model.apply(init)` with `m.weight.data`) do NOT change: call this after editing weights that way.
     (In-place writes through the parameter under torch.no_grad(), load_state_dict and optimiser steps bump the
-    version and need nothing.)"""
+    version and need nothing.)  The native forward plans (plan.ForwardPlan) key on the epoch bumped here as well: they
+    refresh their weight images and combined biases at their next use."""
+    global _WEIGHT_EPOCH
     _WT_CACHE.clear()
+    _WEIGHT_EPOCH += 1
+
+
+_WEIGHT_EPOCH = 0
+
+
+def weight_epoch():
+    return _WEIGHT_EPOCH
 
 
 def _cached_relayout(weight, C, O, F, Ctot, c0):

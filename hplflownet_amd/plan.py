@@ -12,6 +12,7 @@ Only device-built lattices (hplflownet_amd.lattice) are accepted; anything else 
 autograd -- takes the Python path of the model.
 """
 import ctypes
+import weakref
 
 import time
 
@@ -373,12 +374,19 @@ def level_tables(lat, hint):
 
 class ForwardPlan(object):
     def __init__(self, model):
-        self.model = model
+        # The plan is the VALUE of flownet._PLANS (a WeakKeyDictionary keyed by the model): it must not keep its own key
+        # alive, or every model that ever ran a native forward would stay resident together with its weight images and
+        # workspaces.  The model is held weakly; the parameters are reached through it.
+        self._model = weakref.ref(model)
+        self.NLEV = model.NLEV
+        self.epoch = ops.weight_epoch()
         self.bank = ops.WeightBank()
+        self._images_ready = None       # event recorded behind the last write of the weight images / combined biases
+        self._images_stream = None
         with torch.no_grad():
             self.prog = build_program(model, self.bank)
             self.bank.refresh()
-        self._params = [p for p in model.parameters()]
+        self._mark_images_written()
         self._sig = self._signature()
         L = _lib.load()
         P = self.prog
@@ -407,32 +415,65 @@ class ForwardPlan(object):
         try:
             if getattr(self, 'handle', None):
                 self._lib.hpl_plan_destroy(self.handle)
+            self._ws.clear()
         except Exception:
             pass
 
+    @property
+    def model(self):
+        return self._model()
+
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self._params)
+        m = self._model()
+        if m is None:
+            return None
+        return (self.epoch,) + tuple((p.data_ptr(), p._version) for p in m.parameters())
+
+    def _mark_images_written(self):
+        """The weight images and combined biases were just (re)written on the current stream: forwards on OTHER
+        streams must not read them before that work has run (bench.py alternates forwards over three streams)."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self._images_ready, self._images_stream = ev, stream()
+
+    def _wait_images(self):
+        ev = self._images_ready
+        if ev is None:
+            return
+        if ev.query():
+            self._images_ready = None            # seen complete once: visible to every later launch on any stream
+        elif stream() != self._images_stream:
+            torch.cuda.current_stream().wait_event(ev)
 
     def fresh(self):
         """False once a parameter was replaced (new storage): the plan holds stale pointers, build a new one."""
+        self.epoch = ops.weight_epoch()          # ops.invalidate_weight_cache() bumps it: edits through .data
         sig = self._signature()
+        if sig is None:
+            return False
         if sig == self._sig:
             return True
-        if any(a[0] != b[0] for a, b in zip(sig, self._sig)):
+        if any(a[0] != b[0] for a, b in zip(sig[1:], self._sig[1:])):
             return False
         with torch.no_grad():                                  # same storage, new values: refresh the images in place
+            # forwards still in flight on other streams read the images being overwritten: order the refresh behind them
+            cur = torch.cuda.current_stream()
+            for ev in self._fence.values():
+                if ev is not None and not ev.query():
+                    cur.wait_event(ev)
             self.bank.refresh()
             for t, (a, b) in self.prog.combined:
                 t.copy_(a.detach() + b.detach())
+        self._mark_images_written()
         self._sig = sig
         return True
 
     def accepts(self, lat):
-        if getattr(lat, 'tables', None) is not None and getattr(lat, 'n_levels', 0) >= self.model.NLEV:
+        if getattr(lat, 'tables', None) is not None and getattr(lat, 'n_levels', 0) >= self.NLEV:
             return True                                    # lattice.NativeLattice
-        if not isinstance(lat, DeviceLattice) or len(lat.levels) < self.model.NLEV:
+        if not isinstance(lat, DeviceLattice) or len(lat.levels) < self.NLEV:
             return False
-        for lv in lat.levels[:self.model.NLEV]:
+        for lv in lat.levels[:self.NLEV]:
             if lv.pair is None or not isinstance(lv.blur, PairBlur):
                 return False
         return True
@@ -462,11 +503,12 @@ class ForwardPlan(object):
         if arr[0].n0 != p1.shape[1] or arr[0].n1 != p2.shape[1]:
             raise _lib.HplError('lattice was built for %d / %d points, got %d / %d'
                                 % (arr[0].n0, arr[0].n1, p1.shape[1], p2.shape[1]))
-        nlev = self.model.NLEV
+        nlev = self.NLEV
         need = self._lib.hpl_plan_workspace_bytes(self.handle, arr, nlev)
         if need < 0:
             raise _lib.HplError('hpl_plan_workspace_bytes: %s' % self._lib.hpl_last_error().decode())
         slot, ws = self.workspace(need, p1.device)
+        self._wait_images()
         out = torch.empty((p1.shape[1], 3), dtype=torch.float32, device=p1.device)
         check(self._lib.hpl_plan_run(self.handle, arr, nlev, ptr(p1), ptr(p2), ptr(out), ws.data_ptr(), ws.numel(),
                                      stream()), 'hpl_plan_run')

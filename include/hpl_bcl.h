@@ -196,16 +196,26 @@ typedef struct hpl_gconv_desc {
     int64_t rows2;
 } hpl_gconv_desc;
 
-/* Row order for tap skipping: perm = the M vertices grouped by their F-bit tap-presence mask
- * (bit f set iff nbr[f*nbr_stride + m] >= 0; F <= 15).  Order inside a group is unspecified (it
- * does not affect results).  scratch: M + 2 * 524288 + 1100 int32. */
+/* Row order for tap skipping: perm = the M vertices sorted by their F-bit tap-presence mask (bit f set iff
+ * nbr[f*nbr_stride + m] >= 0; F <= 15), ties by ascending row id (a stable radix sort: the order is deterministic and
+ * does not affect results).  scratch: hpl_tap_order_scratch_ints(M) int32, 8-byte aligned. */
+int64_t hpl_tap_order_scratch_ints(int64_t M);
 int hpl_tap_order(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *perm,
                   int32_t *scratch, hplStream stream);
+/* The same with a locality-preserving order inside every mask group: rows follow the Morton code of their lattice
+ * key (transforms/transforms.py:179-192 `last_pc`: the key of every vertex), so that a tile of consecutive rows is a
+ * spatially compact set of vertices and neighbouring tiles gather overlapping source rows.  Row m < H0 is vertex m
+ * of the first key array (coordinate j at vkeys0[j*vstride0 + m], as hpl_lattice_hash writes them), row m >= H0
+ * vertex m - H0 of the second (the stacked pair tables); vkeys1 may be NULL when M <= H0. */
+int hpl_tap_order_keyed(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, const int32_t *vkeys0,
+                        int64_t vstride0, int64_t H0, const int32_t *vkeys1, int64_t vstride1, int32_t *perm,
+                        int32_t *scratch, hplStream stream);
 
 /* Per-tile gather indices of a row-ordered launch: tile j covers output rows row_perm[j*BM .. j*BM+BM) (identity
  * when row_perm is NULL); tile_idx[j][f][r] = nbr[f][row_perm[j*BM + r]] (-1 past M), tile_mask[j][0] = taps present
  * in the tile, [2 + b] = taps present in its b-th block of 32 rows, [j][6] = the tile that is scheduled j-th (most taps
- * first: a launch's workgroups then finish within one light tile of each other), the rest 0.  Sizes: ceil(M/BM)*F*BM and
+ * first: a launch's workgroups then finish within one light tile of each other; equal tap counts in tile order, so
+ * that tiles scheduled back to back are neighbours in the row order), the rest 0.  Sizes: ceil(M/BM)*F*BM and
  * ceil(M/BM)*8 int32.  Built once per lattice and row order (models/bilateralNN.py:215-217 gathers through the same
  * table in every layer call). */
 int hpl_tile_index(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, const int32_t *row_perm, int BM,
