@@ -37,7 +37,7 @@ class GConvDesc(ctypes.Structure):
                 ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('w_rows', c_i32),
                 ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64),
                 ('tile_idx', c_vp), ('tile_mask', c_vp), ('tile_bm', c_i32), ('clock_probe', c_vp),
-                ('Y2', c_vp), ('ldy2', c_i64), ('rows2', c_i64)]
+                ('Y2', c_vp), ('ldy2', c_i64), ('rows2', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64)]
 
 
 class Ref(ctypes.Structure):
@@ -52,7 +52,7 @@ class Buf(ctypes.Structure):
 
 class Weight(ctypes.Structure):
     """Mirror of `hpl_weight`."""
-    _fields_ = [('Wt', c_vp), ('ldw', c_i64), ('rows', c_i64)]
+    _fields_ = [('Wt', c_vp), ('ldw', c_i64), ('rows', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64)]
 
 
 class Op(ctypes.Structure):
@@ -70,7 +70,7 @@ class LevelTables(ctypes.Structure):
                 ('csr_ptr', c_vp), ('csr_pt', c_vp), ('csr_w', c_vp), ('csr_norm', c_vp), ('bary0', c_vp), ('off0', c_vp),
                 ('blur', c_vp), ('blur_stride', c_i64), ('blur_perm', c_vp), ('up_perm', c_vp), ('n_up_groups', c_i32),
                 ('up_group_cut', c_i32 * 5), ('up_group_perm', c_vp * 4), ('corr1', c_vp), ('corr1_stride', c_i64),
-                ('corr1_perm', c_vp), ('corr2', c_vp), ('tile_bm', c_i32),
+                ('corr1_perm', c_vp), ('corr2', c_vp), ('tile_bm', c_i32), ('group_tile_bm', c_i32),
                 ('blur_perm_tidx', c_vp), ('blur_perm_tmask', c_vp), ('up_perm_tidx', c_vp), ('up_perm_tmask', c_vp),
                 ('up_group_tidx', c_vp * 4), ('up_group_tmask', c_vp * 4), ('corr1_perm_tidx', c_vp),
                 ('corr1_perm_tmask', c_vp)]
@@ -80,7 +80,7 @@ class LatticeSpec(ctypes.Structure):
     """Mirror of `hpl_lattice_spec`."""
     _fields_ = [('n_levels', c_i32), ('scale', c_f32 * 8), ('bcn_radius', c_i32 * 8), ('corr_filter_radius', c_i32 * 8),
                 ('corr_corr_radius', c_i32 * 8), ('next_divisor', c_f32 * 8), ('wide_up', c_i32 * 8), ('n_groups', c_i32),
-                ('group_cut', c_i32 * 5), ('groups_min_sparsity', c_f32), ('perm_min_rows', c_i64)]
+                ('group_cut', c_i32 * 5), ('groups_min_sparsity', c_f32), ('perm_min_rows', c_i64), ('group_tile_bm', c_i32)]
 
 
 _SIGNATURES = {
@@ -99,6 +99,9 @@ _SIGNATURES = {
     'hpl_weight_relayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i64, c_i64,
                                            c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
     'hpl_weight_relayout_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp, c_vp]),
+    'hpl_weight_split3': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    'hpl_split3_info': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                       ctypes.POINTER(ctypes.c_int)]),
     'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,
                                            c_i64, c_i64, c_i64, ctypes.c_int, c_vp]),
     'hpl_tap_order_scratch_ints': (c_i64, [c_i64]),

@@ -167,7 +167,7 @@ class NbrTable(object):
         """[(tile_idx, tile_mask)] aligned with groups(), None without groups."""
         if self._group_tiles is False:
             g = self.groups()
-            self._group_tiles = [ops.tile_index(self.t[f0:f1], pm) for f0, f1, pm in g] if (g and not _NO_TILES) else None
+            self._group_tiles = [ops.tile_index(self.t[f0:f1], pm, BM=ops.GROUP_TILE_BM) for f0, f1, pm in g] if (g and not _NO_TILES) else None
         return self._group_tiles
 
     #: per-tap vertex lists pay for wide layers only (wgrad tap mode needs C >= 128-ish) and big tables

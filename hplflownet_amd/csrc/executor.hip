@@ -242,7 +242,12 @@ struct Runner {
             d.Y = Y.p; d.ldy = Y.ld;
             if (last && has_out2) { d.Y2 = Y2.p; d.ldy2 = Y2.ld; d.rows2 = rows2; }
             d.row_perm = row_perm;
-            if (row_perm && ti && tm) { d.tile_idx = ti; d.tile_mask = tm; d.tile_bm = t.tile_bm; }
+            if (row_perm && ti && tm) { d.tile_idx = ti; d.tile_mask = tm; d.tile_bm = ngroups >= 2 ? t.group_tile_bm : t.tile_bm; }
+            // split-operand image of the same rows (csrc/gconv3.hip takes the launch if it qualifies): k-blocks of 8 rows
+            if (w.Wt3 && ((int64_t)f0 * op.C) % 8 == 0) {
+                d.Wt3 = static_cast<const char *>(w.Wt3) + (int64_t)f0 * op.C / 8 * w.ldw * 16;
+                d.wt3_plane_stride = w.wt3_plane_stride;
+            }
             if (prof) d.clock_probe = pl.clock_probe;
             if (M * op.N <= SPLITK_ELEMS) { d.ws = splitk; d.ws_bytes = SPLITK_WS_BYTES; }
             bracket(prof, false);

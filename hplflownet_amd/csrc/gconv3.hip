@@ -1,0 +1,508 @@
+// gconv3.hip -- the wide gather-GEMM launches on the bf16 matrix pipe with fp32-exact split operands.
+//
+//   Y[m, n] = act(bias[n] + res + sum_{f<F} sum_{c<C} A[nbr[f][m], c] * Wt[f*C + c, n])        (as gconv.hip)
+//
+// gfx950 multiplies fp32 operands on the matrix cores at 1/16 of the bf16 rate (v_mfma_f32_32x32x2_f32: 64 cycles
+// for k = 2; v_mfma_f32_32x32x16_bf16: 32 cycles for k = 16).  An fp32 number is EXACTLY the sum of three bf16
+// numbers (8 + 8 + 8 significand bits: hi = rne(x), mid = rne(x - hi), lo = x - hi - mid, every step exact), so
+//      a * b = sum_{i,j} a_i * b_j,      a = a_0 + a_1 + a_2,  b = b_0 + b_1 + b_2,
+// and each partial product of two bf16 values is exact in fp32.  This kernel accumulates the six partial products
+// with i + j <= 2 in fp32 on the bf16 MFMA; the three it drops are bounded by 2^-25 |a b| together (|a_i| <= 2^-9i |a|
+// with round-to-nearest splits) -- below the 2^-24 rounding of an fp32 fused multiply-add.  6 MFMAs of 32 cycles per
+// k = 16 against 8 of 64: 16/6 = 2.67x the fp32-MFMA rate at fp32-class accuracy (tests/test_gpu_split3.py measures
+// both paths against float64).  Activations stay fp32 in HBM and are split while they are staged into LDS; the
+// weights are split once per model into three planes (hpl_weight_split3).
+//
+// Geometry: 128 x (64*WGN) output tile, 2 x WGN waves, each wave 64 x 64 (2 x 2 MFMA tiles of 32 x 32, 64 accumulator
+// registers).  The contraction runs over the tile's list of needed 32-wide slices (as gconv.hip: slices whose taps are
+// absent for the whole tile are skipped) in HALF-slices of 16 -- one MFMA k-step -- through a ring of three LDS stages:
+// while half-step g is multiplied, the gathered rows of half-step g+2 are split and stored, and its weight fragments
+// arrive by LDS-direct loads (the three planes are stored [k/8][n][8] in HBM, i.e. already in MFMA B-fragment order).
+// Gathered rows are loaded as full 128-byte lines (8 lanes x 16 B), two register sets, one slice ahead.
+// LDS per workgroup: 3 x 24 KB + indices (128 x 128 tile): two workgroups per CU.
+#include "common.h"
+#include "gconv_common.h"
+
+#include <stdlib.h>
+#include <string>
+#include <type_traits>
+
+using namespace hpl;
+using namespace hpl_gc;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+// (x0, x1) -> packed bf16 pairs hi / mid / lo with x = hi + mid + lo exactly (round-to-nearest-even at each level)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    const float2_t v = {x0, x1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    const float2_t rv = {r0, r1};
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, bf16x2));
+    const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    const float2_t sv = {s0, s1};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(sv, bf16x2));
+}
+
+constexpr int BM3 = 128;
+
+template <int WGN, int F_LDS>
+__global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
+    constexpr int BM = BM3, BN = 64 * WGN, NT = 128 * WGN;
+    constexpr int ROWS_PP = NT / 8;                 // rows covered by one gathered load instruction of the workgroup
+    constexpr int A_PASSES = BM / ROWS_PP;          // float4 per thread and slice: 4 (WGN = 2) or 2 (WGN = 4)
+    constexpr int HALF_PASSES = A_PASSES / 2;
+    constexpr int A_STAGE = 3 * 2 * BM * 16;        // bytes: [plane][kb 0..1][row][8 bf16]
+    constexpr int B_STAGE = 3 * 2 * BN * 16;        //        [plane][kb 0..1][n][8 bf16]
+    constexpr int STAGE = A_STAGE + B_STAGE;
+    constexpr int B_CHUNKS_PER_WAVE = 3;            // 6 * WGN chunks of 1 KiB per half-step over 2 * WGN waves
+    constexpr int KLIST = 1024;
+    static_assert(A_PASSES == 2 || A_PASSES == 4, "two halves of a slice per thread");
+    // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + (F_LDS * BM + BM + 8) * 4 + KLIST * 2];
+    int *Is = reinterpret_cast<int *>(smem + 3 * STAGE);
+    int *Vs = Is + F_LDS * BM;
+    int *tapmask_s = Vs + BM;                       // [0] taps of the tile, [1] slices needed, [2..5] taps of its 32-row blocks
+    unsigned short *Ks = reinterpret_cast<unsigned short *>(tapmask_s + 8);
+
+    int tile_m, tile_n;
+    tile_coords(p, tile_m, tile_n);
+    if (tile_m < 0) return;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int li = lane & 31, hi = lane >> 5;
+
+    const bool probe = p.clock_probe && (blockIdx.x & 63) == 0 && t == 0;
+    long long probe_c = 0, probe_w = 0;
+    if (probe) { probe_c = (long long)__builtin_readcyclecounter(); probe_w = (long long)__builtin_amdgcn_s_memrealtime(); }
+
+    // ---- tile prologue: output rows, source rows of every (tap, tile row), tap masks
+    if (p.tile_idx && p.tile_bm == BM) {
+        const int32_t *ti = p.tile_idx + (int64_t)tile_m * p.F * BM;
+        if (t < 8) tapmask_s[t] = p.tile_mask[(int64_t)tile_m * 8 + t];
+        for (int r = t; r < BM; r += NT) {
+            const int64_t m = m0 + r;
+            Vs[r] = (m < p.M) ? (p.row_perm ? p.row_perm[m] : (int)m) : -1;
+        }
+        for (int i = t; i < F_LDS * BM; i += NT) Is[i] = (i < p.F * BM) ? ti[i] : -1;
+    } else {
+        if (t < 8) tapmask_s[t] = 0;
+        for (int r = t; r < BM; r += NT) {
+            const int64_t m = m0 + r;
+            Vs[r] = (m < p.M) ? (p.row_perm ? p.row_perm[m] : (int)m) : -1;
+        }
+        __syncthreads();
+        int mybits = 0;
+        for (int i = t; i < F_LDS * BM; i += NT) {       // NT % BM == 0: a thread keeps its tile row
+            const int f = i / BM, r = i - f * BM;
+            const int v = Vs[r];
+            int row = -1;
+            if (v >= 0 && f < p.F) row = p.nbr ? p.nbr[(int64_t)f * p.nbr_stride + v] : (int)((int64_t)f * p.reg_stride + v);
+            Is[i] = row;
+            mybits |= (row >= 0) ? (1 << f) : 0;
+        }
+        if (mybits) {
+            atomicOr(tapmask_s, mybits);
+            atomicOr(tapmask_s + 2 + ((t % BM) >> 5), mybits);
+        }
+    }
+    __syncthreads();
+    const int tapmask = __builtin_amdgcn_readfirstlane(tapmask_s[0]);
+    const bool blockskip = p.C >= BK;
+    int bmask[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bmask[i] = __builtin_amdgcn_readfirstlane(tapmask_s[2 + wm * 2 + i]);
+    // list of the slices this tile needs (entry: bits 0..9 slice, 10..13 first tap, 14 "also the next tap")
+    const int nk = (p.K + BK - 1) / BK;
+    if (wave == 0) {
+        int count = 0;
+        for (int base = 0; base < nk; base += 64) {
+            const int kt = base + lane;
+            bool need = false;
+            int f_lo = 0;
+            if (kt < nk) {
+                f_lo = (kt * BK) / p.C;
+                const int f_hi = min((kt * BK + BK - 1) / p.C, p.F - 1);
+                int bits = 0;
+                for (int f = f_lo; f <= f_hi; ++f) bits |= 1 << f;
+                need = (tapmask & bits) != 0;
+            }
+            const unsigned long long bal = __ballot(need);
+            if (need) {
+                int e = kt;
+                if (blockskip) e |= (f_lo << 10) | (((kt * BK + BK - 1) / p.C > f_lo && f_lo + 1 < p.F) ? (1 << 14) : 0);
+                Ks[count + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
+            }
+            count += __popcll(bal);
+        }
+        if (lane == 0) tapmask_s[1] = count;
+    }
+    __syncthreads();
+    const int nsl = __builtin_amdgcn_readfirstlane(tapmask_s[1]);
+
+    // ---- staging state
+    constexpr unsigned OOB = 0x80000000u;
+    const int32x4_t rsrc_a = make_rsrc(p.A, (int)p.a_bytes);
+    const unsigned lda_b = (unsigned)p.lda * 4u;
+    const int kq = t & 7, arow0 = t >> 3, hb = (t >> 2) & 1;
+    // weight planes: rows of the image that exist = p.w_bytes / (ldw * 4) (a multiple of 8 by contract)
+    const unsigned w3_bytes = (unsigned)(p.w_bytes / 2);                  // (rows / 8) * ldw * 16 bytes per plane
+    __amdgpu_buffer_rsrc_t rsrc_b[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        rsrc_b[pl] = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char *>(reinterpret_cast<const unsigned char *>(p.Wt3) + (int64_t)pl * p.w3_plane_stride),
+            (short)0, (int)w3_bytes, 0x00020000);
+    const unsigned ldw16 = (unsigned)p.ldw * 16u;
+
+    // Gathered rows: buffer_load_dwordx4 through inline asm -- hipcc does not count an asm load in its s_waitcnt
+    // bookkeeping, so the loads of slice s+2 stay in flight across the half-step barriers instead of being drained at
+    // the first use of ANY load result inside the loop (its scoreboard merges conservatively over the back edge: the
+    // builtin form waited vmcnt(0) before every LDS store).  Completion is counted by hand: the end-of-half-step wait
+    // leaves only that half-step's own loads in flight (loads complete in order), so a register set is complete one
+    // half-step after its loads were issued; `pin` then orders the compiler's reads behind that wait.
+    float4_t ra[2][A_PASSES];
+    int f0_u = 0, c0_u = 0, k_u = 0;
+    auto load_a = [&](auto set_tag, int kt) {
+        constexpr int SET = decltype(set_tag)::value;
+        const int k0 = kt * BK;
+        c0_u += k0 - k_u;
+        k_u = k0;
+        while (c0_u >= p.C) { c0_u -= p.C; ++f0_u; }
+        unsigned off[A_PASSES];
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const int kqi = kq ^ ((i & 1) << 2);      // (full 128-byte lines per instruction; every thread ends up with
+            int c = c0_u + kqi * 4, f = f0_u;         //  HALF_PASSES float4 of each half-slice)
+            if (c >= p.C) { c -= p.C; ++f; }
+            const int row = Is[min(f, F_LDS - 1) * BM + arow0 + i * ROWS_PP];
+            const bool ok = (f < p.F) && (row >= 0);
+            off[i] = ok ? (unsigned)row * lda_b + (unsigned)c * 4u : OOB;
+        }
+        const int32x4_t rs = rsrc_a;                  // (asm operands inside a generic lambda must be its own locals)
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            float4_t &dst = ra[SET][i];
+            const unsigned o = off[i];
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(o), "s"(rs) : "memory");
+        }
+    };
+    auto pin = [&](auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            float4_t &x = ra[SET][i];
+            asm volatile("" : "+v"(x));
+        }
+    };
+    // half h of register set `set`: split + store into stage `st` (a thread holds float4 column (t & 3) of the half in
+    // its passes of parity hb ^ h)
+    // LDS slot of tile row r in k-block kb of a stage: r ^ swz(r, kb), swz = 2 * (r / 32) ^ 4 * kb (bits 1..2 of the
+    // row).  Without it the 16 lanes of a store group differ only in address bits that do not reach the bank index
+    // (k-blocks are 2 KiB apart, the two row sets of a thread 32 or 64 rows): 4-way conflicts, half of the LDS cycles
+    // (SQ_LDS_BANK_CONFLICT).  The fragment reads stay conflict-free: the XOR permutes rows inside aligned groups of 8.
+    auto a_slot = [](int row, int kb) { return row ^ ((((row >> 5) & 3) << 1) ^ (kb << 2)); };
+    const int kb_w = (t >> 1) & 1;
+    auto store_a = [&](auto set_tag, int h, int st, int j) {
+        constexpr int SET = decltype(set_tag)::value;
+        const bool odd = (hb ^ h) != 0;
+        const float4_t v = odd ? ra[SET][2 * j + 1] : ra[SET][2 * j];
+        const int row = arow0 + (2 * j + (odd ? 1 : 0)) * ROWS_PP;
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split2(v.x, v.y, h0, m0_, l0);
+        split2(v.z, v.w, h1, m1, l1);
+        unsigned char *base = smem + st * STAGE + (kb_w * BM + a_slot(row, kb_w)) * 16 + (t & 1) * 8;
+        *reinterpret_cast<u32x2 *>(base) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(base + 2 * BM * 16) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2 *>(base + 4 * BM * 16) = u32x2{l0, l1};
+    };
+    // weight fragments of half h of slice kt straight into stage st: wave (wm, wn) fetches k-block wm of the half for
+    // the 64 columns of column block wn, one 1 KiB LDS-direct load per plane
+    auto load_b = [&](int kt, int h, int st) {
+        const unsigned kbg = (unsigned)(kt * (BK / 8) + h * 2 + wm);
+        const unsigned col = (unsigned)(n0 + wn * 64 + lane);
+        const unsigned off = (col < (unsigned)p.ldw) ? kbg * ldw16 + col * 16u : OOB;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc_b[pl],
+                (__attribute__((address_space(3))) void *)(smem + st * STAGE + A_STAGE + ((pl * 2 + wm) * BN + wn * 64) * 16),
+                16, (int)off, 0, 0, 0);
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    unsigned a_rofs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + li;
+        a_rofs[i] = (unsigned)((hi * BM + (row ^ ((((row >> 5) & 3) << 1) ^ (hi << 2)))) * 16);
+    }
+    const unsigned b_rofs = (unsigned)(A_STAGE + (hi * BN + wn * 64 + li) * 16);
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using T = std::true_type;
+    using Fl = std::false_type;
+    auto wait_vm_lgkm0 = [](auto n_tag) {          // vmcnt <= N (loads complete in order), lgkmcnt = 0
+        constexpr int N = decltype(n_tag)::value;
+        __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0x0 << 8));
+    };
+
+    if (nsl > 0) {
+        // ---- fill: slice 0 -> stages 0, 1; slice 1 -> register set 1 (in flight)
+        const int kt0 = (int)(Ks[0] & 1023);
+        load_b(kt0, 0, 0);
+        load_b(kt0, 1, 1);
+        load_a(S0{}, kt0);
+        wait_vm_lgkm0(S0{});
+        pin(S0{});
+#pragma unroll
+        for (int j = 0; j < HALF_PASSES; ++j) { store_a(S0{}, 0, 0, j); store_a(S0{}, 1, 1, j); }
+        // (slice 1 is staged by the very first half-step, before any end-of-half-step wait has covered its loads:
+        // it has to land here)
+        if (nsl > 1) load_a(S1{}, (int)(Ks[1] & 1023));
+        wait_vm_lgkm0(S0{});
+        asm volatile("s_barrier" ::: "memory");
+
+        int st = 0;                                  // stage of the half-step being multiplied
+        // One half-step: multiply stage st (slice entry e_cur); W: stage half h of slice kt_w (half-step g + 2, register
+        // set SETW) into stage (st + 2) % 3; L: issue the gathered loads of slice kt_l into set SETL.
+        auto halfstep = [&](int e_cur, auto w_tag, auto setw_tag, int kt_w, int h, auto l_tag, auto setl_tag, int kt_l) {
+            constexpr bool W = decltype(w_tag)::value, L = decltype(l_tag)::value;
+            const int st2 = st >= 1 ? st - 1 : 2;               // (st + 2) % 3
+            const unsigned char *sa = smem + st * STAGE;
+            bool need[2];
+            {
+                const int f_lo = (e_cur >> 10) & 15, two = (e_cur >> 14) & 1;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    need[i] = !blockskip || (((bmask[i] >> f_lo) | (two ? (bmask[i] >> (f_lo + 1)) : 0)) & 1);
+            }
+            u32x4 af[3][2], bf[3][2];
+            if (need[0] || need[1]) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        af[pl][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i] + pl * 2 * BM * 16);
+                        bf[pl][i] = *reinterpret_cast<const u32x4 *>(sa + b_rofs + pl * 2 * BN * 16 + i * 32 * 16);
+                    }
+            }
+            if constexpr (W) load_b(kt_w, h, st2);
+            if constexpr (L) load_a(setl_tag, kt_l);
+            if constexpr (W) { if (h == 0) pin(setw_tag); }
+            // products a_i * b_j with i + j <= 2, smallest first; per 32-row block alternating over its two accumulators
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+            if (need[0] && need[1]) {
+                // the common case, straight-line: the splits and LDS stores of the staged half-slice are dropped into the
+                // shadows of the MFMAs (a wave issues in order: left behind the MFMAs they would add ~600 cycles per
+                // half-step in which this wave keeps the matrix pipe idle)
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
+                                                                                __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
+                                                                                acc[i][j], 0, 0, 0);
+                if constexpr (W) {
+#pragma unroll
+                    for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, st2, j);
+#pragma unroll
+                    for (int k = 0; k < 24; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // 3 VALU
+                        if (k % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (need[i]) {                      // wave-uniform: the 32-row block has a tap of this slice
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
+                                                                                    __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
+                                                                                    acc[i][j], 0, 0, 0);
+                    }
+                    if constexpr (W) {
+                        if (HALF_PASSES == 2) store_a(setw_tag, h, st2, i);
+                        else if (i == 0) store_a(setw_tag, h, st2, 0);
+                    }
+                }
+            }
+            // everything but this half-step's own loads has landed (the weight fragments staged one half-step ago are
+            // read in the next one; a register set is complete one half-step after its loads); own LDS stores are done
+            wait_vm_lgkm0(std::integral_constant<int, (W ? B_CHUNKS_PER_WAVE : 0) + (L ? A_PASSES : 0)>{});
+            asm volatile("s_barrier" ::: "memory");
+            st = st == 2 ? 0 : st + 1;
+        };
+        auto kt_at = [&](int s) { return (int)(Ks[s] & 1023); };
+        int s = 0;
+        // steady state: slices s, s+1 multiplied, s+1, s+2 staged, s+2, s+3 loaded -- no conditions inside
+        for (; s + 3 < nsl; s += 2) {
+            const int e0 = (int)Ks[s], e1 = (int)Ks[s + 1];
+            const int k1 = kt_at(s + 1), k2 = kt_at(s + 2), k3 = kt_at(s + 3);
+            halfstep(e0, T{}, S1{}, k1, 0, T{}, S0{}, k2);
+            halfstep(e0, T{}, S1{}, k1, 1, Fl{}, S0{}, 0);
+            halfstep(e1, T{}, S0{}, k2, 0, T{}, S1{}, k3);
+            halfstep(e1, T{}, S0{}, k2, 1, Fl{}, S1{}, 0);
+        }
+        // tail: the same sequence with its loads / stagings switched off as the list runs out
+        for (; s < nsl; s += 2) {
+            const int e0 = (int)Ks[s];
+            const bool w1 = s + 1 < nsl, l2 = s + 2 < nsl, l3 = s + 3 < nsl;
+            const int k1 = w1 ? kt_at(s + 1) : 0, k2 = l2 ? kt_at(s + 2) : 0, k3 = l3 ? kt_at(s + 3) : 0;
+            if (w1 && l2) halfstep(e0, T{}, S1{}, k1, 0, T{}, S0{}, k2);
+            else if (w1) halfstep(e0, T{}, S1{}, k1, 0, Fl{}, S0{}, 0);
+            else halfstep(e0, Fl{}, S1{}, 0, 0, Fl{}, S0{}, 0);
+            if (w1) halfstep(e0, T{}, S1{}, k1, 1, Fl{}, S0{}, 0);
+            else halfstep(e0, Fl{}, S1{}, 0, 1, Fl{}, S0{}, 0);
+            if (!w1) break;
+            const int e1 = (int)Ks[s + 1];
+            if (l2 && l3) halfstep(e1, T{}, S0{}, k2, 0, T{}, S1{}, k3);
+            else if (l2) halfstep(e1, T{}, S0{}, k2, 0, Fl{}, S1{}, 0);
+            else halfstep(e1, Fl{}, S0{}, 0, 0, Fl{}, S1{}, 0);
+            if (l2) halfstep(e1, T{}, S0{}, k2, 1, Fl{}, S1{}, 0);
+            else halfstep(e1, Fl{}, S0{}, 0, 1, Fl{}, S1{}, 0);
+        }
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + li;
+            if (n >= p.N) continue;
+            const float bsv = p.bias ? p.bias[n] : 0.f;
+            const int res_mod = (int)p.res_mod;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = Vs[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+                if (m < 0) continue;
+                float v = acc[i][j][r] + bsv;
+                if (p.res) v += p.res[(int64_t)((int)m < res_mod ? (int)m : (int)m % res_mod) * p.ldres + n];
+                if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
+                p.Y[m * p.ldy + n] = v;
+                if (p.Y2 && m < p.rows2) p.Y2[m * p.ldy2 + n] = v;
+            }
+        }
+    if (probe) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe),
+                  (unsigned long long)((long long)__builtin_readcyclecounter() - probe_c));
+        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 1,
+                  (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - probe_w));
+    }
+}
+
+// Wt [k_rows][ldw] fp32 -> three bf16 planes [k_rows/8][ldw][8]
+__global__ void __launch_bounds__(256) k_weight_split3(const float *__restrict__ Wt, int64_t k_rows, int64_t ldw,
+                                                        unsigned char *__restrict__ dst, int64_t plane_stride) {
+    // one thread per (kb, n): 8 strided reads (coalesced across n), one 16-byte store per plane
+    const int64_t total = (k_rows / 8) * ldw;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int64_t kb = i / ldw, n = i - kb * ldw;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = Wt[(kb * 8 + j) * ldw + n];
+        u32x4 h, m, l;
+        unsigned a, b, c;
+        split2(x[0], x[1], a, b, c); h.x = a; m.x = b; l.x = c;
+        split2(x[2], x[3], a, b, c); h.y = a; m.y = b; l.y = c;
+        split2(x[4], x[5], a, b, c); h.z = a; m.z = b; l.z = c;
+        split2(x[6], x[7], a, b, c); h.w = a; m.w = b; l.w = c;
+        *reinterpret_cast<u32x4 *>(dst + i * 16) = h;
+        *reinterpret_cast<u32x4 *>(dst + plane_stride + i * 16) = m;
+        *reinterpret_cast<u32x4 *>(dst + 2 * plane_stride + i * 16) = l;
+    }
+}
+
+}  // namespace
+
+extern "C" int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride,
+                                 hplStream stream) {
+    HPL_REQUIRE(Wt && dst && k_rows > 0 && k_rows % 8 == 0 && ldw > 0 && plane_stride >= k_rows * ldw * 2 &&
+                    plane_stride % 16 == 0 && aligned16(dst),
+                "hpl_weight_split3: bad arguments (k_rows=%lld ldw=%lld)", (long long)k_rows, (long long)ldw);
+    const int grid = (int)imin(cdiv(k_rows / 8 * ldw, 256), 16384);
+    k_weight_split3<<<grid, 256, 0, to_stream(stream)>>>(Wt, k_rows, ldw, reinterpret_cast<unsigned char *>(dst), plane_stride);
+    HPL_CHECK_LAUNCH("hpl_weight_split3");
+    return HPL_OK;
+}
+
+// Diagnostic: residency of the kernel variants (variant 0: 128x128 F<=8, 1: 128x128 F<=15, 2: 128x256 F<=8, 3: 128x256 F<=15)
+extern "C" int hpl_split3_info(int variant, int *blocks_per_cu, int *lds_bytes, int *vgprs) {
+    HPL_REQUIRE(variant >= 0 && variant < 4 && blocks_per_cu && lds_bytes && vgprs, "hpl_split3_info: bad arguments");
+    const void *fn = variant == 0 ? (const void *)k_gconv3<2, 8> : variant == 1 ? (const void *)k_gconv3<2, 15>
+                   : variant == 2 ? (const void *)k_gconv3<4, 8> : (const void *)k_gconv3<4, 15>;
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, fn) != hipSuccess) { set_error("hpl_split3_info: hipFuncGetAttributes failed"); return HPL_EHIP; }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, variant < 2 ? 256 : 512, 0) != hipSuccess) {
+        set_error("hpl_split3_info: occupancy query failed");
+        return HPL_EHIP;
+    }
+    *blocks_per_cu = nb; *lds_bytes = (int)at.sharedSizeBytes; *vgprs = at.numRegs;
+    return HPL_OK;
+}
+
+// HPL_MATH=f32 keeps every launch on the fp32 MFMA (A/B runs, parity baselines)
+static bool split3_enabled() {
+    static const bool on = !(getenv("HPL_MATH") && std::string(getenv("HPL_MATH")) == "f32");
+    return on;
+}
+
+bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
+    // qualifying launches: row-ordered stencil passes (or dense GEMMs) of wide layers, no scatter / split-K
+    if (!split3_enabled() || p.scat || p.C < 32 || p.N % 64 != 0 || p.K > 32768) return false;
+    if (p.F > 15 || (p.w_bytes / (p.ldw * 4)) % 8 != 0) return false;
+    static const int min_rows = getenv("HPL_SPLIT3_MIN_ROWS") ? atoi(getenv("HPL_SPLIT3_MIN_ROWS")) : 8192;
+    if (p.M < min_rows || p.N < 256) return false;
+    p.tiles_m = (int)cdiv(p.M, BM3);
+    static const int wide = getenv("HPL_SPLIT3_BN") ? atoi(getenv("HPL_SPLIT3_BN")) : 128;
+    const bool bn256 = wide == 256 && p.N % 256 == 0;
+    const int BN = bn256 ? 256 : 128;
+    if (p.N % BN != 0) return false;
+    p.tiles_n = p.N / BN;
+    if (p.tile_bm != BM3) p.tile_idx = nullptr;
+    p.splits = 1; p.partial = nullptr;
+    int grid = p.tiles_m * p.tiles_n;
+    p.col_share = 0; p.col_rows = 0;
+    if (p.row_perm) {
+        int g = 8, b = p.tiles_n % 8;
+        while (b) { const int tt = g % b; g = b; b = tt; }
+        p.col_share = 8 / g;
+        p.col_rows = p.col_share == 1 ? p.tiles_m : (int)cdiv(p.tiles_m, COL_CHUNK * p.col_share) * COL_CHUNK;
+        grid = p.tiles_n * p.col_share * p.col_rows;
+    }
+    const bool f8 = p.F <= 8;
+    if (bn256) {
+        if (f8) k_gconv3<4, 8><<<grid, 512, 0, s>>>(p); else k_gconv3<4, 15><<<grid, 512, 0, s>>>(p);
+    } else {
+        if (f8) k_gconv3<2, 8><<<grid, 256, 0, s>>>(p); else k_gconv3<2, 15><<<grid, 256, 0, s>>>(p);
+    }
+    return true;
+}

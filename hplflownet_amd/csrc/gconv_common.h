@@ -1,0 +1,141 @@
+// gconv_common.h -- what the gather-GEMM kernels of gconv.hip (fp32 MFMA) and gconv3.hip (3 x bf16 split operands on the
+// bf16 MFMA) share: launch parameters, buffer descriptors, the XCD-aware tile order.
+#pragma once
+#include "common.h"
+
+namespace hpl_gc {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef int int32x4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// buffer_load_dwordx4 through the LLVM intrinsic (hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128
+// lowers to a single-dword load, so the intrinsic is bound by name instead)
+__device__ float4_t buffer_load_f32x4(int32x4_t srsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+
+
+// raw buffer descriptor: base pointer, stride 0, extent in bytes, gfx9 dword-3 flags (32-bit data format)
+__device__ __forceinline__ int32x4_t make_rsrc(const void *base, int bytes) {
+    union {
+        int32x4_t v;
+        struct { const void *p; int range; int cfg; } s;
+    } u;
+    u.s.p = base;
+    u.s.range = bytes;
+    u.s.cfg = 0x00020000;
+    return u.v;
+}
+
+constexpr int COL_CHUNK = 4;
+constexpr int BK = 32;   // contraction slice per step (floats) = one 128-byte line per gathered row
+
+struct GParams {
+    const float *A; int64_t lda; int64_t rows_a;
+    const int32_t *nbr; int64_t nbr_stride; int64_t reg_stride;
+    int64_t M; int C; int F; int K;
+    const float *Wt; int64_t ldw; int N; int act; float slope;
+    const float *bias; const float *res; int64_t ldres; int64_t res_mod;
+    float *Y; int64_t ldy;
+    const int32_t *scat; int64_t scat_stride; int scat_c;
+    int tiles_m; int tiles_n;
+    int64_t a_bytes; int64_t w_bytes;   // extents of A and Wt for the buffer descriptors
+    const int32_t *row_perm;            // optional permutation of the output rows (tile row -> vertex)
+    const int32_t *tile_idx;            // optional precomputed [tiles_m][F][BM] source rows + [tiles_m][8] masks
+    const int32_t *tile_mask;           //   (hpl_tile_index; only when its BM is this launch's BM)
+    int tile_bm;
+    long long *clock_probe;             // optional: sampled workgroups add their residence in shader cycles / 100 MHz wall ticks
+    int perm_chunk;                     // tile-rows per XCD chunk in permuted launches
+    int col_share;                      // > 0: column-major XCD order, XCDs per column tile (see tile_coords)
+    int col_rows;                       // tile-rows per virtual column in that order
+    int splits; float *partial;         // split-K over the slice list: partial[split][M][N]
+    float *Y2; int64_t ldy2; int64_t rows2;   // optional second destination: rows < rows2 are also written to Y2
+    float *ws; int64_t ws_bytes;
+    const void *Wt3; int64_t w3_plane_stride;      // split weight image (hpl_weight_split3) or nullptr
+};
+
+__device__ __forceinline__ int64_t src_row(const GParams &p, int f, int64_t m) {
+    if (f >= p.F || m >= p.M) return -1;
+    if (p.nbr) return (int64_t)p.nbr[(int64_t)f * p.nbr_stride + m];
+    return (int64_t)f * p.reg_stride + m;
+}
+
+// XCD-aware tile order: the hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs (private 4 MiB L2 each).  Re-number so that each XCD owns a contiguous run of tiles,
+// and walk tiles_n fastest inside a band of 8 tile-rows so that concurrently resident
+// workgroups of one XCD share both gathered A rows and weight panels in that L2.
+__device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x % nwg;       // (split-K: grid = splits x tiles)
+    const int q = nwg / 8, r = nwg % 8;
+    const int xcd = bid % 8, pos = bid / 8;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // bijective
+    if (p.row_perm && p.col_share > 0) {
+        // Column-major order: an XCD works through ONE column tile at a time (its weight panel stays in that
+        // L2), heaviest tile-rows first.  Column tiles shared by col_share XCDs deal their tile-rows round
+        // robin.  The grid is rounded up to 8 equal runs; surplus workgroups get tm = -1.
+        const int gsz = p.tiles_n * p.col_share * p.col_rows;
+        const int q2 = gsz / 8, r2 = gsz % 8;
+        const int b2 = blockIdx.x;
+        const int x2 = b2 % 8, pos2 = b2 / 8;
+        const int id2 = (x2 < r2 ? x2 * (q2 + 1) : r2 * (q2 + 1) + (x2 - r2) * q2) + pos2;
+        const int v = id2 / p.col_rows, pos = id2 - v * p.col_rows;
+        tn = v / p.col_share;
+        // XCDs sharing a column tile take its scheduled tile-rows in chunks of COL_CHUNK: tiles that are neighbours in
+        // the schedule (= in the row order) run on one XCD and share gathered rows in its L2
+        const int sh = v - tn * p.col_share;
+        const int row = p.col_share == 1 ? pos : (pos / COL_CHUNK) * COL_CHUNK * p.col_share + sh * COL_CHUNK + pos % COL_CHUNK;
+        tm = row < p.tiles_m ? (p.tile_idx ? p.tile_mask[(int64_t)row * 8 + 6] : p.tiles_m - 1 - row) : -1;
+        return;
+    }
+    if (p.row_perm) {
+        // Rows are sorted by tap mask: tile-rows differ in work (few taps ... all taps) and have no
+        // spatial coherence.  Tile-rows are dealt to the 8 XCDs in chunks of PERM_CHUNK consecutive
+        // (= similar mask, similar slice list) tile-rows, heaviest chunk first, in snake order
+        // (0..7, 7..0, ...) so that XCDs finish together; the co-resident workgroups of an XCD then
+        // walk nearly the same slices and share weight panels in its L2, and the column tiles of
+        // one tile-row stay adjacent and share its gathered rows.
+        const int G = p.perm_chunk;
+        const int T = p.tiles_m;
+        const int nchunks = (T + G - 1) / G;
+        auto chunk_rows = [&](int c) { return min(G, T - c * G); };
+        auto chunk_of = [&](int x, int r) { return r * 8 + ((r & 1) ? 7 - x : x); };   // round r of XCD x
+        int sq = id / p.tiles_n;            // position in the XCD-major sequence of tile-rows
+        tn = id - sq * p.tiles_n;
+        int x = 0;
+        for (; x < 8; ++x) {
+            int rows_x = 0;
+            for (int r = 0; r * 8 < nchunks; ++r) {      // rounds that contain at least one chunk
+                const int c = chunk_of(x, r);
+                if (c < nchunks) rows_x += chunk_rows(c);
+            }
+            if (sq < rows_x) break;
+            sq -= rows_x;
+        }
+        int row = 0;
+        for (int r = 0;; ++r) {
+            const int c = chunk_of(x, r);
+            if (c >= nchunks) continue;
+            const int n = chunk_rows(c);
+            if (sq < n) { row = c * G + sq; break; }
+            sq -= n;
+        }
+        tm = T - 1 - row;
+        return;
+    }
+    constexpr int BAND = 8;
+    const int band_sz = BAND * p.tiles_n;
+    const int band = id / band_sz;
+    const int in_band = id - band * band_sz;
+    const int rows_in_band = min(BAND, p.tiles_m - band * BAND);
+    tm = band * BAND + in_band % rows_in_band;
+    tn = in_band / rows_in_band;
+}
+
+
+// host side (gconv.hip / gconv3.hip)
+int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who);
+// the split-operand kernel (gconv3.hip): true if it took the launch
+bool launch_split3(GParams &p, hipStream_t s);
+
+}  // namespace hpl_gc

@@ -95,17 +95,17 @@ int level_head(hpl_lattice *b) {
 
 // M <= H0: rows are cloud-1 vertices; M = H0 + H1: the stacked pair
 int order_of(hpl_lattice *b, const int32_t *nbr, int64_t stride, int F, int64_t M, const int32_t **perm,
-             const int32_t **tidx, const int32_t **tmask) {
+             const int32_t **tidx, const int32_t **tmask, int bm = TILE_BM) {
     int32_t *p = b->take<int32_t>(M);
-    const int64_t tiles = cdiv(M, TILE_BM);
-    int32_t *ti = b->take<int32_t>(tiles * F * TILE_BM), *tm = b->take<int32_t>(tiles * 8);
+    const int64_t tiles = cdiv(M, bm);
+    int32_t *ti = b->take<int32_t>(tiles * F * bm), *tm = b->take<int32_t>(tiles * 8);
     if (b->overflow) return HPL_ENOMEM;
     static const bool keyed = !(getenv("HPL_ROW_ORDER") && atoi(getenv("HPL_ROW_ORDER")) == 0);      // A/B switch
     const int64_t H0 = b->n_vert[0];
     int rc = keyed ? hpl_tap_order_keyed(nbr, stride, F, M, b->vk[0], 4 * b->n[0], H0, b->vk[1], 4 * b->n[1], p, b->scratch, b->hs)
                    : hpl_tap_order(nbr, stride, F, M, p, b->scratch, b->hs);
     if (rc) return rc;
-    rc = hpl_tile_index(nbr, stride, F, M, p, TILE_BM, ti, tm, b->hs);
+    rc = hpl_tile_index(nbr, stride, F, M, p, bm, ti, tm, b->hs);
     if (rc) return rc;
     *perm = p; *tidx = ti; *tmask = tm;
     return HPL_OK;
@@ -149,6 +149,7 @@ int level_tail(hpl_lattice *b) {
     t.csr_ptr = csr_ptr; t.csr_pt = csr_pt; t.csr_w = csr_w; t.csr_norm = norm;
     t.blur = blur; t.blur_stride = Hp;
     t.tile_bm = TILE_BM;
+    t.group_tile_bm = sp.group_tile_bm == 128 ? 128 : TILE_BM;
     if (cf != -1) {
         t.corr1 = corr1 ? corr1 : blur;                 // equal radii: corr1 IS the cloud-1 blur table
         t.corr1_stride = corr1 ? H0 : Hp;
@@ -171,7 +172,7 @@ int level_tail(hpl_lattice *b) {
                     const int f0 = sp.group_cut[g], f1 = sp.group_cut[g + 1];
                     t.up_group_cut[g] = f0; t.up_group_cut[g + 1] = f1;
                     rc = order_of(b, blur + (int64_t)f0 * Hp, Hp, f1 - f0, H0, &t.up_group_perm[g], &t.up_group_tidx[g],
-                                  &t.up_group_tmask[g]);
+                                  &t.up_group_tmask[g], t.group_tile_bm);
                     if (rc) return rc;
                 }
             }
@@ -200,7 +201,8 @@ int level_tail(hpl_lattice *b) {
 }  // namespace
 
 extern "C" hpl_lattice *hpl_lattice_create(const hpl_lattice_spec *spec) {
-    if (!spec || spec->n_levels < 1 || spec->n_levels > HPL_MAX_LEVELS || spec->n_groups > 4) {
+    if (!spec || spec->n_levels < 1 || spec->n_levels > HPL_MAX_LEVELS || spec->n_groups > 4 ||
+        (spec->group_tile_bm != 0 && spec->group_tile_bm != 64 && spec->group_tile_bm != 128)) {
         set_error("hpl_lattice_create: bad spec");
         return nullptr;
     }

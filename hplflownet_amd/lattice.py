@@ -454,6 +454,7 @@ class NativeBuilder(object):
             sp.group_cut[i] = round(i * F / G)
         sp.groups_min_sparsity = NbrTable.GROUPS_MIN_SPARSITY
         sp.perm_min_rows = NbrTable.PERM_MIN_ROWS
+        sp.group_tile_bm = ops.GROUP_TILE_BM
         self.spec = sp
         self.free = []
         self.bytes_per_point = 6000            # arena hint, doubled on HPL_ENOMEM

@@ -140,7 +140,7 @@ def tap_order(nbr, keys=None):
     L = _lib.load()
     perm = torch.empty(M, dtype=torch.int32, device=nbr.device)
     scratch = torch.empty((int(L.hpl_tap_order_scratch_ints(M)) + 1) // 2, dtype=torch.int64, device=nbr.device)
-    if keys is None:
+    if keys is None or os.environ.get('HPL_ROW_ORDER') == '0':          # (A/B switch: mask order only)
         check(L.hpl_tap_order(ptr(nbr), nbr.stride(0), F, M, ptr(perm), ptr(scratch), stream()), 'hpl_tap_order')
     else:
         vk0, H0, vk1 = keys
@@ -151,6 +151,12 @@ def tap_order(nbr, keys=None):
 
 
 TILE_BM = 64        # tile height of the gather-GEMM classes that take a row order (csrc/gconv.hip: 64x128, 64x64)
+#: HPL_MATH=f32 keeps every gather-GEMM on the fp32 MFMA; default: the wide tap-group passes run on the bf16 MFMA with
+#: three-way split operands (csrc/gconv3.hip, fp32-class accuracy), whose tiles are 128 rows high
+SPLIT3 = os.environ.get('HPL_MATH', 'split3') != 'f32'
+GROUP_TILE_BM = 128 if SPLIT3 else 64
+#: weight images narrower than this stay fp32-only (the split kernel takes launches with N >= 256, C >= 32)
+SPLIT3_MIN_N, SPLIT3_MIN_C = 256, 32
 
 
 def tile_index(nbr, perm, BM=TILE_BM):
@@ -241,6 +247,19 @@ def weight_relayout(W, R, Q, F, sr, sq, sf, base=0, fmap=None):
     return Wt
 
 
+def weight_split3(Wt, out=None):
+    """fp32 weight image [k_rows (multiple of 8), ldw] -> uint8 tensor [3, k_rows/8 * ldw * 16]: the image as three
+    bf16 planes hi / mid / lo (Wt == hi + mid + lo exactly) in MFMA B-fragment order (hpl_weight_split3); the operand of
+    the split-precision gather-GEMM (gconv_raw Wt3=...)."""
+    k_rows, ldw = Wt.shape
+    if k_rows % 8 or not Wt.is_contiguous():
+        raise _lib.HplError('weight_split3: image must be contiguous with a multiple of 8 rows, got %s' % (tuple(Wt.shape),))
+    if out is None:
+        out = torch.empty((3, k_rows // 8 * ldw * 16), dtype=torch.uint8, device=Wt.device)
+    check(_lib.load().hpl_weight_split3(ptr(Wt), k_rows, ldw, ptr(out), out.stride(0), stream()), 'hpl_weight_split3')
+    return out
+
+
 def _mat(x, what):
     """(data_ptr, leading dimension, rows, cols) of a channel-last 2-D float32 device matrix, validated with one
     stride() / shape read (this sits on the host's critical path: ~100 calls per forward)."""
@@ -253,7 +272,7 @@ def _mat(x, what):
 
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
               scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True, reg_stride=0, tiles=None,
-              out2=None, rows2=0):
+              out2=None, rows2=0, Wt3=None):
     """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
     row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged.
     nbr None and reg_stride > 0: tap f of row m reads row f*reg_stride + m (no table: the displacement
@@ -281,6 +300,8 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
     d.Wt, d.ldw, d.N = ptr(Wt), wsh[1], N
     d.w_rows = min(wsh[0], round_up(F * C, 32))     # rows past the image read as zero
     d.act, d.slope = act, slope
+    if Wt3 is not None:           # weight_split3 of the image Wt is a row range of (same first row)
+        d.Wt3, d.wt3_plane_stride = ptr(Wt3), Wt3.stride(0)
     if bias is not None:
         d.bias = ptr(bias)
     if res is not None:
@@ -502,19 +523,35 @@ def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, r
         # radius-2 stencils (65 taps): the kernel stages the indices of at most 15 taps per tile, so the
         # contraction runs as ceil(F / 15) accumulating passes over consecutive tap ranges
         groups = [(f0, min(F, f0 + MAX_TAPS_PER_PASS), None) for f0 in range(0, F, MAX_TAPS_PER_PASS)]
+    # wide stencil layers also carry the split image of their weights: the kernel takes the launch when it is big enough
+    W3 = split3_of(Wt) if (SPLIT3 and nbr is not None and F > 1 and N >= SPLIT3_MIN_N and C >= SPLIT3_MIN_C) else None
     if not groups or not (nbr is not None or regular) or len(groups) < 2:
         return gconv_raw(A, nbr, M, C, F, Wt, N, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope,
-                         row_perm=row_perm, reg_stride=reg_stride, tiles=tiles if not isinstance(tiles, list) else None)
+                         row_perm=row_perm, reg_stride=reg_stride, tiles=tiles if not isinstance(tiles, list) else None,
+                         Wt3=W3)
     y = out
     gt = tiles if isinstance(tiles, list) and len(tiles) == len(groups) else [None] * len(groups)
     for i, (f0, f1, perm) in enumerate(groups):
         first, last = i == 0, i == len(groups) - 1
+        # the same rows of the split image (k-blocks of 8 rows, 16 bytes per column)
+        w3 = W3[:, (f0 * C // 8) * Wt.shape[1] * 16:] if (W3 is not None and (f0 * C) % 8 == 0) else None
         # a tap range of a regular pattern is the same pattern over the rows from f0*reg_stride on
         y = gconv_raw(A[f0 * reg_stride:] if regular else A, None if regular else nbr[f0:f1], M, C, f1 - f0,
                       Wt[f0 * C:], N, bias=bias if first else None,
                       act=act if last else ACT_NONE, res=res if first else y, res_mod=res_mod if first else 0,
-                      out=y, slope=slope, row_perm=perm, reg_stride=reg_stride, tiles=gt[i] if perm is not None else None)
+                      out=y, slope=slope, row_perm=perm, reg_stride=reg_stride, tiles=gt[i] if perm is not None else None,
+                      Wt3=w3)
     return y
+
+
+def split3_of(Wt):
+    """The split image of a weight image, made once per image tensor (the image caches / banks hand out the same
+    tensor object until the parameter changes)."""
+    w3 = getattr(Wt, '_hpl_split3', None)
+    if w3 is None or w3[1] != Wt._version:
+        w3 = (weight_split3(Wt), Wt._version)
+        Wt._hpl_split3 = w3
+    return w3[0]
 
 
 class GConvFn(torch.autograd.Function):

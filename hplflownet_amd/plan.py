@@ -336,6 +336,7 @@ def level_tables(lat, hint):
         pb = lv.blur.pair
         t.blur, t.blur_stride = pb.t.data_ptr(), pb.t.stride(0)
         t.tile_bm = ops.TILE_BM
+        t.group_tile_bm = ops.GROUP_TILE_BM
         perm = pb.perm
         if perm is not None:
             t.blur_perm = perm.data_ptr()
@@ -393,12 +394,22 @@ class ForwardPlan(object):
         ops_arr = (Op * len(P.ops))(*P.ops)
         bufs_arr = (Buf * len(P.bufs))(*[Buf(r, c) for r, c in P.bufs])
         w_arr = (Weight * len(P.weights))()
+        # weights of the wide tap-group convs also exist as split images (csrc/gconv3.hip: bf16 MFMA, fp32-exact operands)
+        wide = set(o.weight for o in P.ops if o.kind == OP_GCONV and o.F > 1 and o.table in (TBL_BLUR_PAIR, TBL_BLUR0, TBL_CORR1, TBL_CORR2)
+                   and o.N >= ops.SPLIT3_MIN_N and o.C >= ops.SPLIT3_MIN_C) if ops.SPLIT3 else set()
+        self._split3 = {}           # weight index -> (image view, split image)
         for i, key in enumerate(P.weights):
             job = self.bank.jobs[self.bank._key(key[0], *key[1:], False)]
             R, Q, F = key[1], key[2], key[3]
             k_rows, ldw = ops.round_up(F * R, 32), ops.round_up(Q, 4)
             w_arr[i].Wt = self.bank.buf.data_ptr() + 4 * job[2]
             w_arr[i].ldw, w_arr[i].rows = ldw, k_rows
+            if i in wide:
+                img = self.bank.buf[job[2]:job[2] + k_rows * ldw].view(k_rows, ldw)
+                w3 = ops.weight_split3(img)
+                self._split3[i] = (img, w3)
+                w_arr[i].Wt3, w_arr[i].wt3_plane_stride = w3.data_ptr(), w3.stride(0)
+        self._mark_images_written()
         b_arr = (ctypes.c_void_p * max(1, len(P.biases)))(*[b.data_ptr() for b in P.biases])
         self.handle = L.hpl_plan_create(ops_arr, len(P.ops), bufs_arr, len(P.bufs), w_arr, len(P.weights), b_arr,
                                         len(P.biases))
@@ -462,6 +473,8 @@ class ForwardPlan(object):
                 if ev is not None and not ev.query():
                     cur.wait_event(ev)
             self.bank.refresh()
+            for img, w3 in self._split3.values():
+                ops.weight_split3(img, out=w3)
             for t, (a, b) in self.prog.combined:
                 t.copy_(a.detach() + b.detach())
         self._mark_images_written()

@@ -129,6 +129,16 @@ int hpl_weight_relayout_batch(const hpl_relayout_job *jobs /* DEVICE */, int njo
                               const int64_t *prefix /* DEVICE, njobs + 1 */, int64_t total, float *dst,
                               hplStream stream);
 
+/* Split weight image for the bf16-MFMA path: Wt [k_rows][ldw] fp32 (k_rows % 8 == 0) -> three planes p = 0 (hi),
+ * 1 (mid), 2 (lo) of bf16, each [k_rows/8][ldw][8] (element (k, n) at ((k/8)*ldw + n)*8 + k%8: the 8 consecutive k of
+ * one output column are one 16-byte MFMA B fragment), plane p at dst + p*plane_stride bytes; hi = bf16_rne(w),
+ * mid = bf16_rne(w - hi), lo = bf16_rne(w - hi - mid): w == hi + mid + lo exactly.  plane_stride >= k_rows*ldw*2. */
+int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride, hplStream stream);
+
+/* Diagnostic: residency of the split-operand kernel variants (0: 128x128 tile, <= 8 taps; 1: 128x128, <= 15 taps;
+ * 2: 128x256, <= 8; 3: 128x256, <= 15): workgroups per CU by the occupancy API, static LDS bytes, registers. */
+int hpl_split3_info(int variant, int *blocks_per_cu, int *lds_bytes, int *vgprs);
+
 /* inverse scatter for weight gradients: W[base + r*sr + q*sq + f*sf] (+)= Wt[(f*R + r)*ldw + q] */
 int hpl_weight_unlayout(const float *Wt, int64_t ldw, int R, int Q, int F, float *W, int64_t base,
                         int64_t sr, int64_t sq, int64_t sf, int accumulate, hplStream stream);
@@ -194,6 +204,13 @@ typedef struct hpl_gconv_desc {
     float *Y2;
     int64_t ldy2;
     int64_t rows2;
+    /* optional: the same weights as three bf16 planes (hpl_weight_split3 of the image Wt points into, at the same
+     * first row, which must be a multiple of 8).  Launches that qualify (wide row-ordered stencil passes) then run
+     * on the bf16 matrix pipe with every fp32 operand carried EXACTLY as hi + mid + lo bf16 terms and the six
+     * leading partial products accumulated in fp32 (csrc/gconv3.hip: per-product error <= 2^-24 relative, the fp32
+     * rounding class; 16/6 of the fp32-MFMA rate).  NULL: fp32 MFMA. */
+    const void *Wt3;
+    int64_t wt3_plane_stride;   /* bytes between the planes */
 } hpl_gconv_desc;
 
 /* Row order for tap skipping: perm = the M vertices sorted by their F-bit tap-presence mask (bit f set iff
@@ -413,6 +430,8 @@ typedef struct hpl_weight {   /* a re-laid weight image (hpl_weight_relayout) */
     const float *Wt;
     int64_t ldw;
     int64_t rows;
+    const void *Wt3;          /* optional: hpl_weight_split3 of the whole image (NULL: the layer stays on the fp32 MFMA) */
+    int64_t wt3_plane_stride;
 } hpl_weight;
 
 typedef struct hpl_op {
@@ -463,6 +482,7 @@ typedef struct hpl_level_tables {
     const int32_t *corr2;             /* [15][15*H0] or NULL */
     /* optional per-tile index tables (hpl_tile_index, tiles of tile_bm rows) of the row orders above; NULL = none */
     int32_t tile_bm;
+    int32_t group_tile_bm;            /* tile height of the up_group tables (128: the split-operand kernel's tiles) */
     const int32_t *blur_perm_tidx, *blur_perm_tmask;
     const int32_t *up_perm_tidx, *up_perm_tmask;
     const int32_t *up_group_tidx[4], *up_group_tmask[4];
@@ -513,6 +533,7 @@ typedef struct hpl_lattice_spec {
     int32_t group_cut[5];
     float groups_min_sparsity;                   /* groups only where H0 / n0 >= this */
     int64_t perm_min_rows;                       /* row orders only for tables with at least this many rows */
+    int32_t group_tile_bm;                       /* tile height of the tap-group tile tables: 64 or 128 (0 = 64) */
 } hpl_lattice_spec;
 
 typedef struct hpl_lattice hpl_lattice;   /* one pair under construction per builder; use several builders to overlap pairs */

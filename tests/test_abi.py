@@ -30,10 +30,10 @@ def test_gconv_desc_layout_matches_header():
     hdr = header_text()
     struct = hdr[hdr.index('typedef struct hpl_gconv_desc {'):hdr.index('} hpl_gconv_desc;')]
     struct = re.sub(r'/\*.*?\*/', '', struct, flags=re.S)
-    fields = re.findall(r'(?:const\s+)?(?:float|int32_t|int64_t)\s*\*?\s*(\w+);', struct)
+    fields = re.findall(r'(?:const\s+)?(?:float|int32_t|int64_t|void)\s*\*?\s*(\w+);', struct)
     assert fields == [f[0] for f in _lib.GConvDesc._fields_]
     assert ctypes.sizeof(_lib.GConvDesc) == (8 * 3 + 8 * 3 + 8 + 4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8
-                                             + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8)
+                                             + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8)
 
 
 def test_relayout_job_layout_matches_header():
@@ -41,7 +41,7 @@ def test_relayout_job_layout_matches_header():
     struct = hdr[hdr.index('typedef struct hpl_relayout_job {'):hdr.index('} hpl_relayout_job;')]
     struct = re.sub(r'/\*.*?\*/', '', struct, flags=re.S)
     names = []
-    for decl in re.findall(r'(?:const\s+)?(?:float|int32_t|int64_t)\s*\*?\s*([\w\s,]+);', struct):
+    for decl in re.findall(r'(?:const\s+)?(?:float|int32_t|int64_t|void)\s*\*?\s*([\w\s,]+);', struct):
         names += [n.strip() for n in decl.split(',')]
     assert names == [f[0] for f in _lib.RelayoutJob._fields_]
     assert ctypes.sizeof(_lib.RelayoutJob) == 8 + 4 * 8 + 4 * 4 + 8
