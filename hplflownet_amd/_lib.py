@@ -37,8 +37,7 @@ class GConvDesc(ctypes.Structure):
                 ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('w_rows', c_i32),
                 ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64),
                 ('tile_idx', c_vp), ('tile_mask', c_vp), ('tile_bm', c_i32), ('clock_probe', c_vp),
-                ('Y2', c_vp), ('ldy2', c_i64), ('rows2', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64),
-                ('A3', c_vp), ('a3_ld', c_i64), ('a3_plane_stride', c_i64), ('wt3_rows', c_i32)]
+                ('Y2', c_vp), ('ldy2', c_i64), ('rows2', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64)]
 
 
 class Ref(ctypes.Structure):
@@ -101,8 +100,6 @@ _SIGNATURES = {
                                            c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
     'hpl_weight_relayout_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp, c_vp]),
     'hpl_weight_split3': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
-    'hpl_weight_split3p': (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_i64, c_vp, c_i64, c_vp]),
-    'hpl_rows_split3': (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_i64, c_vp]),
     'hpl_split3_info': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                        ctypes.POINTER(ctypes.c_int)]),
     'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,

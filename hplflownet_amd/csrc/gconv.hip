@@ -967,15 +967,6 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     }
     p.ws = d->ws; p.ws_bytes = d->ws ? d->ws_bytes : 0; p.splits = 1; p.partial = nullptr;
     p.Wt3 = d->Wt3; p.w3_plane_stride = d->wt3_plane_stride;
-    p.Cp = (d->C + 7) / 8 * 8;
-    p.A3 = (d->A3 && d->Wt3 && d->wt3_rows > 0) ? d->A3 : nullptr;
-    p.a3_ld = d->a3_ld; p.a3_plane_stride = d->a3_plane_stride; p.a3_bytes = 0; p.w3_bytes = 0;
-    if (p.A3) {
-        HPL_REQUIRE(d->a3_ld >= p.Cp && d->a3_ld % 8 == 0, "%s: a3_ld %lld must be a multiple of 8 >= %d", who, (long long)d->a3_ld, p.Cp);
-        p.a3_bytes = ((d->rows_a - 1) * d->a3_ld + p.Cp) * 2;
-        p.w3_bytes = imin((int64_t)d->wt3_rows, cdiv((int64_t)d->F * p.Cp, 32) * 32) / 8 * d->ldw * 16;
-        HPL_REQUIRE(p.a3_bytes < (int64_t)INT32_MAX && p.w3_bytes < (int64_t)INT32_MAX, "%s: split operands span >= 2 GiB", who);
-    }
     p.col_share = 0; p.col_rows = 0;
     p.tiles_m = p.tiles_n = 0;
     p.a_bytes = ((d->rows_a - 1) * d->lda + d->C) * 4;
@@ -1105,7 +1096,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     if (p.M == 0) return HPL_OK;
     hipStream_t s = to_stream(stream);
     const bool avec = (p.C % 4 == 0) && (p.lda % 4 == 0) && aligned16(p.A);
-    if (avec && p.Wt3 && (p.A3 ? launch_split3b(p, s) : (d->wt3_rows == 0 && launch_split3(p, s)))) {
+    if (avec && p.Wt3 && launch_split3(p, s)) {
         HPL_CHECK_LAUNCH("hpl_gconv_forward");
         return HPL_OK;
     }

@@ -326,8 +326,10 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                 if constexpr (W) {
 #pragma unroll
                     for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, st2, j);
+                    // (measured: the forced interleave gains 3 % on the 128-wide tile and loses 5 % on the 256-wide one,
+                    // whose 8 waves cover each other's conversion blocks)
 #pragma unroll
-                    for (int k = 0; k < 24; ++k) {
+                    for (int k = 0; k < (WGN == 2 ? 24 : 0); ++k) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
                         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // 3 VALU
                         if (k % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
@@ -482,7 +484,9 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     static const int min_rows = getenv("HPL_SPLIT3_MIN_ROWS") ? atoi(getenv("HPL_SPLIT3_MIN_ROWS")) : 8192;
     if (p.M < min_rows || p.N < 256) return false;
     p.tiles_m = (int)cdiv(p.M, BM3);
-    static const int wide = getenv("HPL_SPLIT3_BN") ? atoi(getenv("HPL_SPLIT3_BN")) : 128;
+    // 128 x 256 tiles (8 waves, one workgroup per CU) where N allows: 5-12 % faster than 128 x 128 on every wide launch of
+    // the model (profiles/r03c_split3_kernel_ab.txt) although they leave fewer tiles per CU
+    static const int wide = getenv("HPL_SPLIT3_BN") ? atoi(getenv("HPL_SPLIT3_BN")) : 256;
     const bool bn256 = wide == 256 && p.N % 256 == 0;
     const int BN = bn256 ? 256 : 128;
     if (p.N % BN != 0) return false;

@@ -51,9 +51,7 @@ struct GParams {
     int splits; float *partial;         // split-K over the slice list: partial[split][M][N]
     float *Y2; int64_t ldy2; int64_t rows2;   // optional second destination: rows < rows2 are also written to Y2
     float *ws; int64_t ws_bytes;
-    const void *Wt3; int64_t w3_plane_stride;      // split weight image (hpl_weight_split3 / hpl_weight_split3p) or nullptr
-    const void *A3; int64_t a3_ld; int64_t a3_plane_stride; int64_t a3_bytes;   // pre-split activation rows (hpl_rows_split3)
-    int Cp; int64_t w3_bytes;                      // C rounded up to 8; extent of one plane of the padded weight image
+    const void *Wt3; int64_t w3_plane_stride;      // split weight image (hpl_weight_split3) or nullptr
 };
 
 __device__ __forceinline__ int64_t src_row(const GParams &p, int f, int64_t m) {
@@ -139,7 +137,5 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
 int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who);
 // the split-operand kernel (gconv3.hip): true if it took the launch
 bool launch_split3(GParams &p, hipStream_t s);
-// the same with both operands pre-split (gconv3b.hip)
-bool launch_split3b(GParams &p, hipStream_t s);
 
 }  // namespace hpl_gc

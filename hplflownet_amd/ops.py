@@ -140,7 +140,7 @@ def tap_order(nbr, keys=None):
     L = _lib.load()
     perm = torch.empty(M, dtype=torch.int32, device=nbr.device)
     scratch = torch.empty((int(L.hpl_tap_order_scratch_ints(M)) + 1) // 2, dtype=torch.int64, device=nbr.device)
-    if keys is None or os.environ.get('HPL_ROW_ORDER') == '0':          # (A/B switch: mask order only)
+    if keys is None or os.environ.get('HPL_ROW_ORDER') != '1':          # (the Morton order buys nothing: csrc/lattice_builder.hip)
         check(L.hpl_tap_order(ptr(nbr), nbr.stride(0), F, M, ptr(perm), ptr(scratch), stream()), 'hpl_tap_order')
     else:
         vk0, H0, vk1 = keys
@@ -260,29 +260,6 @@ def weight_split3(Wt, out=None):
     return out
 
 
-def weight_split3p(Wt, F, C, out=None):
-    """The split image with every tap padded to Cp = roundup(C, 8) rows (hpl_weight_split3p): uint8 [3, rows/8*ldw*16],
-    rows = roundup(F*Cp, 32) -- the weight operand of the pre-split form (gconv_raw A3=...)."""
-    ldw = Wt.shape[1]
-    Cp = round_up(C, 8)
-    rows = round_up(F * Cp, 32)
-    if out is None:
-        out = torch.empty((3, rows // 8 * ldw * 16), dtype=torch.uint8, device=Wt.device)
-    check(_lib.load().hpl_weight_split3p(ptr(Wt), F, C, ldw, ptr(out), out.stride(0), stream()), 'hpl_weight_split3p')
-    return out
-
-
-def rows_split3(A, C, out=None):
-    """Channel-last fp32 activations [rows, >= C] -> uint8 [3, rows*Cp*2]: three bf16 planes [rows][Cp] with
-    A == hi + mid + lo exactly (hpl_rows_split3)."""
-    a, lda, rows, cols = _mat(A, 'activation')
-    Cp = round_up(C, 8)
-    if out is None:
-        out = torch.empty((3, rows * Cp * 2), dtype=torch.uint8, device=A.device)
-    check(_lib.load().hpl_rows_split3(a, lda, rows, C, ptr(out), out.stride(0), stream()), 'hpl_rows_split3')
-    return out
-
-
 def _mat(x, what):
     """(data_ptr, leading dimension, rows, cols) of a channel-last 2-D float32 device matrix, validated with one
     stride() / shape read (this sits on the host's critical path: ~100 calls per forward)."""
@@ -295,7 +272,7 @@ def _mat(x, what):
 
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
               scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True, reg_stride=0, tiles=None,
-              out2=None, rows2=0, Wt3=None, A3=None, wt3_rows=0):
+              out2=None, rows2=0, Wt3=None):
     """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
     row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged.
     nbr None and reg_stride > 0: tap f of row m reads row f*reg_stride + m (no table: the displacement
@@ -325,8 +302,6 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
     d.act, d.slope = act, slope
     if Wt3 is not None:           # weight_split3 of the image Wt is a row range of (same first row)
         d.Wt3, d.wt3_plane_stride = ptr(Wt3), Wt3.stride(0)
-        if A3 is not None:        # rows_split3 of A + the tap-padded image (weight_split3p), wt3_rows rows from Wt3 on
-            d.A3, d.a3_ld, d.a3_plane_stride, d.wt3_rows = ptr(A3), round_up(C, 8), A3.stride(0), wt3_rows
     if bias is not None:
         d.bias = ptr(bias)
     if res is not None:
@@ -549,7 +524,7 @@ def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, r
         # contraction runs as ceil(F / 15) accumulating passes over consecutive tap ranges
         groups = [(f0, min(F, f0 + MAX_TAPS_PER_PASS), None) for f0 in range(0, F, MAX_TAPS_PER_PASS)]
     # wide stencil layers also carry the split image of their weights: the kernel takes the launch when it is big enough
-    W3 = split3_of(Wt) if (SPLIT3 and nbr is not None and F > 1 and N >= SPLIT3_MIN_N and C >= SPLIT3_MIN_C) else None
+    W3 = split3_of(Wt) if (SPLIT3 and (nbr is not None or F == 1) and N >= SPLIT3_MIN_N and C >= SPLIT3_MIN_C) else None
     if not groups or not (nbr is not None or regular) or len(groups) < 2:
         return gconv_raw(A, nbr, M, C, F, Wt, N, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope,
                          row_perm=row_perm, reg_stride=reg_stride, tiles=tiles if not isinstance(tiles, list) else None,

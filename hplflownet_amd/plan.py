@@ -395,7 +395,7 @@ class ForwardPlan(object):
         bufs_arr = (Buf * len(P.bufs))(*[Buf(r, c) for r, c in P.bufs])
         w_arr = (Weight * len(P.weights))()
         # weights of the wide tap-group convs also exist as split images (csrc/gconv3.hip: bf16 MFMA, fp32-exact operands)
-        wide = set(o.weight for o in P.ops if o.kind == OP_GCONV and o.F > 1 and o.table in (TBL_BLUR_PAIR, TBL_BLUR0, TBL_CORR1, TBL_CORR2)
+        wide = set(o.weight for o in P.ops if o.kind == OP_GCONV and o.table in (TBL_NONE, TBL_BLUR_PAIR, TBL_BLUR0, TBL_CORR1, TBL_CORR2)
                    and o.N >= ops.SPLIT3_MIN_N and o.C >= ops.SPLIT3_MIN_C) if ops.SPLIT3 else set()
         self._split3 = {}           # weight index -> (image view, split image)
         for i, key in enumerate(P.weights):

@@ -134,13 +134,6 @@ int hpl_weight_relayout_batch(const hpl_relayout_job *jobs /* DEVICE */, int njo
  * one output column are one 16-byte MFMA B fragment), plane p at dst + p*plane_stride bytes; hi = bf16_rne(w),
  * mid = bf16_rne(w - hi), lo = bf16_rne(w - hi - mid): w == hi + mid + lo exactly.  plane_stride >= k_rows*ldw*2. */
 int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride, hplStream stream);
-/* The same with every tap padded to Cp = roundup(C, 8) rows: source row f*C + c -> row f*Cp + c of the split image
- * (rows c >= C zero), roundup(F*Cp, 32) rows per plane.  An 8-row block then never straddles two taps. */
-int hpl_weight_split3p(const float *Wt, int F, int C, int64_t ldw, void *dst, int64_t plane_stride, hplStream stream);
-/* Activation rows for the same path: A [rows][lda] fp32 (C channels) -> three bf16 planes hi / mid / lo, each
- * [rows][Cp] (Cp = roundup(C, 8), channels >= C zero), plane p at dst + p*plane_stride; A == hi + mid + lo exactly.
- * One streaming pass per layer input instead of one split per (column tile, tap) inside the GEMM. */
-int hpl_rows_split3(const float *A, int64_t lda, int64_t rows, int C, void *dst, int64_t plane_stride, hplStream stream);
 
 /* Diagnostic: residency of the split-operand kernel variants (0: 128x128 tile, <= 8 taps; 1: 128x128, <= 15 taps;
  * 2: 128x256, <= 8; 3: 128x256, <= 15): workgroups per CU by the occupancy API, static LDS bytes, registers. */
@@ -218,14 +211,6 @@ typedef struct hpl_gconv_desc {
      * rounding class; 16/6 of the fp32-MFMA rate).  NULL: fp32 MFMA. */
     const void *Wt3;
     int64_t wt3_plane_stride;   /* bytes between the planes */
-    /* optional, second form: the activation rows pre-split as well (hpl_rows_split3 of A: three bf16 planes
-     * [rows_a][a3_ld], a3_ld >= C rounded up to 8) and Wt3 in the tap-padded layout of hpl_weight_split3p with
-     * wt3_rows rows from Wt3 on (> 0 selects this form; the first row must be a multiple of Cp).  Nothing passes
-     * through registers on its way to LDS then (csrc/gconv3b.hip). */
-    const void *A3;
-    int64_t a3_ld;
-    int64_t a3_plane_stride;
-    int32_t wt3_rows;
 } hpl_gconv_desc;
 
 /* Row order for tap skipping: perm = the M vertices sorted by their F-bit tap-presence mask (bit f set iff

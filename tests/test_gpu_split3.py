@@ -35,15 +35,15 @@ def _table(M, rows_a, F, density, seed):
     return nbr.to(DEV)
 
 
-@pytest.mark.parametrize('form', ['a', 'b'])
 @pytest.mark.parametrize('M,C,F,N,density,order', [
     (8192, 64, 1, 256, 1.0, None),            # dense GEMM, K = 64
     (9000, 580, 8, 1024, 0.45, 'tiles'),      # the dominant launch's shape class: tap group of bcn1_, 128-row tile tables
     (8200, 324, 7, 512, 0.7, 'perm'),         # second group of bcn2_: K = 2268 is not a multiple of 32, prologue without tables
     (8193, 100, 15, 256, 0.5, 'tiles'),       # C % 8 = 4: 8-blocks straddle taps; one row in the last tile
-    (8300, 36, 3, 384, 0.9, None),            # N = 384: 3 column tiles of 128 (form b: 128-wide tiles only)
+    (8300, 36, 3, 320, 0.9, None),            # N = 320: 2.5 column tiles of 128
+    (8400, 64, 8, 512, 0.8, 'tiles'),         # N = 512: the 256-wide tile variant
 ])
-def test_split3_matches_float64_like_the_fp32_kernel(M, C, F, N, density, order, form):
+def test_split3_matches_float64_like_the_fp32_kernel(M, C, F, N, density, order):
     from hplflownet_amd import ops
     torch.manual_seed(M + C)
     rows_a = M if F == 1 else M + 37
@@ -63,15 +63,7 @@ def test_split3_matches_float64_like_the_fp32_kernel(M, C, F, N, density, order,
     pl = W3.view(torch.bfloat16).view(3, k_rows // 8, Wt.shape[1], 8).float()
     assert torch.equal(pl.sum(0).permute(0, 2, 1).reshape(k_rows, Wt.shape[1]), Wt)
     kw = dict(bias=bias, act=ops.ACT_LEAKY, row_perm=perm, tiles=tiles, split_k=False)
-    if form == 'b':               # both operands pre-split (csrc/gconv3b.hip)
-        A3 = ops.rows_split3(A, C)
-        Cp = ops.round_up(C, 8)
-        pa = A3.view(torch.bfloat16).view(3, rows_a, Cp).float()
-        assert torch.equal(pa.sum(0)[:, :C], A) and float(pa[:, :, C:].abs().sum()) == 0.0
-        W3p = ops.weight_split3p(Wt, F, C)
-        y3 = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3p, A3=A3, wt3_rows=ops.round_up(F * Cp, 32), **kw)
-    else:
-        y3 = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3, **kw)
+    y3 = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3, **kw)
     y1 = ops.gconv_raw(A, nbr, M, C, F, Wt, N, **kw)
     ref = _ref64(A, nbr, M, C, F, Wt, N, bias, ops.LEAKY_RATE)
     scale = float(ref.abs().max())

@@ -60,18 +60,11 @@ for name, lvl, C, O, f0, f1 in cases:
     y = torch.empty(M, O, device=dev)
     f32 = lambda: ops.gconv_raw(A, nbr, M, C, F, Wt, O, out=y, row_perm=perm, tiles=t64, split_k=False)
     sp3 = lambda: ops.gconv_raw(A, nbr, M, C, F, Wt, O, out=y, row_perm=perm, tiles=t128, split_k=False, Wt3=W3)
-    A3 = ops.rows_split3(A, C)
-    W3p = ops.weight_split3p(Wt, F, C)
-    rows3 = ops.round_up(F * ops.round_up(C, 8), 32)
-    sp3b = lambda: ops.gconv_raw(A, nbr, M, C, F, Wt, O, out=y, row_perm=perm, tiles=t128, split_k=False, Wt3=W3p, A3=A3, wt3_rows=rows3)
-    pre = lambda: ops.rows_split3(A, C, out=A3)
-    res = {'f32': [], 'split3': [], 'split3b': [], 'pre': []}
+    res = {'f32': [], 'split3': []}
     for _ in range(rounds):
         res['f32'].append(timeit(f32))
         res['split3'].append(timeit(sp3))
-        res['split3b'].append(timeit(sp3b))
-        res['pre'].append(timeit(pre))
     fl = 2.0 * M * F * C * O
-    a, b, c, d = min(res['f32']), min(res['split3']), min(res['split3b']), min(res['pre'])
-    print('%-24s M=%6d K=%5d N=%5d taps %.2f | fp32 %7.1f us %5.1f TF | split3 %7.1f us %5.1f TF x%.2f | split3b %7.1f us %5.1f TF x%.2f (+ pre-pass %5.1f us)' %
-          (name, M, F * C, O, valid, a * 1e3, fl / a / 1e9, b * 1e3, fl / b / 1e9, a / b, c * 1e3, fl / c / 1e9, a / c, d * 1e3), flush=True)
+    a, b = min(res['f32']), min(res['split3'])
+    print('%-24s M=%6d K=%5d N=%5d taps %.2f | fp32 %8.1f us %6.1f TF | split3 %8.1f us %6.1f TF | x%.2f' %
+          (name, M, F * C, O, valid, a * 1e3, fl / a / 1e9, b * 1e3, fl / b / 1e9, a / b), flush=True)
