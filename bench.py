@@ -9,15 +9,16 @@ configuration ("point-pairs/sec + EPE3D, N=8192").  Pairs shard over GPUs as ind
 `--gpus N` is weak scaling: every rank runs K steps on its own pairs, value = N*K / max-rank time.
 
 Printed JSON (rank 0, one line): the contract fields plus
-  roofline      dominant kernel (fp32-MFMA gather-GEMM, 64x128 tiles, 8 waves): algorithmic flops of its
-                launches / their HIP-event time.  With several forward streams the launches inside the
-                timed loop share the GPU with other pairs' kernels, so the headline figures come from the
-                single-stream pass right after the timed loop (`measured` says which); `in_loop` keeps
-                the timed-region figures;
+  roofline      dominant kernel (the wide gather-GEMM launches: bf16 MFMA with fp32-exact split operands by default,
+                fp32 MFMA with HPL_MATH=f32): executed MFMA flops per launch / HIP-event launch time, as a fraction of
+                the matrix pipe's peak.  With several forward streams the launches inside the timed loop share the GPU
+                with other pairs' kernels, so the headline figures come from the single-stream pass right after the
+                timed loop (`measured` says which); `in_loop` keeps the timed-region figures;
   kernels       per-kernel-class breakdown (gather-GEMM classes by MFMA roofline, splat / slice by
                 HBM roofline with the algorithmic bytes of SURVEY.md §8 d2);
-  cpu_baseline  the CPU oracle ("port": C lattice + numpy/BLAS layers) timed on this host on ONE
-                pair of the same workload (rank 0, N=1 only); it doubles as the EPE3D parity check.
+  train         BASELINE config 4 on this GPU: 5 training steps on the same pairs (fwd + bwd + all-reduce + Adam);
+  cpu_baseline  the CPU oracle ("port": C lattice + the faster of the numpy/BLAS and torch-CPU layer ports) timed on this
+                host on a bounded sample of the same workload (rank 0, N=1 only); it doubles as the EPE3D parity check.
 """
 import argparse
 import json
@@ -34,7 +35,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+MFMA_BF16_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense = 1024 SIMDs x 1024 FLOP/clk (32x32x16 in 32 cycles) x 2.4 GHz
+SIMDS, PEAK_CLOCK_HZ = 1024, 2.4e9
+#: the split-operand path (csrc/gconv3.hip) spends 6 bf16 MFMA flops per fp32 flop it stands for
+SPLIT3_PRODUCTS = 6
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s measured copy)
+
+
+def split3_takes(M, N, C, F, scat=False):
+    """Mirror of hpl_gc::launch_split3 (csrc/gconv3.hip): which launches run on the bf16 MFMA with split operands."""
+    from hplflownet_amd import ops
+    return (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N % 128 == 0 and N >= 256 and F <= 15 and
+            M >= int(os.environ.get('HPL_SPLIT3_MIN_ROWS', 8192)) and (F == 1 or M >= int(os.environ.get('HPL_SPLIT3_MIN_ROWS_STENCIL', 16384))))
 
 
 def gconv_class(M, N, K=1 << 20):
@@ -48,7 +60,8 @@ def gconv_class(M, N, K=1 << 20):
     return '128x32' if t128 >= 512 else '64x32'
 
 
-DOMINANT = 'gconv_64x128_g'
+DOMINANT_F32 = 'gconv_64x128_g'
+DOMINANT_SPLIT3 = 'gconv3_128x256_g'
 
 
 class KernelTimers(object):
@@ -79,7 +92,11 @@ class KernelTimers(object):
             return inner
 
         def d_gconv(A, nbr, M, C, F, Wt, N, **k):
-            # suffix: g = gathered (15-tap stencil, template F_LDS=15), d = dense (F_LDS=1)
+            # suffix: g = gathered (15-tap stencil, template F_LDS=15), d = dense (F_LDS=1); gconv3_* = the split-operand
+            # kernel (bf16 MFMA); flops = the fp32 multiply-adds the launch stands for (2*M*F*C*N)
+            if k.get('Wt3') is not None and split3_takes(M, N, C, F, k.get('scat') is not None):
+                return ('gconv3_128x%d_%s%s' % (256 if N % 256 == 0 else 128, 'g' if F > 1 else 'd', '' if M >= 16384 else '_mid'),
+                        2.0 * M * F * C * N, 0.0)
             return ('gconv_%s_%s' % (gconv_class(M, N, F * C), 'g' if F > 1 else 'd'), 2.0 * M * F * C * N, 0.0)
 
         # the HBM-bound gathers by lattice size: levels 0-2 of the N=8192 frustum move 10-140 MB per launch, the deeper
@@ -111,8 +128,12 @@ class KernelTimers(object):
             d = {'launches_per_step': cnt / float(steps), 'avg_launch_us': 1e3 * ms / cnt,
                  'ms_per_step': ms / steps}
             if flops:
-                d.update(bound='mfma', achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TFLOPS,
-                         unit='TFLOP/s', gflop_per_step=flops / steps / 1e9)
+                # fp32-equivalent algorithmic rate; the split-operand classes are priced against the bf16 peak / 6
+                split = name.startswith('gconv3_')
+                d.update(bound='mfma', achieved=flops / (ms * 1e-3) / 1e12,
+                         peak=MFMA_BF16_PEAK_TFLOPS / SPLIT3_PRODUCTS if split else MFMA_F32_PEAK_TFLOPS,
+                         unit='TFLOP/s (fp32-equivalent, algorithmic)', gflop_per_step=flops / steps / 1e9,
+                         path='3 x bf16 split operands on the bf16 MFMA' if split else 'fp32 MFMA')
             else:
                 d.update(bound='hbm', achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
                          mbytes_per_step=nbytes / steps / 1e6)
@@ -213,14 +234,96 @@ def cpu_baseline(samples, sfm, state_dict, shallow=False):
         t_lat, t_fwd = t_lat + (t1 - t0), t_fwd + (t2 - t1)
         flow0 = flow if flow0 is None else flow0
     n = len(samples)
-    d = {'value': n / (t_lat + t_fwd), 'unit': 'point-pairs/s', 'cores': int(threads), 'kind': 'port',
-         'sample': '%d pairs, N=%d, %d-level lattice build (C oracle, 1 thread) + %s forward '
-                   '(numpy oracle, BLAS threads = cores)' % (n, samples[0][0].shape[0], len(sfm),
-                                                             'HPLFlowNetShallow' if shallow else 'full HPLFlowNet'),
-         'lattice_s': t_lat / n, 'forward_s': t_fwd / n, 'host_cpus': os.cpu_count(), 'cpu_model': cpu_model(),
+    # second port of the layer half: torch-CPU ops in fp32 (oracle/torch_oracle.py; MKL-DNN convs / index ops as the
+    # reference's own CPU path uses, models/bilateralNN.py:219), intra-op threads = the same core count (SURVEY.md 8 d3 ii).
+    # ONE pair: the faster of the two ports is the baseline.
+    t_torch = None
+    try:
+        from oracle import torch_oracle
+        old_threads = torch.get_num_threads()
+        torch.set_num_threads(int(threads))
+        pc1, pc2, _ = samples[0]
+        with torch.no_grad():
+            sd_t = torch_oracle.parameters(state_dict, torch.float32, requires_grad=False)
+            gd_t = torch_oracle.lattice(gd, torch.float32) if len(samples) == 1 else torch_oracle.lattice(
+                lattice_oracle.generate_data(pc1, pc2, sfm), torch.float32)
+            t0 = time.time()
+            torch_oracle.hplflownet_forward(sd_t, torch.from_numpy(pc1.T.copy()), torch.from_numpy(pc2.T.copy()), gd_t, shallow=shallow)
+            t_torch = time.time() - t0
+        torch.set_num_threads(old_threads)
+    except Exception as e_:          # report, do not fail the bench
+        t_torch = 'failed: %s' % e_
+    fwd_numpy = t_fwd / n
+    fwd_best = min(fwd_numpy, t_torch) if isinstance(t_torch, float) else fwd_numpy
+    d = {'value': 1.0 / (t_lat / n + fwd_best), 'unit': 'point-pairs/s', 'cores': int(threads), 'kind': 'port',
+         'sample': '%d pairs, N=%d, %d-level lattice build (C oracle, 1 thread) + %s forward timed with both CPU ports '
+                   '(numpy/BLAS oracle on %d pairs, torch-CPU fp32 oracle on 1 pair; threads = cores), the faster one counted'
+                   % (n, samples[0][0].shape[0], len(sfm), 'HPLFlowNetShallow' if shallow else 'full HPLFlowNet', n),
+         'lattice_s': t_lat / n, 'forward_s': fwd_best, 'forward_s_numpy': fwd_numpy, 'forward_s_torch': t_torch,
+         'host_cpus': os.cpu_count(), 'cpu_model': cpu_model(),
          # the lattice stage alone with P worker processes, as the reference's DataLoader runs it
          'lattice_pairs_per_s_by_workers': dict({'1': n / t_lat}, **lattice_worker_rates(samples[0], sfm))}
     return d, flow0, bcl_oracle.epe3d(flow0, samples[0][2].T)
+
+
+def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=5, warmup=2):
+    """BASELINE config 4 on this GPU, inside the default command: `steps` training steps (device lattice build + forward +
+    EPE3D loss + backward + gradient all-reduce + Adam lr 1e-4, the reference's loop main.py:203-217) on the pairs of the
+    inference run; a fresh model with the same weights.  -> dict for the JSON line."""
+    from hplflownet_amd import ops, parallel
+    dev = pairs[0][0].device
+    targs = types.SimpleNamespace(**dict(vars(margs), evaluate=False))
+    model = getattr(H, arch)(targs)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(dev).train()
+    bank = ops.enable_weight_bank(True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    reducer = parallel.GradAllReducer(model.parameters())
+    loss = None
+
+    def one(i):
+        p1, p2 = pairs[i % len(pairs)]
+        with torch.no_grad():
+            lat = gen.build(p1, p2)
+        if bank is not None:
+            bank.refresh()
+        flow = model(p1[None], p2[None], lat)
+        ls = torch.norm(flow - sfs[i % len(pairs)][None], p=2, dim=1).mean()
+        opt.zero_grad(set_to_none=True)
+        ls.backward()
+        reducer()
+        opt.step()
+        return ls
+    try:
+        for i in range(warmup):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = one(warmup + i)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        out = {'ms_per_step': ms, 'steps': steps, 'warmup': warmup, 'pairs_per_s': 1e3 / ms, 'loss_last_step': float(loss),
+               'step': 'device lattice build + forward + EPE3D loss + backward + gradient all-reduce (world size 1 here) + Adam, '
+                       'one pair per GPU (BASELINE config 4), single stream'}
+    except Exception as e_:
+        out = {'failed': str(e_)}
+    ops.enable_weight_bank(False)
+    del model, opt, reducer
+    torch.cuda.empty_cache()
+    return out
+
+
+def source_stamp():
+    """What a PMC profile under profiles/ must have been taken with to describe THIS run's kernels: the kernel sources
+    and the switches that select kernels / tiles."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('gconv.hip', 'gconv3.hip', 'gconv_common.h', 'executor.hip'):
+        h.update(open(os.path.join(ROOT, 'hplflownet_amd', 'csrc', f), 'rb').read())
+    for k in ('HPL_MATH', 'HPL_SPLIT3_BN', 'HPL_TAP_GROUPS', 'HPL_TILE', 'HPL_WG3', 'HPL_PERSISTENT', 'HPL_SPLIT3_MIN_ROWS', 'HPL_SPLIT3_MIN_ROWS_STENCIL'):
+        h.update(('%s=%s;' % (k, os.environ.get(k, ''))).encode())
+    return h.hexdigest()
 
 
 def host_report(host, steps):
@@ -244,6 +347,7 @@ def main():
     ap.add_argument('--pool', type=int, default=4, help='distinct resident pairs cycled through the steps')
     ap.add_argument('--no-lattice', action='store_true', help='exclude the device lattice build from the step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-train-probe', action='store_true', help='skip the 5 training steps reported under "train"')
     ap.add_argument('--no-overlap', action='store_true',
                     help='build each lattice on the main stream instead of a second stream overlapping the previous forward')
     ap.add_argument('--streams', type=int, default=3,
@@ -398,7 +502,7 @@ def main():
         return out
 
     # which gather-GEMM class dominates this model / size: one untimed step with every launch timed
-    dominant = DOMINANT
+    dominant = DOMINANT_SPLIT3 if ops.SPLIT3 else DOMINANT_F32
     if not full:
         timers.enabled, timers.only = True, None
         model.native_forward = False         # the per-launch HIP events wrap the Python ops
@@ -465,9 +569,7 @@ def main():
         lps = float(sum(len(lat0.levels[L].blur[0].groups() or [1]) for L in (0, 1)))
         covered = n_l / lps
         dom = {'launches_per_step': lps, 'avg_launch_us': 1e3 * ms / n_l, 'ms_per_step': ms / covered,
-               'bound': 'mfma', 'achieved': gf * covered / (ms * 1e-3) / 1e3, 'peak': MFMA_F32_PEAK_TFLOPS,
-               'unit': 'TFLOP/s', 'gflop_per_step': gf, 'steps_covered': covered}
-        dom['frac'] = dom['achieved'] / dom['peak']
+               'gflop_per_step': gf, 'steps_covered': covered}
     # per-kernel detail: a separate, untimed, non-overlapped pass (an event pair around each of the
     # ~130 launches costs ~1.5 ms of host time per step, which the timed loop does not pay)
     detail_steps = min(a.steps, 10)
@@ -506,120 +608,129 @@ def main():
     clock_ghz = cyc / float(ticks) * 0.1 if ticks > 0 else None
     kernels = timers.summary(detail_steps)
     if rank == 0:
-        roofline = {'bound': 'mfma', 'achieved': dom.get('achieved'), 'peak': MFMA_F32_PEAK_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': dom.get('frac'), 'traffic': None,
-                    'kernel': ('k_gconv<64,128,2,4,true,8,COMPACT> (fp32-MFMA gather-GEMM, 64x128 tiles, 8 waves, 3 workgroups per CU: '
-                               'blur convs of bcn1_/bcn2_ as two tap-group passes each)') if full else 'k_gconv, class %s (fp32-MFMA gather-GEMM)' % dominant,
-                    'measured_mfma_ceiling': ceiling,
-                    'launches_per_step': dom.get('launches_per_step'), 'avg_launch_us': dom.get('avg_launch_us'),
-                    'gflop_per_step': dom.get('gflop_per_step')}
-        # how much of the algorithmic work the dominant kernel really executes (absent taps are skipped)
+        split3 = bool(ops.SPLIT3) and full
         lat0 = gen.build(*pairs[0])
+        # ---------------------------------------------------------------- roofline of the dominant kernel
+        # The unit is MATRIX-PIPE TIME.  SQ_VALU_MFMA_BUSY_CYCLES counts the cycles a SIMD's matrix pipe is occupied: 64 per
+        # v_mfma_f32_32x32x2_f32 (4096 flop), 32 per v_mfma_f32_32x32x16_bf16 (32768 flop) -- at 2.4 GHz on 1024 SIMDs that is
+        # the 157.3 TF fp32 / 2.5 PF bf16 datasheet peaks.  achieved = executed MFMA flops per launch / launch duration;
+        # frac = achieved / peak = busy cycles / (1024 SIMDs x duration x 2.4 GHz), a fraction <= 1 whatever the operand type.
+        # The executed work per launch is MEASURED (rocprofv3 --pmc on this command, tools/pmc_mfma.py -> profiles/r03_mfma_pmc.json,
+        # used only when its stamp matches the kernel sources and tile configuration of this run) or, failing that, mirrored
+        # on the host from the lattice tables (the kernel skips the MFMAs of a 32-row block for slices whose taps it lacks).
+        wide = [(0, 580, 1024), (1, 324, 512)] if full else []
+        alg_gf = [2.0 * lat0.levels[L].H[0] * 15 * c * o / 1e9 for L, c, o in wide]          # fp32 multiply-adds, GF
+        ex = kernels.get(dominant, {})
+        roofline = {'bound': 'mfma', 'unit': 'TFLOP/s', 'traffic': None}
         if full:
-            fl = [2.0 * lat0.levels[L].H[0] * 15 * c * o for L, c, o in ((0, 580, 1024), (1, 324, 512))]
             def executed(tbl, c):
-                # share of (tile, slice) pairs executed; with tap groups: one pass per group, own row order
                 groups = tbl.groups()
                 if not groups:
-                    return needed_slice_fraction(tbl, c, BM=64)
+                    return needed_slice_fraction(tbl, c, BM=32)
                 F = tbl.t.shape[0]
-                return sum((f1 - f0) * needed_slice_fraction(types.SimpleNamespace(t=tbl.t[f0:f1], perm=p), c, BM=64)
+                return sum((f1 - f0) * needed_slice_fraction(types.SimpleNamespace(t=tbl.t[f0:f1], perm=p), c, BM=32)
                            for f0, f1, p in groups) / F
-            fr = [executed(lat0.levels[L].blur[0], c) for L, c in ((0, 580), (1, 324))]
-            roofline['executed_fraction'] = (fl[0] * fr[0] + fl[1] * fr[1]) / (fl[0] + fl[1])
-        # Kernel quality is what the kernel does alone on the GPU: with several forward streams the
-        # launches inside the timed loop share the CUs with the kernels of other pairs, so their HIP-event
-        # durations measure the sharing, not the kernel.  The headline roofline numbers therefore come from
-        # the single-stream pass that follows the timed loop in this same process (HIP events around the
-        # same launches; this is also what a rocprofv3 run of this command sees, because kernel tracing
-        # serialises the streams); the in-loop figures are kept next to them.
-        ex = kernels.get(dominant, {})
-        if overlap and n_fwd > 1 and ex.get('achieved'):
-            roofline['in_loop'] = {'achieved': roofline['achieved'], 'frac': roofline['frac'],
-                                   'avg_launch_us': roofline['avg_launch_us'],
-                                   'launches_per_step': roofline['launches_per_step']}
-            roofline.update(achieved=ex['achieved'], frac=ex['frac'], avg_launch_us=ex['avg_launch_us'],
-                            launches_per_step=ex['launches_per_step'], gflop_per_step=ex.get('gflop_per_step'))
-            roofline['measured'] = ('single-stream pass of %d steps right after the timed loop (same process, HIP events '
-                                    'around the same launches); in_loop = inside the timed loop, where kernels of %d pairs '
-                                    'share the GPU' % (detail_steps, n_fwd))
-        else:
-            roofline['measured'] = 'HIP events around the launches inside the timed loop'
-        # `achieved` / `frac` are the MFMA flops the kernel EXECUTES per launch / its launch duration: a roofline
-        # fraction (<= 1).  The algorithmic rate (2*H*15*C_in*C_out, what the reference multiplies, incl. the
-        # products with absent neighbours' zero rows that the kernel skips) is kept as *_algorithmic; it can
-        # exceed the peak.  The executed share is MEASURED when profiles/r02_mfma_pmc.json exists (rocprofv3
-        # --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 on this command, tools/pmc_mfma.py), else mirrored on the host.
-        if roofline.get('achieved'):
-            roofline['achieved_algorithmic'] = roofline['achieved']
-            roofline['frac_algorithmic'] = roofline['achieved'] / MFMA_F32_PEAK_TFLOPS
-            share, src = roofline.get('executed_fraction', 1.0), 'host mirror of the kernel\'s slice lists (bench.needed_slice_fraction)'
-            pmc = os.path.join(ROOT, 'profiles', 'r02_mfma_pmc.json')
-            # (the PMC figure is per launch of the default tap-group schedule at N = 8192)
-            if full and os.path.exists(pmc) and a.points == 8192 and a.data == 'frustum':
+            fr = [executed(lat0.levels[L].blur[0], c) for L, c, _ in wide]
+            mirror_gf = sum(a_ * b_ for a_, b_ in zip(alg_gf, fr))                              # executed fp32-equivalent GF / step
+            lps = float(sum(len(lat0.levels[L].blur[0].groups() or [1]) for L, _, _ in wide))
+            flop_per_busy = 1024.0 if split3 else 64.0
+            peak = MFMA_BF16_PEAK_TFLOPS if split3 else MFMA_F32_PEAK_TFLOPS
+            products = SPLIT3_PRODUCTS if split3 else 1
+            busy_per_launch = mirror_gf * 1e9 * products / flop_per_busy / lps                # matrix-pipe cycles per launch
+            src = 'host mirror of the kernel\'s slice lists and 32-row block masks (bench.needed_slice_fraction)'
+            stamp = source_stamp()
+            pmc_path = os.path.join(ROOT, 'profiles', 'r03_mfma_pmc.json')
+            pmc_note = None
+            if os.path.exists(pmc_path) and a.points == 8192 and a.data == 'frustum' and not a.train:
                 try:
-                    pj = json.load(open(pmc))
-                    if abs(pj.get('dominant_launches_per_step', 4.0) - roofline.get('launches_per_step', 0.0)) > 1e-6:
-                        raise ValueError('the PMC run used another tap-group schedule')
-                    alg = roofline['gflop_per_step'] / roofline['launches_per_step']        # GF per launch
-                    share = pj['dominant_executed_gflop_per_launch'] / alg
-                    src = 'rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 (profiles/r02_mfma_pmc.json: %.1f GF executed per launch)' \
-                        % pj['dominant_executed_gflop_per_launch']
-                    roofline['executed_fraction_host_mirror'] = roofline.get('executed_fraction')
-                    roofline['executed_fraction'] = share
-                    if pj.get('executed_gflop_per_step') and not a.train:
-                        # the whole step against the same roofline: every kernel's executed MFMA flops (PMC) / step time
-                        tf = pj['executed_gflop_per_step'] / (elapsed / a.steps * 1e3)        # GF / ms, per GPU
-                        roofline['whole_step'] = {'executed_gflop': pj['executed_gflop_per_step'], 'achieved': tf,
-                                                  'frac': tf / MFMA_F32_PEAK_TFLOPS,
-                                                  'note': 'all MFMA kernels of one pair (PMC) / ms_per_step, per GPU'}
-                except Exception:
-                    pass
-            if not full:
-                share, src = 1.0, 'no tap skipping counted for this model (algorithmic = executed)'
-            roofline['executed_source'] = src
-            roofline['achieved'] = roofline['achieved_algorithmic'] * share
-            roofline['frac'] = roofline['achieved'] / MFMA_F32_PEAK_TFLOPS
-            if 'in_loop' in roofline and roofline['in_loop'].get('achieved') is None:
-                del roofline['in_loop']          # nothing was bracketed inside the timed loop (native run, other model)
-            if 'in_loop' in roofline:
-                roofline['in_loop']['achieved_algorithmic'] = roofline['in_loop']['achieved']
-                roofline['in_loop']['achieved'] = roofline['in_loop']['achieved'] * share
-                roofline['in_loop']['frac'] = roofline['in_loop']['achieved'] / MFMA_F32_PEAK_TFLOPS
+                    pj = json.load(open(pmc_path))
+                    if pj.get('stamp') != stamp:
+                        pmc_note = 'profiles/r03_mfma_pmc.json ignored: it was taken with other kernel sources / configuration'
+                    elif abs(pj['dominant_launches_per_step'] - lps) > 1e-6:
+                        pmc_note = 'profiles/r03_mfma_pmc.json ignored: another tap-group schedule'
+                    elif abs(pj['dominant_busy_cycles_per_launch'] / busy_per_launch - 1.0) > 0.05:
+                        pmc_note = ('profiles/r03_mfma_pmc.json ignored: its executed work (%.4g pipe cycles per launch) and the host '
+                                    'mirror (%.4g) disagree by more than 5 %%' % (pj['dominant_busy_cycles_per_launch'], busy_per_launch))
+                    else:
+                        roofline['executed_host_mirror_busy_cycles'] = busy_per_launch
+                        busy_per_launch = pj['dominant_busy_cycles_per_launch']
+                        src = 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES (profiles/r03_mfma_pmc.json, stamp %s)' % stamp[:12]
+                        if pj.get('busy_cycles_per_step'):
+                            # the whole step against the same roofline: matrix-pipe cycles of ALL kernels of one pair / step time
+                            t_step = elapsed / a.steps / world
+                            roofline['whole_step'] = {
+                                'mfma_busy_cycles': pj['busy_cycles_per_step'],
+                                'frac': pj['busy_cycles_per_step'] / (SIMDS * PEAK_CLOCK_HZ * elapsed / a.steps),
+                                'note': 'matrix-pipe cycles of all kernels of one pair (PMC) / (1024 SIMDs x ms_per_step x 2.4 GHz), per GPU'}
+                            del t_step
+                except Exception as e_:
+                    pmc_note = 'profiles/r03_mfma_pmc.json unreadable: %s' % e_
+            if pmc_note:
+                roofline['pmc_note'] = pmc_note
+
+            def rates(avg_launch_us):
+                t_ = avg_launch_us * 1e-6
+                ach = busy_per_launch * flop_per_busy / t_ / 1e12
+                return {'achieved': ach, 'frac': busy_per_launch / (SIMDS * PEAK_CLOCK_HZ * t_), 'avg_launch_us': avg_launch_us,
+                        'f32_equivalent_tflops': ach / products,
+                        'f32_equivalent_algorithmic_tflops': sum(alg_gf) / lps * 1e9 / t_ / 1e12}
+            roofline.update(peak=peak, launches_per_step=lps, gflop_per_step_algorithmic_f32=sum(alg_gf),
+                            executed_fraction=mirror_gf / sum(alg_gf), executed_source=src,
+                            mfma_busy_cycles_per_launch=busy_per_launch,
+                            kernel=('k_gconv3<4,8> (gather-GEMM on the bf16 MFMA, every fp32 operand split exactly into 3 bf16 terms, 6 partial '
+                                    'products accumulated in fp32; 128x256 tiles, 8 waves; blur convs of bcn1_/bcn2_ as two tap-group passes each)')
+                            if split3 else 'k_gconv<64,128,2,4,true,8,COMPACT> (fp32-MFMA gather-GEMM, 64x128 tiles, 8 waves, 3 workgroups per CU)')
+            # Kernel quality is what the kernel does alone on the GPU: with several forward streams the launches inside the timed
+            # loop share the CUs with kernels of other pairs.  Headline = the single-stream pass right after the timed loop (same
+            # process, HIP events around the same launches; also what rocprofv3 sees, because kernel tracing serialises the
+            # streams); in_loop = the same launches bracketed by the native executor inside the timed loop.
+            if ex.get('avg_launch_us'):
+                roofline.update(rates(ex['avg_launch_us']))
+                roofline['measured'] = 'single-stream pass of %d steps right after the timed loop (HIP events around each launch)' % detail_steps
+                if dom.get('avg_launch_us'):
+                    roofline['in_loop'] = rates(dom['avg_launch_us'])
+                    roofline['in_loop']['note'] = 'inside the timed loop, where kernels of %d pairs share the GPU' % n_fwd
+            elif dom.get('avg_launch_us'):
+                roofline.update(rates(dom['avg_launch_us']))
+                roofline['measured'] = 'HIP events around the launches inside the timed loop'
+            if split3:
+                roofline['f32_mfma_peak'] = MFMA_F32_PEAK_TFLOPS
+                roofline['arithmetic'] = ('fp32 operands as exact sums of three bf16 terms (round-to-nearest splits); the 6 partial products with '
+                                          'i + j <= 2 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16: error vs float64 not larger than the '
+                                          'fp32-MFMA kernel\'s (tests/test_gpu_split3.py); HPL_MATH=f32 selects the fp32-MFMA kernels')
+        else:
+            # other models / sizes: the dominant class of the per-class table, algorithmic = executed (no skipping counted)
+            roofline.update(peak=ex.get('peak'), achieved=ex.get('achieved'), frac=ex.get('frac'), avg_launch_us=ex.get('avg_launch_us'),
+                            launches_per_step=ex.get('launches_per_step'), kernel='class %s of the per-class table' % dominant,
+                            measured='single-stream pass after the timed loop', executed_source='algorithmic = executed')
+        roofline['measured_f32_mfma_ceiling'] = ceiling
         if clock_ghz:
-            # the chip clocks to its power budget: the fp32 matrix pipe alone sustains 2.39 GHz on changing operands
-            # (tools/mfma_probe3.py), this kernel's global-load traffic pulls the clock down (profiles/r02g_ablate.txt:
-            # 2.19 GHz with the loads removed, 2.04 when every load hits cache, 1.88 as shipped)
+            # the chip clocks to its power budget: sampled workgroups of the dominant launches accumulate shader cycles and
+            # 100 MHz wall ticks (hpl_gconv_desc.clock_probe)
             roofline['shader_clock_ghz'] = clock_ghz
-            roofline['peak_at_measured_clock'] = 1024 * 64 * clock_ghz / 1e3          # 1024 SIMDs x 64 FLOP/clk
-            if roofline.get('achieved'):
-                roofline['frac_at_measured_clock'] = roofline['achieved'] / roofline['peak_at_measured_clock']
-        roofline['note'] = ('achieved / frac: executed MFMA flops per launch / HIP-event launch duration (a fraction of the '
-                            '157.3 TFLOP/s fp32-MFMA peak, <= 1); *_algorithmic: 2*H*15*C_in*C_out per launch, what the '
-                            'reference multiplies -- slices whose taps are absent for a whole tile are skipped, '
-                            'executed_fraction is the share that runs')
+            if roofline.get('frac'):
+                roofline['frac_at_measured_clock'] = roofline['frac'] * PEAK_CLOCK_HZ / (clock_ghz * 1e9)
+        roofline['note'] = ('achieved = executed MFMA flops per launch / launch duration on the stream it runs on; frac = the matrix pipe\'s busy '
+                            'cycles / (1024 SIMDs x duration x 2.4 GHz); f32_equivalent_* = the fp32 multiply-adds that work stands for '
+                            '(executed: absent-neighbour products skipped; algorithmic: 2*H*15*C_in*C_out as the reference multiplies them)')
         prof = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(prof) and full:
             try:
-                roofline['traffic'] = json.load(open(prof)).get('k_gconv_64x128_bytes_per_launch')
+                tj = json.load(open(prof))
+                if tj.get('stamp') == source_stamp():
+                    roofline['traffic'] = tj.get('dominant_bytes_per_launch')
+                    for nm in ('splat', 'slice'):
+                        if nm in kernels and tj.get('k_%s_bytes_per_launch_all_levels' % nm):
+                            kernels[nm]['traffic_all_levels_avg'] = tj['k_%s_bytes_per_launch_all_levels' % nm]
+                else:
+                    roofline['traffic_note'] = 'profiles/pmc_traffic.json ignored: taken with other kernel sources / configuration'
             except Exception:
                 pass
-        try:        # measured HBM-side bytes per launch of the splat / slice kernels (profiles/pmc_traffic.json, PMC passes)
-            pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-            for nm in ('splat', 'slice'):
-                if nm in kernels and full and pj.get('k_%s_bytes_per_launch_all_levels' % nm):
-                    kernels[nm]['traffic_all_levels_avg'] = pj['k_%s_bytes_per_launch_all_levels' % nm]
-        except Exception:
-            pass
-        if dominant in kernels and roofline.get('executed_fraction') is not None and kernels[dominant].get('achieved'):
-            kd = kernels[dominant]           # same convention in the per-class table: frac = executed, <= 1
-            kd['achieved_algorithmic'], kd['frac_algorithmic'] = kd['achieved'], kd['frac']
-            kd['achieved'] = kd['achieved_algorithmic'] * (roofline['executed_fraction'] if full else 1.0)
-            kd['frac'] = kd['achieved'] / kd['peak']
         line = {'metric': 'point-pairs/sec + EPE3D, N=8192 FlyingThings3D, 1/2/4/8 MI355X',
                 'value': world * a.steps / elapsed, 'unit': 'point-pairs/s', 'n_gpus': world, 'steps': a.steps,
                 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
-                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic' if a.data == 'frustum' else 'synthetic (surface patches)',
+                'scaling': 'weak', 'vs_baseline': None,
+                'dtype': 'f32 (wide layers: fp32 operands as exact 3 x bf16 splits, fp32 accumulate)' if ops.SPLIT3 else 'f32', 'data': 'synthetic' if a.data == 'frustum' else 'synthetic (surface patches)',
                 'config': {'workload': ('full HPLFlowNet %s (7 levels, 19.3M params, random init), ' if full else 'HPLFlowNetShallow %s (5 levels, random init), ') % ('training step (fwd+bwd+grad all-reduce+Adam)' if a.train else 'inference') +
                                        ('FT3D-like synthetic pair' if a.data == 'frustum' else 'synthetic pair of surface patches') + ', N=%d, bs=1 per GPU' % a.points,
                            'num_points': a.points, 'step_includes_lattice_build': not a.no_lattice,
@@ -636,6 +747,9 @@ def main():
                 'pipelined_output_check': pipe_check, 'single_pair_latency_ms': latency,
                 'device_memory_mb': {'max_allocated': torch.cuda.max_memory_allocated(dev) / 2 ** 20,
                                      'reserved': torch.cuda.memory_reserved(dev) / 2 ** 20}}
+        if world == 1 and not a.train and not a.no_train_probe and full:
+            sfs_ = [torch.from_numpy(sf.T.copy()).to(dev) for _, _, sf in pairs_np]
+            line['train'] = train_probe(H, a.arch, margs, state, pairs, sfs_, gen)
         if world == 1 and not a.no_cpu_baseline and not a.train:
             p1, p2, sf = pairs_np[0]
             base, flow_cpu, epe_cpu = cpu_baseline(pairs_np[:2], sfm, state, shallow=not full)

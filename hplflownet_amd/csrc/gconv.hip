@@ -1179,30 +1179,43 @@ namespace {
 // the mask's numeric value, which is not their weight; with the heaviest tiles first the workgroups of a launch
 // finish within one light tile of each other instead of one average tile.
 __global__ void __launch_bounds__(1024) k_tile_rank(int32_t *__restrict__ tile_mask, int tiles) {
-    // stable counting sort by tap count, descending: thread (c, seg) owns class c in segment seg of the tile list
-    __shared__ int cnt[16][64];
-    __shared__ int base[16];
-    const int t = threadIdx.x, c = t >> 6, seg = t & 63;
-    const int per = (tiles + 63) / 64;
-    const int j0 = seg * per, j1 = min(tiles, j0 + per);
-    int n = 0;
-    for (int j = j0; j < j1; ++j) n += (__popc(tile_mask[(int64_t)j * 8] & 0x7fff) == c) ? 1 : 0;
-    cnt[c][seg] = n;
+    // stable counting sort by tap count, descending (equal counts keep tile order): chunks of 1024 tiles, one per thread;
+    // inside a chunk a tile's rank in its class = ballot prefix inside its wave + the class counts of the waves before it
+    __shared__ int hist[16], base[16], running[16], wcnt[16][16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < 16) { hist[t] = 0; running[t] = 0; }
     __syncthreads();
-    if (t < 16) {
-        int run = 0;
-        for (int s2 = 0; s2 < 64; ++s2) { const int v = cnt[t][s2]; cnt[t][s2] = run; run += v; }
-        base[t] = run;                      // class total
-    }
+    for (int j = t; j < tiles; j += 1024) atomicAdd(&hist[__popc(tile_mask[(int64_t)j * 8] & 0x7fff)], 1);
     __syncthreads();
     if (t == 0) {
         int off = 0;
-        for (int b = 15; b >= 0; --b) { const int v = base[b]; base[b] = off; off += v; }
+        for (int b = 15; b >= 0; --b) { base[b] = off; off += hist[b]; }
     }
     __syncthreads();
-    int pos = base[c] + cnt[c][seg];
-    for (int j = j0; j < j1; ++j)
-        if (__popc(tile_mask[(int64_t)j * 8] & 0x7fff) == c) tile_mask[(int64_t)(pos++) * 8 + 6] = j;
+    for (int j0 = 0; j0 < tiles; j0 += 1024) {
+        const int j = j0 + t;
+        const int c = j < tiles ? __popc(tile_mask[(int64_t)j * 8] & 0x7fff) : -1;
+        int mine = 0;
+#pragma unroll
+        for (int cls = 0; cls < 16; ++cls) {
+            const unsigned long long bal = __ballot(c == cls);
+            if (c == cls) mine = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[wave][cls] = __popcll(bal);
+        }
+        __syncthreads();
+        if (c >= 0) {
+            int before = 0;
+            for (int w = 0; w < wave; ++w) before += wcnt[w][c];
+            tile_mask[(int64_t)(base[c] + running[c] + before + mine) * 8 + 6] = j;
+        }
+        __syncthreads();
+        if (t < 16) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wcnt[w][t];
+            running[t] += tot;
+        }
+        __syncthreads();
+    }
 }
 }  // namespace
 

@@ -482,7 +482,10 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     if (!split3_enabled() || p.scat || p.C < 32 || p.N % 64 != 0 || p.K > 32768) return false;
     if (p.F > 15 || (p.w_bytes / (p.ldw * 4)) % 8 != 0) return false;
     static const int min_rows = getenv("HPL_SPLIT3_MIN_ROWS") ? atoi(getenv("HPL_SPLIT3_MIN_ROWS")) : 8192;
-    if (p.M < min_rows || p.N < 256) return false;
+    // single-pass stencils of the mid-size levels (bcn3_: 9 433 rows x 15 taps x 388 channels) run faster on the fp32 kernel's
+    // 64 x 64 tiles (0.31 vs 0.45 ms: a 128-row tile unites many more tap masks); dense launches gain from 8 192 rows on
+    static const int min_rows_stencil = getenv("HPL_SPLIT3_MIN_ROWS_STENCIL") ? atoi(getenv("HPL_SPLIT3_MIN_ROWS_STENCIL")) : 16384;
+    if (p.M < min_rows || p.N < 256 || (p.F > 1 && p.M < min_rows_stencil)) return false;
     p.tiles_m = (int)cdiv(p.M, BM3);
     // 128 x 256 tiles (8 waves, one workgroup per CU) where N allows: 5-12 % faster than 128 x 128 on every wide launch of
     // the model (profiles/r03c_split3_kernel_ab.txt) although they leave fewer tiles per CU
@@ -502,11 +505,15 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
         p.col_rows = p.col_share == 1 ? p.tiles_m : (int)cdiv(p.tiles_m, COL_CHUNK * p.col_share) * COL_CHUNK;
         grid = p.tiles_n * p.col_share * p.col_rows;
     }
-    const bool f8 = p.F <= 8;
+    // instances by the taps whose indices a tile stages in LDS: 1 (dense GEMMs), <= 8 (tap-group passes), <= 15
     if (bn256) {
-        if (f8) k_gconv3<4, 8><<<grid, 512, 0, s>>>(p); else k_gconv3<4, 15><<<grid, 512, 0, s>>>(p);
+        if (p.F == 1) k_gconv3<4, 1><<<grid, 512, 0, s>>>(p);
+        else if (p.F <= 8) k_gconv3<4, 8><<<grid, 512, 0, s>>>(p);
+        else k_gconv3<4, 15><<<grid, 512, 0, s>>>(p);
     } else {
-        if (f8) k_gconv3<2, 8><<<grid, 256, 0, s>>>(p); else k_gconv3<2, 15><<<grid, 256, 0, s>>>(p);
+        if (p.F == 1) k_gconv3<2, 1><<<grid, 256, 0, s>>>(p);
+        else if (p.F <= 8) k_gconv3<2, 8><<<grid, 256, 0, s>>>(p);
+        else k_gconv3<2, 15><<<grid, 256, 0, s>>>(p);
     }
     return true;
 }

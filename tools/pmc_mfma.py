@@ -14,8 +14,11 @@ import sqlite3
 import sys
 
 PROBE_FLOP = 1024 * 4.0 * 1500 * 64 * 4096
+import os
 import re
-DOMINANT = re.compile(r'k_gconv<64, 128, 2, 4, true, (8|15)\b')      # the stencil instances of the 64 x 128 class
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the wide tap-group passes: the split-operand kernel (default) or, with HPL_MATH=f32, the fp32-MFMA 64 x 128 stencil class
+DOMINANT = re.compile(r'k_gconv3<4, 8>' if os.environ.get('HPL_MATH', 'split3') != 'f32' else r'k_gconv<64, 128, 2, 4, true, (8|15)\b')
 
 
 def main():
@@ -43,7 +46,7 @@ def main():
         gf = mops * unit_used / 1e9
         lines.append('%-92s %7d ' % (name[:92], n) + ' '.join('%26.1f' % v.get(x, (0, 0.0, 0.0))[1] for x in ctrs)
                      + ' %14.3f' % gf)
-        if gf > 0:
+        if gf > 0 or v.get('SQ_VALU_MFMA_BUSY_CYCLES', (0, 0.0, 0.0))[1] > 0:
             out['kernels'][name] = {'launches': n, 'executed_gflop_per_launch': gf,
                                     **{x: v[x][1] for x in v}}
         if DOMINANT.search(name):
@@ -51,6 +54,10 @@ def main():
             out['dominant_executed_gflop_per_launch'] = gf
             out['dominant_launches'] = n
             busy = v.get('SQ_VALU_MFMA_BUSY_CYCLES')
+            if busy:
+                # matrix-pipe cycles per launch, summed over the SIMDs: 64 per v_mfma_f32_32x32x2_f32, 32 per
+                # v_mfma_f32_32x32x16_bf16 -- the dtype-independent measure bench.py prices against 1024 SIMDs x 2.4 GHz
+                out['dominant_busy_cycles_per_launch'] = busy[1]
             gui = v.get('GRBM_GUI_ACTIVE')
             if busy and gui and gui[1] > 0:
                 # busy cycles are summed over the SIMDs that report (per-XCD sampling): quote the ratio only
@@ -61,9 +68,13 @@ def main():
         once = [k['launches'] for n_, k in out['kernels'].items() if re.search(r'k_gconv<64, 32, 2, 1, false, 1\b', n_)]
         steps = float(once[0]) if once else out['dominant_launches'] / 4.0
         out['dominant_launches_per_step'] = out['dominant_launches'] / steps
+        out['busy_cycles_per_step'] = sum(v_.get('SQ_VALU_MFMA_BUSY_CYCLES', (0, 0.0, 0.0))[2] for n_, v_ in per.items()
+                                          if 'k_mfma_probe' not in n_) / steps
         out['executed_gflop_per_step'] = sum(k['launches'] * k['executed_gflop_per_launch'] for n_, k in out['kernels'].items()
                                              if 'k_mfma_probe' not in n_) / steps
         lines.append('# executed MFMA work of the whole step (all kernels): %.1f GF' % out['executed_gflop_per_step'])
+    import bench
+    out['stamp'] = bench.source_stamp()
     open(prefix + '.txt', 'w').write('\n'.join(lines) + '\n')
     json.dump(out, open(prefix + '.json', 'w'), indent=1)
     print('\n'.join(lines[:14]))

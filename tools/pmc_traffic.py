@@ -7,8 +7,10 @@ import json
 import sqlite3
 import sys
 
+import os
 import re
-DOMINANT = re.compile(r'k_gconv<64, 128, 2, 4, true, (8|15)\b')      # the stencil instances of the 64 x 128 class
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+DOMINANT = re.compile(r'k_gconv3<4, 8>' if os.environ.get('HPL_MATH', 'split3') != 'f32' else r'k_gconv<64, 128, 2, 4, true, (8|15)\b')
 
 
 def per_launch(db, ctr):
@@ -37,7 +39,8 @@ def main():
                      'the dominant k_gconv<64,128,2,4,true,...> stencil instance, averaged over its four launches per step. Counter unit KiB; FETCH_SIZE '
                      'doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane reads), WRITE_SIZE as is.',
          'fetch_size_kib_per_launch_raw': fetch_kib, 'write_size_kib_per_launch': write_kib, 'launches_fetch_pass': f[fk][0],
-         'k_gconv_64x128_bytes_per_launch': total, 'algorithmic_bytes_per_launch': 82000000, 'history': hist,
+         'k_gconv_64x128_bytes_per_launch': total, 'dominant_bytes_per_launch': total, 'dominant_kernel': fk,
+         'algorithmic_bytes_per_launch': 82000000, 'history': hist,
          'note': 'fetch >> algorithmic: L2-miss traffic of the gathered activation rows (every column tile re-gathers its '
                  'tile-row from the 60 MB matrix, which lives in the 256 MB Infinity Cache); the weight panels are shared in '
                  'L2 by the column-major XCD order. The kernel is matrix-pipe bound at the clock the chip sustains; see '
@@ -48,6 +51,8 @@ def main():
         if fk2 and wk2:
             d['%s_bytes_per_launch_all_levels' % nm] = int((2 * f[fk2[0]][1] + w[wk2[0]][1]) * 1024)
             d['%s_launches' % nm] = f[fk2[0]][0]
+    import bench
+    d['stamp'] = bench.source_stamp()
     json.dump(d, open(out, 'w'), indent=1)
     print(json.dumps({k: d[k] for k in ('fetch_size_kib_per_launch_raw', 'write_size_kib_per_launch', 'k_gconv_64x128_bytes_per_launch')}))
     for name, tab in (('FETCH_SIZE', f), ('WRITE_SIZE', w)):
