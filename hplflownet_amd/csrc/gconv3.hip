@@ -36,6 +36,12 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// Diagnostic builds (tools/gpu/ablate.sh, -DHPL_ABLATE=n; results are WRONG, timing only): 1 = no global loads in the main
+// loop (gathered rows and weight fragments), 2 = no split + LDS stores of the gathered rows, 3 = both, 4 = no fragment reads
+#ifndef HPL_ABLATE
+#define HPL_ABLATE 0
+#endif
+
 namespace {
 
 // (x0, x1) -> packed bf16 pairs hi / mid / lo with x = hi + mid + lo exactly (round-to-nearest-even at each level)
@@ -172,29 +178,40 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     // half-step after its loads were issued; `pin` then orders the compiler's reads behind that wait.
     float4_t ra[2][A_PASSES];
     int f0_u = 0, c0_u = 0, k_u = 0;
-    auto load_a = [&](auto set_tag, int kt) {
-        constexpr int SET = decltype(set_tag)::value;
+    // load_a_rows: (f, c) of this thread's float4 columns in slice kt and the LDS reads of their source rows;
+    // load_a_issue: the loads.  Two calls, so that the LDS round trip of the indices sits behind the first MFMAs of a
+    // half-step instead of in front of them.
+    int a_rows[A_PASSES], a_c[A_PASSES];
+    bool a_ok[A_PASSES];
+    auto load_a_rows = [&](int kt) {
         const int k0 = kt * BK;
         c0_u += k0 - k_u;
         k_u = k0;
         while (c0_u >= p.C) { c0_u -= p.C; ++f0_u; }
-        unsigned off[A_PASSES];
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             const int kqi = kq ^ ((i & 1) << 2);      // (full 128-byte lines per instruction; every thread ends up with
             int c = c0_u + kqi * 4, f = f0_u;         //  HALF_PASSES float4 of each half-slice)
             if (c >= p.C) { c -= p.C; ++f; }
-            const int row = Is[min(f, F_LDS - 1) * BM + arow0 + i * ROWS_PP];
-            const bool ok = (f < p.F) && (row >= 0);
-            off[i] = ok ? (unsigned)row * lda_b + (unsigned)c * 4u : OOB;
+            a_rows[i] = Is[min(f, F_LDS - 1) * BM + arow0 + i * ROWS_PP];
+            a_c[i] = c;
+            a_ok[i] = f < p.F;
         }
+    };
+    auto load_a_issue = [&](auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        if (HPL_ABLATE == 1 || HPL_ABLATE == 3) return;
         const int32x4_t rs = rsrc_a;                  // (asm operands inside a generic lambda must be its own locals)
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             float4_t &dst = ra[SET][i];
-            const unsigned o = off[i];
+            const unsigned o = (a_ok[i] && a_rows[i] >= 0) ? (unsigned)a_rows[i] * lda_b + (unsigned)a_c[i] * 4u : OOB;
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(o), "s"(rs) : "memory");
         }
+    };
+    auto load_a = [&](auto set_tag, int kt) {
+        load_a_rows(kt);
+        load_a_issue(set_tag);
     };
     auto pin = [&](auto set_tag) {
         constexpr int SET = decltype(set_tag)::value;
@@ -214,6 +231,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     const int kb_w = (t >> 1) & 1;
     auto store_a = [&](auto set_tag, int h, int st, int j) {
         constexpr int SET = decltype(set_tag)::value;
+        if (HPL_ABLATE == 2 || HPL_ABLATE == 3) return;
         const bool odd = (hb ^ h) != 0;
         const float4_t v = odd ? ra[SET][2 * j + 1] : ra[SET][2 * j];
         const int row = arow0 + (2 * j + (odd ? 1 : 0)) * ROWS_PP;
@@ -228,6 +246,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     // weight fragments of half h of slice kt straight into stage st: wave (wm, wn) fetches k-block wm of the half for
     // the 64 columns of column block wn, one 1 KiB LDS-direct load per plane
     auto load_b = [&](int kt, int h, int st) {
+        if (HPL_ABLATE == 1 || HPL_ABLATE == 3) return;
         const unsigned kbg = (unsigned)(kt * (BK / 8) + h * 2 + wm);
         const unsigned col = (unsigned)(n0 + wn * 64 + lane);
         const unsigned off = (col < (unsigned)p.ldw) ? kbg * ldw16 + col * 16u : OOB;
@@ -295,6 +314,12 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                     need[i] = !blockskip || (((bmask[i] >> f_lo) | (two ? (bmask[i] >> (f_lo + 1)) : 0)) & 1);
             }
             u32x4 af[3][2], bf[3][2];
+            if (HPL_ABLATE == 4) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { af[pl][i] = u32x4{(unsigned)st, 1u, 2u, 3u}; bf[pl][i] = u32x4{4u, 5u, (unsigned)h, 7u}; }
+            } else
             if (need[0] || need[1]) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
@@ -305,17 +330,16 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                     }
             }
             if constexpr (W) load_b(kt_w, h, st2);
-            if constexpr (L) load_a(setl_tag, kt_l);
+            if constexpr (L) load_a_rows(kt_l);
             if constexpr (W) { if (h == 0) pin(setw_tag); }
-            // products a_i * b_j with i + j <= 2, smallest first; per 32-row block alternating over its two accumulators
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+            // products a_i * b_j with i + j <= 2 in the order their fragments arrive from LDS (planes are read hi, mid, lo: the
+            // hi x hi product starts after the first four reads instead of after all twelve)
+            constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
+            constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
             if (need[0] && need[1]) {
-                // the common case, straight-line: the splits and LDS stores of the staged half-slice are dropped into the
-                // shadows of the MFMAs (a wave issues in order: left behind the MFMAs they would add ~600 cycles per
-                // half-step in which this wave keeps the matrix pipe idle)
+                // the common case, straight-line
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                for (int q = 0; q < 6; ++q) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -323,6 +347,14 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
                                                                                 __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
                                                                                 acc[i][j], 0, 0, 0);
+                    if (q == 0) {
+                        // the gathered loads of slice s+2 go out behind the first product: their row indices have come
+                        // back from LDS by now
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (L) load_a_issue(setl_tag);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 if constexpr (W) {
 #pragma unroll
                     for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, st2, j);
@@ -336,6 +368,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                     }
                 }
             } else {
+                if constexpr (L) load_a_issue(setl_tag);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if (need[i]) {                      // wave-uniform: the 32-row block has a tap of this slice
