@@ -111,3 +111,47 @@ def test_transforms_match_reference_vectors():
                 assert got.dtype == want.dtype and np.array_equal(got, want), (tag, name, suffix)
         assert np.array_equal(pc1, keep1) and np.array_equal(pc2, keep2)      # inputs are left alone
     assert 'together_args' in repr(F.make(data, 'Augmentation', F.CASES[3][3 - 1]))
+
+
+def test_readers_match_reference_readers(tmp_path):
+    """Row f3 pinned to the reference: tests/golden/datasets.npz holds what the reference's own FlyingThings3DSubset /
+    KITTI classes returned on the synthetic tree of tools/make_dataset_fixture.make_tree (sample lists, pc_loader
+    outputs, one __getitem__ through the reference's ProcessData under np.random.seed); the readers here give the same
+    on the same tree, bit for bit."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), 'tools'))
+    import make_dataset_fixture as F
+    gold = np.load(os.path.join(here, 'golden', 'datasets.npz'))
+    root = str(tmp_path)
+    F.make_tree(root)
+    real = os.path.realpath(root)
+    rel = lambda ds: [os.path.relpath(p, real) for p in ds.samples]
+    pd = lambda seed=None: ProcessData(F.PD_ARGS['dp'], F.PD_ARGS['n'], F.PD_ARGS['less'], seed=seed)
+    for split, train in (('train', True), ('val', False)):
+        for full in (False, True):
+            ds = FlyingThings3DSubset(train, None, root, full=full, device='cpu')
+            assert rel(ds) == list(gold['ft3d_%s_%s_samples' % (split, 'full' if full else 'quarter')])
+        ds = FlyingThings3DSubset(train, None, root, device='cpu')
+        for k in (0, len(ds) - 1):
+            a, b = ds.load(ds.samples[k])
+            assert np.array_equal(a, gold['ft3d_%s_load%d_pc1' % (split, k)]) and np.array_equal(b, gold['ft3d_%s_load%d_pc2' % (split, k)])
+        ds = FlyingThings3DSubset(train, pd(F.SEED), root, device='cpu')
+        assert os.path.relpath(ds.samples[1], real) == str(gold['ft3d_%s_item1_path' % split])
+        p1, p2, sf = ds[1]
+        for got, name in ((p1, 'pc1'), (p2, 'pc2'), (sf, 'sf')):
+            assert np.array_equal(got.numpy().T, gold['ft3d_%s_item1_%s' % (split, name)]), (split, name)
+    # KITTI: the 142-frame split of the reference's mapping file (here: a stand-in with the same empty lines)
+    mapping = os.path.join(root, 'mapping.txt')
+    with open(mapping, 'w') as f:
+        f.write(''.join('x\n' if m else '\n' for m in gold['kitti_mapped']))
+    assert int(gold['kitti_mapped'].sum()) == 142
+    for rg, tag in ((True, 'kitti_noground'), (False, 'kitti_all')):
+        ds = KITTI(None, root, remove_ground=rg, mapping_file=mapping, device='cpu')
+        assert rel(ds) == list(gold[tag + '_samples']) and len(ds) == 142
+        for k in (0, 77):
+            a, b = ds.load(ds.samples[k])
+            assert np.array_equal(a, gold['%s_load%d_pc1' % (tag, k)]) and np.array_equal(b, gold['%s_load%d_pc2' % (tag, k)])
+        p1, p2, sf = KITTI(pd(F.SEED), root, remove_ground=rg, mapping_file=mapping, device='cpu')[5]
+        for got, name in ((p1, 'pc1'), (p2, 'pc2'), (sf, 'sf')):
+            assert np.array_equal(got.numpy().T, gold['%s_item5_%s' % (tag, name)]), (tag, name)

@@ -13,16 +13,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_two_ranks(extra, timeout=420):
+def _run_two_ranks(extra, timeout=420, world=2):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', LOCAL_RANK='0',
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), LOCAL_RANK='0',
                HPL_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--no-cpu-baseline'] + extra
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--no-cpu-baseline'] + extra
     procs = [subprocess.Popen(cmd, cwd=ROOT, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                              text=True) for r in (1, 0)]
+                              text=True) for r in reversed(range(world))]
     outs = []
     try:
         for p in procs:
@@ -33,7 +33,7 @@ def _run_two_ranks(extra, timeout=420):
                 p.kill()                                   # the exact processes started above
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
-    return outs[1][0], outs[0][0]                           # stdout of rank 0, of rank 1
+    return outs[-1][0], outs[-2][0]                         # stdout of rank 0, of rank 1
 
 
 @pytest.mark.gpu
@@ -56,3 +56,19 @@ def test_two_ranks_training_step_on_one_gpu():
     assert not [ln for ln in out1.splitlines() if ln.startswith('{')]        # only rank 0 reports (gloo logs a line)
     d = json.loads([ln for ln in out0.strip().splitlines() if ln.startswith('{')][0])
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['workload'].lower().find('train') >= 0
+
+
+@pytest.mark.gpu
+def test_eight_ranks_dry_run_on_one_gpu():
+    """The rank count the driver launches (WORLD_SIZE = 8), all on the one GPU over gloo: eight host threads, eight lattice
+    pipelines, the seed partition and -- in training -- the bucket order of the gradient all-reduce at that size.  Small
+    clouds (N = 1024, 3 steps): this checks the code path, not the speed.  Nothing here runs over RCCL with > 1 rank."""
+    out0, out1 = _run_two_ranks(['--steps', '3', '--warmup', '1', '--points', '1024', '--no-train-probe'], timeout=600, world=8)
+    assert not [ln for ln in out1.splitlines() if ln.startswith('{')]
+    d = json.loads([ln for ln in out0.strip().splitlines() if ln.startswith('{')][0])
+    assert d['n_gpus'] == 8 and d['steps'] == 3 and d['value'] > 0
+    assert abs(d['value'] - 8 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert d['pipelined_output_check']['max_abs_diff'] == 0.0
+    out0, _ = _run_two_ranks(['--train', '--steps', '3', '--warmup', '1', '--points', '1024'], timeout=600, world=8)
+    d = json.loads([ln for ln in out0.strip().splitlines() if ln.startswith('{')][0])
+    assert d['n_gpus'] == 8 and d['value'] > 0 and 'train' in d['config']['workload'].lower()
