@@ -81,6 +81,14 @@ def _grads_close(got, want, norm_tol, entry_tol):
     within entry_tol of the tensor's largest entry."""
     assert set(got) == set(want)
     scale = max(float(np.linalg.norm(v)) for v in want.values())
+    worst_n = worst_e = (0.0, '')
+    for k in want:
+        a, b = got[k].astype(np.float64), np.asarray(want[k], np.float64)
+        nb = float(np.linalg.norm(b))
+        worst_n = max(worst_n, (abs(float(np.linalg.norm(a)) - nb) / max(nb, 1e-3 * scale), k))
+        worst_e = max(worst_e, ((float(np.abs(a - b).max()) - 1e-7 * scale) / float(np.abs(b).max()), k))
+    print('gradient parity: worst norm deviation %.3g (%s), worst entry deviation %.3g of the tensor maximum (%s)'
+          % (worst_n + worst_e))
     for k in want:
         a, b = got[k].astype(np.float64), np.asarray(want[k], np.float64)
         nb = float(np.linalg.norm(b))
@@ -146,9 +154,10 @@ def test_config4_train_step_n8192_vs_oracle():
     flow_o, loss_o, grads_o = TO.model_step(sd, pc1.T, pc2.T, sf.T, gd, dtype=torch.float64)
     assert abs(float(loss) - loss_o) < 1e-4
     assert np.abs(flow.detach()[0].cpu().numpy() - flow_o).max() < 2e-4 * max(1.0, float(np.abs(flow_o).max()))
-    # fp32 sums over up to 35 k vertices against the exact gradient: norms to 1e-3, entries to 1 % of the tensor's
-    # largest (LeakyReLU kinks deep in the chain move single vertices' contributions)
-    _grads_close(grads, grads_o, 1e-3, 1e-2)
+    # fp32 sums over up to 35 k vertices against the exact gradient.  Measured on this pair (both arithmetic paths):
+    # norms within 2e-5 .. 3e-5, every entry within 1e-4 of its tensor's largest -- the bars are 2e-4 / 5e-4 (round 2
+    # accepted 1e-3 / 1e-2 without having measured what the kernels need; the isolated kernels hold 1e-4 below)
+    _grads_close(grads, grads_o, 2e-4, 5e-4)
     # first Adam step from zero moments: every entry moves by lr * g / (|g| + eps) -- at most lr, towards -sign(g)
     for k, p in m.named_parameters():
         d = (p.detach() - before[k]).cpu().numpy()
@@ -226,3 +235,49 @@ def test_grad_allreduce_through_rccl_single_rank():
         assert parallel.max_over_ranks(1.5, device=DEV) == 1.5
     finally:
         dist.destroy_process_group()
+
+
+def test_weight_gradient_and_mirrored_data_gradient_at_bench_size_vs_float64():
+    """The two backward kernels of the dominant layer in isolation, at its real size and on its real table (bcn1_ blur:
+    H = 25 8xx vertices, 15 taps, C = 580, O = 1 024): the tap-list weight gradient (atomics over vertex slabs) and the
+    mirrored-gather data gradient against float64.  The whole-model test above accepts entries within 1 % of a tensor's
+    largest because LeakyReLU kinks upstream move single vertices; the kernels themselves hold 1e-4."""
+    import hplflownet_amd as H
+    from hplflownet_amd import ops
+    pc1, pc2, sf = synthetic_pair(8192, 0)
+    gen = H.GenerateDataUnsymmetric(model_args(False), device=DEV)
+    t1, t2, _, lat = gen([pc1, pc2, sf])
+    tb = lat.levels[0].blur[0]
+    nbr = tb.t
+    F, M = nbr.shape
+    C, O = 580, 1024
+    g = torch.Generator(device='cpu').manual_seed(7)
+    A = torch.randn(M, C, generator=g).to(DEV)
+    dY = (torch.randn(M, O, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))).to(DEV)
+    # ---- weight gradient dWt[f*C + c, o] = sum_m A[nbr[f, m], c] * dY[m, o]
+    dWt = ops.wgrad_raw(A, nbr, M, C, F, dY, O, taps=ops.tap_lists(nbr))
+    A64, dY64 = A.double(), dY.double()
+    worst = 0.0
+    for f in range(F):
+        idx = nbr[f].long()
+        rows = torch.where((idx >= 0)[:, None], A64[idx.clamp(min=0)], torch.zeros((), dtype=torch.float64, device=DEV))
+        ref = rows.t() @ dY64                                           # [C, O]
+        err = float((dWt[f * C:(f + 1) * C, :O].double() - ref).abs().max())
+        worst = max(worst, err / float(ref.abs().max()))
+    assert worst < 1e-4, worst
+    # ---- data gradient through the symmetric table: dA[v, c] = sum_f sum_o dY[nbr[F-f][v], o] * W[(f), c, o] (mirrored taps)
+    assert tb.symmetric
+    W = (torch.randn(O, C, F, 1, generator=g) / (C * F) ** 0.5).to(DEV)
+    A.requires_grad_(True)
+    y = ops.gconv(A, W, None, nbr, M, F, bwd_mode=tb.bwd_mode(M), row_perm=tb.perm, taps=tb.taps)
+    y.backward(dY)
+    dA = A.grad
+    ref = torch.zeros(M, C, dtype=torch.float64, device=DEV)
+    W64 = W.double()[:, :, :, 0]                                        # [O, C, F]
+    for f in range(F):
+        idx = nbr[f].long()
+        contrib = dY64 @ W64[:, :, f]                                   # [M, C]: what row m sends to its tap-f source
+        ok = idx >= 0
+        ref.index_add_(0, idx[ok], contrib[ok])
+    rel = float((dA.double() - ref).abs().max() / ref.abs().max())
+    assert rel < 1e-4, rel
