@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s 
 def split3_takes(M, N, C, F, scat=False):
     """Mirror of hpl_gc::launch_split3 (csrc/gconv3.hip): which launches run on the bf16 MFMA with split operands."""
     from hplflownet_amd import ops
-    return (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N % 128 == 0 and N >= 256 and F <= 15 and
+    return (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N >= 256 and F <= 15 and
             M >= int(os.environ.get('HPL_SPLIT3_MIN_ROWS', 8192)) and (F == 1 or M >= int(os.environ.get('HPL_SPLIT3_MIN_ROWS_STENCIL', 16384))))
 
 
@@ -95,7 +95,7 @@ class KernelTimers(object):
             # suffix: g = gathered (15-tap stencil, template F_LDS=15), d = dense (F_LDS=1); gconv3_* = the split-operand
             # kernel (bf16 MFMA); flops = the fp32 multiply-adds the launch stands for (2*M*F*C*N)
             if k.get('Wt3') is not None and split3_takes(M, N, C, F, k.get('scat') is not None):
-                return ('gconv3_128x%d_%s%s' % (256 if N % 256 == 0 else 128, 'g' if F > 1 else 'd', '' if M >= 16384 else '_mid'),
+                return ('gconv3_128x%d_%s%s' % (256 if -(-N // 256) * 256 * 100 <= -(-N // 128) * 128 * 108 else 128, 'g' if F > 1 else 'd', '' if M >= 16384 else '_mid'),
                         2.0 * M * F * C * N, 0.0)
             return ('gconv_%s_%s' % (gconv_class(M, N, F * C), 'g' if F > 1 else 'd'), 2.0 * M * F * C * N, 0.0)
 

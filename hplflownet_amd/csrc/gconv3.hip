@@ -512,7 +512,7 @@ static bool split3_enabled() {
 
 bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // qualifying launches: row-ordered stencil passes (or dense GEMMs) of wide layers, no scatter / split-K
-    if (!split3_enabled() || p.scat || p.C < 32 || p.N % 64 != 0 || p.K > 32768) return false;
+    if (!split3_enabled() || p.scat || p.C < 32 || p.K > 32768) return false;
     if (p.F > 15 || (p.w_bytes / (p.ldw * 4)) % 8 != 0) return false;
     static const int min_rows = getenv("HPL_SPLIT3_MIN_ROWS") ? atoi(getenv("HPL_SPLIT3_MIN_ROWS")) : 8192;
     // single-pass stencils of the mid-size levels (bcn3_: 9 433 rows x 15 taps x 388 channels) run faster on the fp32 kernel's
@@ -523,10 +523,11 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // 128 x 256 tiles (8 waves, one workgroup per CU) where N allows: 5-12 % faster than 128 x 128 on every wide launch of
     // the model (profiles/r03c_split3_kernel_ab.txt) although they leave fewer tiles per CU
     static const int wide = getenv("HPL_SPLIT3_BN") ? atoi(getenv("HPL_SPLIT3_BN")) : 256;
-    const bool bn256 = wide == 256 && p.N % 256 == 0;
+    // any N: columns past N are neither loaded (the image's row length bounds the loads) nor stored; the wider tile unless
+    // its padding costs more than it gains (N = 580, the data gradient of bcn1_: 3 x 256 = 768 vs 5 x 128 = 640 columns)
+    const bool bn256 = wide == 256 && cdiv(p.N, 256) * 256 * 100 <= cdiv(p.N, 128) * 128 * 108;
     const int BN = bn256 ? 256 : 128;
-    if (p.N % BN != 0) return false;
-    p.tiles_n = p.N / BN;
+    p.tiles_n = (int)cdiv(p.N, BN);
     if (p.tile_bm != BM3) p.tile_idx = nullptr;
     p.splits = 1; p.partial = nullptr;
     int grid = p.tiles_m * p.tiles_n;

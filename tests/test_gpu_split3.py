@@ -42,6 +42,7 @@ def _table(M, rows_a, F, density, seed):
     (8193, 100, 15, 256, 0.5, 'tiles'),       # C % 8 = 4: 8-blocks straddle taps; one row in the last tile
     (8300, 36, 3, 320, 0.9, None),            # N = 320: 2.5 column tiles of 128
     (8400, 64, 8, 512, 0.8, 'tiles'),         # N = 512: the 256-wide tile variant
+    (8300, 1024, 15, 580, 0.45, 'perm'),      # the data gradient of bcn1_ (mirrored gather): N = 580 = 4.5 tiles of 128
 ])
 def test_split3_matches_float64_like_the_fp32_kernel(M, C, F, N, density, order):
     from hplflownet_amd import ops
