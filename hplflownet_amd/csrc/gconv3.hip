@@ -58,7 +58,9 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned
 
 constexpr int BM3 = 128;
 
-template <int WGN, int F_LDS>
+// NB = stages of the weight-fragment ring (3 or 4); the gathered rows use NB - 1 register sets: with NB = 4 every load has one
+// more half-step to land (the end-of-half-step wait then leaves the loads of TWO half-steps in flight)
+template <int WGN, int F_LDS, int NB = 3>
 __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     constexpr int BM = BM3, BN = 64 * WGN, NT = 128 * WGN;
     constexpr int ROWS_PP = NT / 8;                 // rows covered by one gathered load instruction of the workgroup
@@ -66,13 +68,15 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     constexpr int HALF_PASSES = A_PASSES / 2;
     constexpr int A_STAGE = 3 * 2 * BM * 16;        // bytes: [plane][kb 0..1][row][8 bf16]
     constexpr int B_STAGE = 3 * 2 * BN * 16;        //        [plane][kb 0..1][n][8 bf16]
-    constexpr int STAGE = A_STAGE + B_STAGE;
+    constexpr int NA = 3;                            // stages of the gathered-row ring
+    constexpr int ASETS = NB - 1;                    // register sets of gathered rows in flight
+    constexpr int B_BASE = NA * A_STAGE;             // LDS: A ring | B ring | indices
     constexpr int B_CHUNKS_PER_WAVE = 3;            // 6 * WGN chunks of 1 KiB per half-step over 2 * WGN waves
     constexpr int KLIST = 1024;
     static_assert(A_PASSES == 2 || A_PASSES == 4, "two halves of a slice per thread");
     // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + (F_LDS * BM + BM + 8) * 4 + KLIST * 2];
-    int *Is = reinterpret_cast<int *>(smem + 3 * STAGE);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NA * A_STAGE + NB * B_STAGE + (F_LDS * BM + BM + 8) * 4 + KLIST * 2];
+    int *Is = reinterpret_cast<int *>(smem + NA * A_STAGE + NB * B_STAGE);
     int *Vs = Is + F_LDS * BM;
     int *tapmask_s = Vs + BM;                       // [0] taps of the tile, [1] slices needed, [2..5] taps of its 32-row blocks
     unsigned short *Ks = reinterpret_cast<unsigned short *>(tapmask_s + 8);
@@ -176,7 +180,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     // builtin form waited vmcnt(0) before every LDS store).  Completion is counted by hand: the end-of-half-step wait
     // leaves only that half-step's own loads in flight (loads complete in order), so a register set is complete one
     // half-step after its loads were issued; `pin` then orders the compiler's reads behind that wait.
-    float4_t ra[2][A_PASSES];
+    float4_t ra[ASETS][A_PASSES];
     int f0_u = 0, c0_u = 0, k_u = 0;
     // load_a_rows: (f, c) of this thread's float4 columns in slice kt and the LDS reads of their source rows;
     // load_a_issue: the loads.  Two calls, so that the LDS round trip of the indices sits behind the first MFMAs of a
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
         unsigned h0, m0_, l0, h1, m1, l1;
         split2(v.x, v.y, h0, m0_, l0);
         split2(v.z, v.w, h1, m1, l1);
-        unsigned char *base = smem + st * STAGE + (kb_w * BM + a_slot(row, kb_w)) * 16 + (t & 1) * 8;
+        unsigned char *base = smem + st * A_STAGE + (kb_w * BM + a_slot(row, kb_w)) * 16 + (t & 1) * 8;
         *reinterpret_cast<u32x2 *>(base) = u32x2{h0, h1};
         *reinterpret_cast<u32x2 *>(base + 2 * BM * 16) = u32x2{m0_, m1};
         *reinterpret_cast<u32x2 *>(base + 4 * BM * 16) = u32x2{l0, l1};
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
         for (int pl = 0; pl < 3; ++pl)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 rsrc_b[pl],
-                (__attribute__((address_space(3))) void *)(smem + st * STAGE + A_STAGE + ((pl * 2 + wm) * BN + wn * 64) * 16),
+                (__attribute__((address_space(3))) void *)(smem + B_BASE + st * B_STAGE + ((pl * 2 + wm) * BN + wn * 64) * 16),
                 16, (int)off, 0, 0, 0);
     };
 
@@ -272,7 +276,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
         const int row = wm * 64 + i * 32 + li;
         a_rofs[i] = (unsigned)((hi * BM + (row ^ ((((row >> 5) & 3) << 1) ^ (hi << 2)))) * 16);
     }
-    const unsigned b_rofs = (unsigned)(A_STAGE + (hi * BN + wn * 64 + li) * 16);
+    const unsigned b_rofs = (unsigned)(B_BASE + (hi * BN + wn * 64 + li) * 16);
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -283,29 +287,37 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
         __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0x0 << 8));
     };
 
+    using S2 = std::integral_constant<int, 2>;
     if (nsl > 0) {
-        // ---- fill: slice 0 -> stages 0, 1; slice 1 -> register set 1 (in flight)
-        const int kt0 = (int)(Ks[0] & 1023);
-        load_b(kt0, 0, 0);
-        load_b(kt0, 1, 1);
-        load_a(S0{}, kt0);
+        auto kt_at = [&](int sl) { return (int)(Ks[sl] & 1023); };
+        // ---- fill: weight fragments of the first NB - 1 half-steps, slice 0 -> A stages 0 and 1, slices 1 .. ASETS-1 -> their
+        // register sets; everything has landed before the first barrier (the first half-step stages slice 1 at once)
+#pragma unroll
+        for (int g = 0; g < NB - 1; ++g)
+            if (g / 2 < nsl) load_b(kt_at(g / 2), g & 1, g);
+        load_a(S0{}, kt_at(0));
         wait_vm_lgkm0(S0{});
         pin(S0{});
 #pragma unroll
         for (int j = 0; j < HALF_PASSES; ++j) { store_a(S0{}, 0, 0, j); store_a(S0{}, 1, 1, j); }
-        // (slice 1 is staged by the very first half-step, before any end-of-half-step wait has covered its loads:
-        // it has to land here)
-        if (nsl > 1) load_a(S1{}, (int)(Ks[1] & 1023));
+        if (nsl > 1) load_a(S1{}, kt_at(1));
+        if constexpr (ASETS == 3) { if (nsl > 2) load_a(S2{}, kt_at(2)); }
         wait_vm_lgkm0(S0{});
         asm volatile("s_barrier" ::: "memory");
 
-        int st = 0;                                  // stage of the half-step being multiplied
-        // One half-step: multiply stage st (slice entry e_cur); W: stage half h of slice kt_w (half-step g + 2, register
-        // set SETW) into stage (st + 2) % 3; L: issue the gathered loads of slice kt_l into set SETL.
-        auto halfstep = [&](int e_cur, auto w_tag, auto setw_tag, int kt_w, int h, auto l_tag, auto setl_tag, int kt_l) {
-            constexpr bool W = decltype(w_tag)::value, L = decltype(l_tag)::value;
-            const int st2 = st >= 1 ? st - 1 : 2;               // (st + 2) % 3
-            const unsigned char *sa = smem + st * STAGE;
+        int sta = 0, stb = 0;                        // stages of the half-step being multiplied (A ring, B ring)
+        // One half-step g = 2*s + h: multiply (A stage sta, B stage stb; slice entry e_cur);
+        //   B: LDS-direct loads of the weight fragments of half-step g + NB - 1 (slice kt_b, half hb) -> B stage (stb + NB - 1) % NB
+        //   W: split + store half h of slice s + 1 (register set SETW) -> A stage (sta + 2) % 3
+        //   L: gathered loads of slice s + ASETS (kt_l) -> register set SETL (h == 0 only)
+        // The wait at its end leaves the loads of the last NB - 2 half-steps in flight (`inflight`, counted by the caller).
+        auto halfstep = [&](int e_cur, int h, auto b_tag, int kt_b, int hb_b, auto w_tag, auto setw_tag, auto l_tag, auto setl_tag,
+                            int kt_l, auto inflight_tag) {
+            constexpr bool B = decltype(b_tag)::value, W = decltype(w_tag)::value, L = decltype(l_tag)::value;
+            const int sta2 = sta >= 1 ? sta - 1 : 2;                      // (sta + 2) % 3
+            const int stb2 = stb >= 1 ? stb - 1 : NB - 1;                  // (stb + NB - 1) % NB
+            const unsigned char *sa = smem + sta * A_STAGE;
+            const unsigned char *sb = smem + stb * B_STAGE;
             bool need[2];
             {
                 const int f_lo = (e_cur >> 10) & 15, two = (e_cur >> 14) & 1;
@@ -318,7 +330,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) { af[pl][i] = u32x4{(unsigned)st, 1u, 2u, 3u}; bf[pl][i] = u32x4{4u, 5u, (unsigned)h, 7u}; }
+                    for (int i = 0; i < 2; ++i) { af[pl][i] = u32x4{(unsigned)sta, 1u, 2u, 3u}; bf[pl][i] = u32x4{4u, 5u, (unsigned)h, 7u}; }
             } else
             if (need[0] || need[1]) {
 #pragma unroll
@@ -326,10 +338,10 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         af[pl][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i] + pl * 2 * BM * 16);
-                        bf[pl][i] = *reinterpret_cast<const u32x4 *>(sa + b_rofs + pl * 2 * BN * 16 + i * 32 * 16);
+                        bf[pl][i] = *reinterpret_cast<const u32x4 *>(sb + b_rofs + pl * 2 * BN * 16 + i * 32 * 16);
                     }
             }
-            if constexpr (W) load_b(kt_w, h, st2);
+            if constexpr (B) load_b(kt_b, hb_b, stb2);
             if constexpr (L) load_a_rows(kt_l);
             if constexpr (W) { if (h == 0) pin(setw_tag); }
             // products a_i * b_j with i + j <= 2 in the order their fragments arrive from LDS (planes are read hi, mid, lo: the
@@ -348,8 +360,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                                                                                 __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
                                                                                 acc[i][j], 0, 0, 0);
                     if (q == 0) {
-                        // the gathered loads of slice s+2 go out behind the first product: their row indices have come
-                        // back from LDS by now
+                        // the gathered loads go out behind the first product: their row indices have come back from LDS by now
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (L) load_a_issue(setl_tag);
                         __builtin_amdgcn_sched_barrier(0);
@@ -357,7 +368,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                 }
                 if constexpr (W) {
 #pragma unroll
-                    for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, st2, j);
+                    for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, sta2, j);
                     // (measured: the forced interleave gains 3 % on the 128-wide tile and loses 5 % on the 256-wide one,
                     // whose 8 waves cover each other's conversion blocks)
 #pragma unroll
@@ -381,45 +392,75 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                                                                                     acc[i][j], 0, 0, 0);
                     }
                     if constexpr (W) {
-                        if (HALF_PASSES == 2) store_a(setw_tag, h, st2, i);
-                        else if (i == 0) store_a(setw_tag, h, st2, 0);
+                        if (HALF_PASSES == 2) store_a(setw_tag, h, sta2, i);
+                        else if (i == 0) store_a(setw_tag, h, sta2, 0);
                     }
                 }
             }
-            // everything but this half-step's own loads has landed (the weight fragments staged one half-step ago are
-            // read in the next one; a register set is complete one half-step after its loads); own LDS stores are done
-            wait_vm_lgkm0(std::integral_constant<int, (W ? B_CHUNKS_PER_WAVE : 0) + (L ? A_PASSES : 0)>{});
+            // everything older than the last NB - 2 half-steps' loads has landed (loads complete in order); own LDS stores done
+            wait_vm_lgkm0(inflight_tag);
             asm volatile("s_barrier" ::: "memory");
-            st = st == 2 ? 0 : st + 1;
+            sta = sta == 2 ? 0 : sta + 1;
+            stb = stb == NB - 1 ? 0 : stb + 1;
         };
-        auto kt_at = [&](int s) { return (int)(Ks[s] & 1023); };
-        int s = 0;
-        // steady state: slices s, s+1 multiplied, s+1, s+2 staged, s+2, s+3 loaded -- no conditions inside
-        for (; s + 3 < nsl; s += 2) {
-            const int e0 = (int)Ks[s], e1 = (int)Ks[s + 1];
-            const int k1 = kt_at(s + 1), k2 = kt_at(s + 2), k3 = kt_at(s + 3);
-            halfstep(e0, T{}, S1{}, k1, 0, T{}, S0{}, k2);
-            halfstep(e0, T{}, S1{}, k1, 1, Fl{}, S0{}, 0);
-            halfstep(e1, T{}, S0{}, k2, 0, T{}, S1{}, k3);
-            halfstep(e1, T{}, S0{}, k2, 1, Fl{}, S1{}, 0);
+        // one slice (two half-steps) at position U of the unrolled steady loop: register sets by position
+        constexpr int NLB = B_CHUNKS_PER_WAVE, NLA = A_PASSES;
+        auto slice_steady = [&](int sl, auto u_tag) {
+            constexpr int U = decltype(u_tag)::value;
+            using SW = std::integral_constant<int, (U + 1) % ASETS>;
+            using SL = std::integral_constant<int, U % ASETS>;
+            const int e = (int)Ks[sl];
+            const int k1 = kt_at(sl + 1), kl = kt_at(sl + ASETS);
+            if constexpr (NB == 3) {
+                halfstep(e, 0, T{}, k1, 0, T{}, SW{}, T{}, SL{}, kl, std::integral_constant<int, NLB + NLA>{});
+                halfstep(e, 1, T{}, k1, 1, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB>{});
+            } else {
+                // weight fragments three half-steps ahead: (g + 3) = slice s+1 half 1, then slice s+2 half 0
+                halfstep(e, 0, T{}, k1, 1, T{}, SW{}, T{}, SL{}, kl, std::integral_constant<int, 2 * NLB + NLA>{});
+                halfstep(e, 1, T{}, kt_at(sl + 2), 0, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, 2 * NLB + NLA>{});
+            }
+        };
+        // the same with its loads / stagings switched off as the list runs out; waits drain everything (tail only)
+        auto slice_tail = [&](int sl, auto u_tag) {
+            constexpr int U = decltype(u_tag)::value;
+            using SW = std::integral_constant<int, (U + 1) % ASETS>;
+            using SL = std::integral_constant<int, U % ASETS>;
+            using Z = std::integral_constant<int, 0>;
+            const int e = (int)Ks[sl];
+            const bool w = sl + 1 < nsl, l = sl + ASETS < nsl;
+            const int k1 = w ? kt_at(sl + 1) : 0, kl = l ? kt_at(sl + ASETS) : 0;
+            // half 0
+            {
+                const int gb = 2 * sl + NB - 1;                 // half-step whose weight fragments are fetched now
+                const bool b = gb / 2 < nsl;
+                const int kb = b ? kt_at(gb / 2) : 0;
+                if (b && w && l) halfstep(e, 0, T{}, kb, gb & 1, T{}, SW{}, T{}, SL{}, kl, Z{});
+                else if (b && w) halfstep(e, 0, T{}, kb, gb & 1, T{}, SW{}, Fl{}, SL{}, 0, Z{});
+                else if (w) halfstep(e, 0, Fl{}, 0, 0, T{}, SW{}, Fl{}, SL{}, 0, Z{});
+                else if (b) halfstep(e, 0, T{}, kb, gb & 1, Fl{}, SW{}, Fl{}, SL{}, 0, Z{});
+                else halfstep(e, 0, Fl{}, 0, 0, Fl{}, SW{}, Fl{}, SL{}, 0, Z{});
+            }
+            {
+                const int gb = 2 * sl + 1 + NB - 1;
+                const bool b = gb / 2 < nsl;
+                const int kb = b ? kt_at(gb / 2) : 0;
+                if (b && w) halfstep(e, 1, T{}, kb, gb & 1, T{}, SW{}, Fl{}, SL{}, 0, Z{});
+                else if (w) halfstep(e, 1, Fl{}, 0, 0, T{}, SW{}, Fl{}, SL{}, 0, Z{});
+                else if (b) halfstep(e, 1, T{}, kb, gb & 1, Fl{}, SW{}, Fl{}, SL{}, 0, Z{});
+                else halfstep(e, 1, Fl{}, 0, 0, Fl{}, SW{}, Fl{}, SL{}, 0, Z{});
+            }
+        };
+        int sl = 0;
+        // steady state: every load / staging of the ASETS slices of an iteration exists -- no conditions inside
+        for (; sl + 2 * ASETS < nsl; sl += ASETS) {
+            slice_steady(sl, S0{});
+            slice_steady(sl + 1, S1{});
+            if constexpr (ASETS == 3) slice_steady(sl + 2, S2{});
         }
-        // tail: the same sequence with its loads / stagings switched off as the list runs out
-        for (; s < nsl; s += 2) {
-            const int e0 = (int)Ks[s];
-            const bool w1 = s + 1 < nsl, l2 = s + 2 < nsl, l3 = s + 3 < nsl;
-            const int k1 = w1 ? kt_at(s + 1) : 0, k2 = l2 ? kt_at(s + 2) : 0, k3 = l3 ? kt_at(s + 3) : 0;
-            if (w1 && l2) halfstep(e0, T{}, S1{}, k1, 0, T{}, S0{}, k2);
-            else if (w1) halfstep(e0, T{}, S1{}, k1, 0, Fl{}, S0{}, 0);
-            else halfstep(e0, Fl{}, S1{}, 0, 0, Fl{}, S0{}, 0);
-            if (w1) halfstep(e0, T{}, S1{}, k1, 1, Fl{}, S0{}, 0);
-            else halfstep(e0, Fl{}, S1{}, 0, 1, Fl{}, S0{}, 0);
-            if (!w1) break;
-            const int e1 = (int)Ks[s + 1];
-            if (l2 && l3) halfstep(e1, T{}, S0{}, k2, 0, T{}, S1{}, k3);
-            else if (l2) halfstep(e1, T{}, S0{}, k2, 0, Fl{}, S1{}, 0);
-            else halfstep(e1, Fl{}, S0{}, 0, 0, Fl{}, S1{}, 0);
-            if (l2) halfstep(e1, T{}, S0{}, k2, 1, Fl{}, S1{}, 0);
-            else halfstep(e1, Fl{}, S0{}, 0, 1, Fl{}, S1{}, 0);
+        for (; sl < nsl; sl += ASETS) {
+            slice_tail(sl, S0{});
+            if (sl + 1 < nsl) slice_tail(sl + 1, S1{});
+            if constexpr (ASETS == 3) { if (sl + 2 < nsl) slice_tail(sl + 2, S2{}); }
         }
     }
 
@@ -540,7 +581,13 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
         grid = p.tiles_n * p.col_share * p.col_rows;
     }
     // instances by the taps whose indices a tile stages in LDS: 1 (dense GEMMs), <= 8 (tap-group passes), <= 15
-    if (bn256) {
+    // HPL_SPLIT3_NB=3: the three-stage pipeline for the 256-wide tile too (A/B runs)
+    static const int nb = getenv("HPL_SPLIT3_NB") ? atoi(getenv("HPL_SPLIT3_NB")) : 4;
+    if (bn256 && nb == 4) {
+        if (p.F == 1) k_gconv3<4, 1, 4><<<grid, 512, 0, s>>>(p);
+        else if (p.F <= 8) k_gconv3<4, 8, 4><<<grid, 512, 0, s>>>(p);
+        else k_gconv3<4, 15, 4><<<grid, 512, 0, s>>>(p);
+    } else if (bn256) {
         if (p.F == 1) k_gconv3<4, 1><<<grid, 512, 0, s>>>(p);
         else if (p.F <= 8) k_gconv3<4, 8><<<grid, 512, 0, s>>>(p);
         else k_gconv3<4, 15><<<grid, 512, 0, s>>>(p);
