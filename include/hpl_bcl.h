@@ -213,9 +213,9 @@ typedef struct hpl_gconv_desc {
     int64_t wt3_plane_stride;   /* bytes between the planes */
 } hpl_gconv_desc;
 
-/* Row order for tap skipping: perm = the M vertices sorted by their F-bit tap-presence mask (bit f set iff
- * nbr[f*nbr_stride + m] >= 0; F <= 15), ties by ascending row id (a stable radix sort: the order is deterministic and
- * does not affect results).  scratch: hpl_tap_order_scratch_ints(M) int32, 8-byte aligned. */
+/* Row order for tap skipping: perm = the M vertices grouped by their F-bit tap-presence mask (bit f set iff
+ * nbr[f*nbr_stride + m] >= 0; F <= 15), the groups in Gray-code order of their masks (neighbouring groups differ in
+ * one tap), ties by ascending row id (a stable radix sort: the order is deterministic and does not affect results).  scratch: hpl_tap_order_scratch_ints(M) int32, 8-byte aligned. */
 int64_t hpl_tap_order_scratch_ints(int64_t M);
 int hpl_tap_order(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *perm,
                   int32_t *scratch, hplStream stream);

@@ -147,7 +147,12 @@ def test_tap_order_and_row_perm_leave_results_unchanged():
     p = perm.cpu().numpy()
     assert np.array_equal(np.sort(p), np.arange(H))                       # a permutation
     mask = ((nbr_np >= 0) * (1 << np.arange(F))[:, None]).sum(0)
-    assert np.all(np.diff(mask[p]) >= 0)                                  # grouped by ascending mask
+    rank = mask.copy()                                                   # position of a mask in the Gray-code sequence
+    for sh in (1, 2, 4, 8):
+        rank ^= rank >> sh
+    key = rank[p].astype(np.int64) * H + p                                # groups in Gray order, ascending row id inside: deterministic
+    assert np.all(np.diff(key) > 0)
+    assert np.array_equal(ops.tap_order(nbr).cpu().numpy(), p)           # same bits on every call
     g = torch.Generator().manual_seed(4)
     for C, O in ((68, 64), (132, 128)):
         A = torch.randn(H, C, generator=g).to(DEV)
