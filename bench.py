@@ -319,7 +319,7 @@ def source_stamp():
     and the switches that select kernels / tiles."""
     import hashlib
     h = hashlib.sha256()
-    for f in ('gconv.hip', 'gconv3.hip', 'gconv_common.h', 'executor.hip'):
+    for f in ('gconv.hip', 'gconv3.hip', 'gconv_common.h', 'executor.hip', 'row_order.hip'):
         h.update(open(os.path.join(ROOT, 'hplflownet_amd', 'csrc', f), 'rb').read())
     for k in ('HPL_MATH', 'HPL_SPLIT3_BN', 'HPL_TAP_GROUPS', 'HPL_TILE', 'HPL_WG3', 'HPL_PERSISTENT', 'HPL_SPLIT3_MIN_ROWS', 'HPL_SPLIT3_MIN_ROWS_STENCIL'):
         h.update(('%s=%s;' % (k, os.environ.get(k, ''))).encode())
