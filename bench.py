@@ -16,7 +16,7 @@ Printed JSON (rank 0, one line): the contract fields plus
                 timed loop (`measured` says which); `in_loop` keeps the timed-region figures;
   kernels       per-kernel-class breakdown (gather-GEMM classes by MFMA roofline, splat / slice by
                 HBM roofline with the algorithmic bytes of SURVEY.md §8 d2);
-  train         BASELINE config 4 on this GPU: 5 training steps on the same pairs (fwd + bwd + all-reduce + Adam);
+  train         BASELINE config 4 on this GPU: 8 training steps on the same pairs (fwd + bwd + all-reduce + Adam);
   cpu_baseline  the CPU oracle ("port": C lattice + the faster of the numpy/BLAS and torch-CPU layer ports) timed on this
                 host on a bounded sample of the same workload (rank 0, N=1 only); it doubles as the EPE3D parity check.
 """
@@ -266,7 +266,7 @@ def cpu_baseline(samples, sfm, state_dict, shallow=False):
     return d, flow0, bcl_oracle.epe3d(flow0, samples[0][2].T)
 
 
-def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=5, warmup=2):
+def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
     """BASELINE config 4 on this GPU, inside the default command: `steps` training steps (device lattice build + forward +
     EPE3D loss + backward + gradient all-reduce + Adam lr 1e-4, the reference's loop main.py:203-217) on the pairs of the
     inference run; a fresh model with the same weights.  -> dict for the JSON line."""
@@ -276,36 +276,47 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=5, warmup=2):
     model = getattr(H, arch)(targs)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(dev).train()
-    bank = ops.enable_weight_bank(True)
+    ops.enable_weight_bank(True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     reducer = parallel.GradAllReducer(model.parameters())
     loss = None
+    from hplflownet_amd.lattice import LatticePipeline
+    side = torch.cuda.Stream(device=dev, priority=-1)
+    main = torch.cuda.current_stream(dev)
+    # as `bench.py --train`: the lattice of the next pair is built on a second stream while this pair trains; exactly one
+    # build and one optimiser step per timed step
+    pipe = LatticePipeline(gen, lambda i: pairs[i % len(pairs)], 0, warmup + steps, depth=2, stream=side, for_training=True)
+    keep = []
 
-    def one(i):
+    def one():
+        (i, _), lat, ev = pipe.get()
+        main.wait_event(ev)
         p1, p2 = pairs[i % len(pairs)]
-        with torch.no_grad():
-            lat = gen.build(p1, p2)
-        if bank is not None:
-            bank.refresh()
-        flow = model(p1[None], p2[None], lat)
+        flow = model(p1[None], p2[None], lat)                     # (refreshes the weight bank: one batched re-layout per step)
         ls = torch.norm(flow - sfs[i % len(pairs)][None], p=2, dim=1).mean()
         opt.zero_grad(set_to_none=True)
         ls.backward()
         reducer()
         opt.step()
+        fin = torch.cuda.Event()
+        fin.record(main)
+        keep.append((lat, fin))                # side-stream allocations stay alive until the step that used them has RUN
+        while len(keep) > 2:
+            keep[0][1].synchronize()
+            keep.pop(0)
         return ls
     try:
-        for i in range(warmup):
-            one(i)
+        for _ in range(warmup):
+            one()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            loss = one(warmup + i)
+        for _ in range(steps):
+            loss = one()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / steps
-        out = {'ms_per_step': ms, 'steps': steps, 'warmup': warmup, 'pairs_per_s': 1e3 / ms, 'loss_last_step': float(loss),
-               'step': 'device lattice build + forward + EPE3D loss + backward + gradient all-reduce (world size 1 here) + Adam, '
-                       'one pair per GPU (BASELINE config 4), single stream'}
+        out = {'ms_per_step': ms, 'steps': steps, 'warmup': warmup, 'pairs_per_s': 1e3 / ms, 'loss_last_step': float(loss.detach()),
+               'step': 'device lattice build (second stream, next pair) + forward + EPE3D loss + backward + gradient all-reduce '
+                       '(world size 1 here) + Adam, one pair per GPU (BASELINE config 4)'}
     except Exception as e_:
         out = {'failed': str(e_)}
     ops.enable_weight_bank(False)
@@ -347,7 +358,7 @@ def main():
     ap.add_argument('--pool', type=int, default=4, help='distinct resident pairs cycled through the steps')
     ap.add_argument('--no-lattice', action='store_true', help='exclude the device lattice build from the step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-train-probe', action='store_true', help='skip the 5 training steps reported under "train"')
+    ap.add_argument('--no-train-probe', action='store_true', help='skip the training steps reported under "train"')
     ap.add_argument('--no-overlap', action='store_true',
                     help='build each lattice on the main stream instead of a second stream overlapping the previous forward')
     ap.add_argument('--streams', type=int, default=3,
