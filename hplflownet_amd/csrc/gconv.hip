@@ -1489,18 +1489,7 @@ extern "C" int hpl_weight_unlayout(const float *Wt, int64_t ldw, int R, int Q, i
 // atomics (L2 atomics on gfx950), dWt is zero-initialised by the caller.
 // ------------------------------------------------------------------------------------------
 namespace {
-struct WParams {
-    const float *A; int64_t lda; const int32_t *nbr; int64_t nbr_stride; int64_t reg_stride;
-    int64_t M; int C; int F; int K;
-    const float *dY; int64_t lddy; int N;
-    float *dWt; int64_t ldw;
-    int tiles_n; int64_t m_per_split;
-    // tap mode: k tiles are (tap f, 128-channel block) and the vertex loop of tap f runs over its
-    // compacted list of present (vertex, source row) pairs tap_m / tap_row[tap_ptr[f] .. tap_ptr[f+1])
-    // (hpl_tap_lists)
-    const int32_t *tap_m; const int32_t *tap_row; const int32_t *tap_ptr; int c_tiles;
-    float *dbias;        // optional: dbias[n] += sum_m dY[m, n] (by the k-tile-0 workgroups; not in tap mode)
-};
+using hpl_gc::WParams;
 
 template <int BN, bool VEC, bool TAP, int NT = 256, bool DEEP = false>
 __global__ void __launch_bounds__(NT) k_wgrad(const WParams p) {
@@ -1732,7 +1721,6 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
                                const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
                                const int32_t *tap_m, const int32_t *tap_row, const int32_t *tap_ptr,
                                int64_t tap_max, float *dbias, hplStream stream) {
-    (void)rows_a;
     HPL_REQUIRE(A && dY && dWt, "hpl_gconv_wgrad: null pointer");
     HPL_REQUIRE(M >= 0 && C > 0 && F > 0 && N > 0 && lda >= C && lddy >= N && ldw >= N,
                 "hpl_gconv_wgrad: bad sizes");
@@ -1742,6 +1730,7 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
     WParams p;
     p.A = A; p.lda = lda; p.nbr = nbr; p.nbr_stride = nbr_stride; p.reg_stride = reg_stride;
     p.M = M; p.C = C; p.F = F; p.K = F * C; p.dY = dY; p.lddy = lddy; p.N = N; p.dWt = dWt; p.ldw = ldw;
+    p.rows_a = rows_a;
     const bool vec = (C % 4 == 0) && (lda % 4 == 0) && (lddy % 4 == 0) && aligned16(A) && aligned16(dY);
     const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
     // Tap mode (per-tap lists of present vertices given, wide layers): k tiles are aligned to taps so
@@ -1758,6 +1747,15 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
     if (tap && dbias) colsum_accumulate(dY, lddy, M, N, dbias, to_stream(stream));
     const int tiles_k = tap ? F * c_tiles : (int)cdiv(p.K, 128);
     const int64_t m_len = tap ? tap_max : M;                 // longest vertex loop of a tile
+    if (vec) {
+        // wide layers: split operands on the bf16 MFMA (wgrad3.hip)
+        WParams q = p;
+        if (launch_wgrad3(q, tap, m_len, to_stream(stream))) {
+            if (!tap && dbias) colsum_accumulate(dY, lddy, M, N, dbias, to_stream(stream));
+            HPL_CHECK_LAUNCH("hpl_gconv_wgrad");
+            return HPL_OK;
+        }
+    }
     p.tiles_n = (int)cdiv(N, bn);
     const int tiles = tiles_k * p.tiles_n;
     // split the vertex axis so that ~4 workgroups per CU exist, each with >= 256 vertices

@@ -41,6 +41,16 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef HPL_ABLATE
 #define HPL_ABLATE 0
 #endif
+// (5 = 3 + 4: matrix instructions, barriers and waits only; 6 = 5 without the half-step barriers)
+constexpr bool ABL_LOADS = HPL_ABLATE == 1 || HPL_ABLATE == 3 || HPL_ABLATE >= 5;
+constexpr bool ABL_STORES = HPL_ABLATE == 2 || HPL_ABLATE == 3 || HPL_ABLATE >= 5;
+constexpr bool ABL_FRAGS = HPL_ABLATE >= 4;
+
+// Fragment prefetch across the half-step barrier: 0 = none (all 12 fragment reads behind the barrier), 1 = the hi plane of
+// the gathered rows, 2 = hi planes of rows and weights (the weight ring then needs its loads landed one half-step earlier)
+#ifndef HPL_PF
+#define HPL_PF 1
+#endif
 
 namespace {
 
@@ -60,8 +70,12 @@ constexpr int BM3 = 128;
 
 // NB = stages of the weight-fragment ring (3 or 4); the gathered rows use NB - 1 register sets: with NB = 4 every load has one
 // more half-step to land (the end-of-half-step wait then leaves the loads of TWO half-steps in flight)
+#define HPL_VGPR_ATTR
+#ifndef HPL_WAVES_EU
+#define HPL_WAVES_EU 2
+#endif
 template <int WGN, int F_LDS, int NB = 3>
-__global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
+__global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv3(const GParams p) {
     constexpr int BM = BM3, BN = 64 * WGN, NT = 128 * WGN;
     constexpr int ROWS_PP = NT / 8;                 // rows covered by one gathered load instruction of the workgroup
     constexpr int A_PASSES = BM / ROWS_PP;          // float4 per thread and slice: 4 (WGN = 2) or 2 (WGN = 4)
@@ -73,6 +87,8 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     constexpr int B_BASE = NA * A_STAGE;             // LDS: A ring | B ring | indices
     constexpr int B_CHUNKS_PER_WAVE = 3;            // 6 * WGN chunks of 1 KiB per half-step over 2 * WGN waves
     constexpr int KLIST = 1024;
+    // (a 3-stage weight ring has its next half-step still in flight; the 4-wave tile runs two workgroups per CU in 128 registers)
+    constexpr int PF = WGN != 4 ? 0 : NB == 4 ? HPL_PF : (HPL_PF ? 1 : 0);
     static_assert(A_PASSES == 2 || A_PASSES == 4, "two halves of a slice per thread");
     // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NA * A_STAGE + NB * B_STAGE + (F_LDS * BM + BM + 8) * 4 + KLIST * 2];
@@ -204,7 +220,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     };
     auto load_a_issue = [&](auto set_tag) {
         constexpr int SET = decltype(set_tag)::value;
-        if (HPL_ABLATE == 1 || HPL_ABLATE == 3) return;
+        if (ABL_LOADS) return;
         const int32x4_t rs = rsrc_a;                  // (asm operands inside a generic lambda must be its own locals)
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
@@ -235,7 +251,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     const int kb_w = (t >> 1) & 1;
     auto store_a = [&](auto set_tag, int h, int st, int j) {
         constexpr int SET = decltype(set_tag)::value;
-        if (HPL_ABLATE == 2 || HPL_ABLATE == 3) return;
+        if (ABL_STORES) return;
         const bool odd = (hb ^ h) != 0;
         const float4_t v = odd ? ra[SET][2 * j + 1] : ra[SET][2 * j];
         const int row = arow0 + (2 * j + (odd ? 1 : 0)) * ROWS_PP;
@@ -250,7 +266,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     // weight fragments of half h of slice kt straight into stage st: wave (wm, wn) fetches k-block wm of the half for
     // the 64 columns of column block wn, one 1 KiB LDS-direct load per plane
     auto load_b = [&](int kt, int h, int st) {
-        if (HPL_ABLATE == 1 || HPL_ABLATE == 3) return;
+        if (ABL_LOADS) return;
         const unsigned kbg = (unsigned)(kt * (BK / 8) + h * 2 + wm);
         const unsigned col = (unsigned)(n0 + wn * 64 + lane);
         const unsigned off = (col < (unsigned)p.ldw) ? kbg * ldw16 + col * 16u : OOB;
@@ -306,6 +322,21 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
         asm volatile("s_barrier" ::: "memory");
 
         int sta = 0, stb = 0;                        // stages of the half-step being multiplied (A ring, B ring)
+        // hi-plane fragments of the half-step about to be multiplied: read from LDS behind the last-but-one product of the
+        // half-step before (whose last product, mid x mid, does not use the hi registers), so that the first product of a
+        // half-step issues right behind the barrier instead of behind the 8 waves' 96 fragment reads
+        u32x4 ah[2], bh[2];
+        auto read_hi = [&](int st_a, int st_b) {
+            if (ABL_FRAGS || PF == 0) return;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const u32x4 *>(smem + st_a * A_STAGE + a_rofs[i]);
+                if (PF == 2) bh[i] = *reinterpret_cast<const u32x4 *>(smem + st_b * B_STAGE + b_rofs + i * 32 * 16);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { ah[i] = u32x4{0u, 1u, 2u, 3u}; bh[i] = u32x4{4u, 5u, 6u, 7u}; }
+        read_hi(0, 0);
         // One half-step g = 2*s + h: multiply (A stage sta, B stage stb; slice entry e_cur);
         //   B: LDS-direct loads of the weight fragments of half-step g + NB - 1 (slice kt_b, half hb) -> B stage (stb + NB - 1) % NB
         //   W: split + store half h of slice s + 1 (register set SETW) -> A stage (sta + 2) % 3
@@ -326,7 +357,7 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                     need[i] = !blockskip || (((bmask[i] >> f_lo) | (two ? (bmask[i] >> (f_lo + 1)) : 0)) & 1);
             }
             u32x4 af[3][2], bf[3][2];
-            if (HPL_ABLATE == 4) {
+            if (ABL_FRAGS) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -334,20 +365,30 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
             } else
             if (need[0] || need[1]) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 1; pl < 3; ++pl)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         af[pl][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i] + pl * 2 * BM * 16);
                         bf[pl][i] = *reinterpret_cast<const u32x4 *>(sb + b_rofs + pl * 2 * BN * 16 + i * 32 * 16);
                     }
             }
+            if (!ABL_FRAGS) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (PF >= 1) af[0][i] = ah[i];
+                    else if (need[0] || need[1]) af[0][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i]);
+                    if (PF == 2) bf[0][i] = bh[i];
+                    else if (need[0] || need[1]) bf[0][i] = *reinterpret_cast<const u32x4 *>(sb + b_rofs + i * 32 * 16);
+                }
+            }
+            const int sta1 = sta == 2 ? 0 : sta + 1, stb1 = stb == NB - 1 ? 0 : stb + 1;      // the next half-step's stages
             if constexpr (B) load_b(kt_b, hb_b, stb2);
             if constexpr (L) load_a_rows(kt_l);
             if constexpr (W) { if (h == 0) pin(setw_tag); }
             // products a_i * b_j with i + j <= 2 in the order their fragments arrive from LDS (planes are read hi, mid, lo: the
             // hi x hi product starts after the first four reads instead of after all twelve)
-            constexpr int PA[6] = {0, 0, 1, 1, 0, 2};
-            constexpr int PB[6] = {0, 1, 0, 1, 2, 0};
+            constexpr int PA[6] = {0, 0, 1, 0, 2, 1};
+            constexpr int PB[6] = {0, 1, 0, 2, 0, 1};
             if (need[0] && need[1]) {
                 // the common case, straight-line
 #pragma unroll
@@ -363,6 +404,11 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                         // the gathered loads go out behind the first product: their row indices have come back from LDS by now
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (L) load_a_issue(setl_tag);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (q == 4) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        read_hi(sta1, stb1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -396,10 +442,11 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
                         else if (i == 0) store_a(setw_tag, h, sta2, 0);
                     }
                 }
+                read_hi(sta1, stb1);
             }
             // everything older than the last NB - 2 half-steps' loads has landed (loads complete in order); own LDS stores done
             wait_vm_lgkm0(inflight_tag);
-            asm volatile("s_barrier" ::: "memory");
+            if (HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");
             sta = sta == 2 ? 0 : sta + 1;
             stb = stb == NB - 1 ? 0 : stb + 1;
         };
@@ -411,6 +458,12 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
             using SL = std::integral_constant<int, U % ASETS>;
             const int e = (int)Ks[sl];
             const int k1 = kt_at(sl + 1), kl = kt_at(sl + ASETS);
+            if constexpr (NB == 4 && PF == 2) {
+                // as below, but the weight fragments of half-step g + 1 have landed when half-step g starts (its hi plane is read
+                // during g): the end-of-half-step wait leaves only that half-step's own loads in flight
+                halfstep(e, 0, T{}, k1, 1, T{}, SW{}, T{}, SL{}, kl, std::integral_constant<int, NLB + NLA>{});
+                halfstep(e, 1, T{}, kt_at(sl + 2), 0, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB>{});
+            } else
             if constexpr (NB == 3) {
                 halfstep(e, 0, T{}, k1, 0, T{}, SW{}, T{}, SL{}, kl, std::integral_constant<int, NLB + NLA>{});
                 halfstep(e, 1, T{}, k1, 1, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB>{});
@@ -546,7 +599,7 @@ extern "C" int hpl_split3_info(int variant, int *blocks_per_cu, int *lds_bytes, 
 }
 
 // HPL_MATH=f32 keeps every launch on the fp32 MFMA (A/B runs, parity baselines)
-static bool split3_enabled() {
+bool hpl_gc::split3_enabled() {
     static const bool on = !(getenv("HPL_MATH") && std::string(getenv("HPL_MATH")) == "f32");
     return on;
 }

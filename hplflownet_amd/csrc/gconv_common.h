@@ -140,5 +140,25 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
 int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who);
 // the split-operand kernel (gconv3.hip): true if it took the launch
 bool launch_split3(GParams &p, hipStream_t s);
+// HPL_MATH=f32 keeps every launch on the fp32 MFMA (A/B runs, parity baselines)
+bool split3_enabled();
+
+// weight gradient (gconv.hip: fp32 MFMA; wgrad3.hip: split operands on the bf16 MFMA)
+struct WParams {
+    const float *A; int64_t lda; const int32_t *nbr; int64_t nbr_stride; int64_t reg_stride;
+    int64_t M; int C; int F; int K;
+    const float *dY; int64_t lddy; int N;
+    float *dWt; int64_t ldw;
+    int tiles_n; int64_t m_per_split;
+    // tap mode: k tiles are (tap f, 128-channel block) and the vertex loop of tap f runs over its
+    // compacted list of present (vertex, source row) pairs tap_m / tap_row[tap_ptr[f] .. tap_ptr[f+1])
+    // (hpl_tap_lists)
+    const int32_t *tap_m; const int32_t *tap_row; const int32_t *tap_ptr; int c_tiles;
+    float *dbias;        // optional: dbias[n] += sum_m dY[m, n] (by the k-tile-0 workgroups; not in tap mode)
+    int64_t rows_a;      // rows of A (0 = unknown)
+};
+// the split-operand weight gradient (wgrad3.hip): true if it took the launch.  tap: p.tap_* are set (k tiles = (tap, channel
+// block)); m_len = longest vertex loop of a tile
+bool launch_wgrad3(WParams &p, bool tap, int64_t m_len, hipStream_t s);
 
 }  // namespace hpl_gc

@@ -1,0 +1,90 @@
+"""The split-operand weight gradient (csrc/wgrad3.hip: both fp32 operands carried as three bf16 terms on the bf16 matrix
+pipe, MFMA fragments fetched with the LDS transpose read) against float64 and against the fp32-MFMA kernel
+(HPL_WGRAD3=0 in a second interpreter).  Pinned here: its error against the exact result is of the fp32 rounding class on
+tap-list stencils and dense 1x1 layers, including the tails (channels past the last 128-block, columns past the last
+256-block, slabs that end inside a 16-vertex stage, taps with empty lists) and the bias gradient of the same call."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _table(M, rows_a, F, density, seed, empty_tap=None):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    nbr = torch.randint(0, rows_a, (F, M), generator=g, dtype=torch.int32)
+    nbr[torch.rand((F, M), generator=g) > density] = -1
+    if empty_tap is not None:
+        nbr[empty_tap] = -1
+    return nbr.to(DEV)
+
+
+def _ref64(A, nbr, M, C, F, dY, N):
+    A64, dY64 = A.double(), dY.double()
+    out = torch.zeros(F * C, N, dtype=torch.float64, device=A.device)
+    for f in range(F):
+        if nbr is None:
+            rows = A64[:M, :C]
+        else:
+            idx = nbr[f].long()
+            rows = torch.where((idx >= 0)[:, None], A64[idx.clamp(min=0), :C], torch.zeros((), dtype=torch.float64, device=A.device))
+        out[f * C:(f + 1) * C] = rows.t() @ dY64[:M, :N]
+    return out
+
+
+CASES = [
+    # M, C, F, N, density, empty tap
+    (9000, 580, 15, 1024, 0.42, None),        # bcn1_: 5 channel blocks (the last one 68 wide), 4 column blocks
+    (8200, 324, 15, 512, 0.7, 3),             # bcn2_: 3 channel blocks (the last one 68 wide); one tap without neighbours
+    (8195, 128, 2, 260, 0.9, None),           # N = 260: 4 columns in the second block; slabs end inside a stage
+    (8192, 1024, 1, 1024, 1.0, None),         # dense 1x1 layer
+    (9001, 512, 1, 512, 1.0, None),           # dense, odd vertex count
+    (8192, 132, 1, 256, 1.0, None),           # dense, 4 channels in the second block
+]
+
+
+def _run_case(M, C, F, N, density, empty_tap):
+    from hplflownet_amd import ops
+    torch.manual_seed(M + C + N)
+    rows_a = M if F == 1 else M + 53
+    A = torch.randn(rows_a, C, device=DEV) * torch.exp(torch.randn(rows_a, 1, device=DEV))       # rows of very different scale
+    dY = torch.randn(M, N, device=DEV) * torch.exp(0.5 * torch.randn(M, 1, device=DEV))
+    nbr = _table(M, rows_a, F, density, 5, empty_tap) if F > 1 else None
+    taps = ops.tap_lists(nbr) if nbr is not None else None
+    got, gb = ops.wgrad_raw(A, nbr, M, C, F, dY, N, taps=taps, want_bias=True)
+    ref = _ref64(A, nbr, M, C, F, dY, N)
+    err = float((got[:F * C, :N].double() - ref).abs().max() / ref.abs().max())
+    # rows / columns of the image outside [F*C, N) stay zero (the kernel's tiles are cut there)
+    assert float(got[F * C:].abs().max() if got.shape[0] > F * C else 0.0) == 0.0
+    assert float(got[:, N:].abs().max() if got.shape[1] > N else 0.0) == 0.0
+    gb_err = float((gb.double() - dY.double().sum(0)).abs().max() / dY.double().sum(0).abs().max())
+    return err, gb_err
+
+
+@pytest.mark.parametrize('M,C,F,N,density,empty_tap', CASES)
+def test_wgrad3_matches_float64(M, C, F, N, density, empty_tap):
+    err, gb_err = _run_case(M, C, F, N, density, empty_tap)
+    assert err < 2e-5, err           # fp32 rounding class (the fp32-MFMA kernel: see the next test)
+    assert gb_err < 1e-5, gb_err
+
+
+def test_wgrad3_error_is_not_larger_than_the_fp32_kernels():
+    """The same cases through the fp32-MFMA kernel (HPL_WGRAD3=0, its own interpreter: the switch is read once): the
+    split-operand kernel's worst error against float64 stays within 1.5x of it."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import tests.test_gpu_wgrad3 as t\n"
+            "print('ERRS', ' '.join('%%.3e' %% t._run_case(*c)[0] for c in t.CASES))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    errs = {}
+    for mode in ('1', '0'):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, HPL_WGRAD3=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith('ERRS')][0]
+        errs[mode] = [float(x) for x in line.split()[1:]]
+    print('split operands:', errs['1'])
+    print('fp32 MFMA     :', errs['0'])
+    for a, b in zip(errs['1'], errs['0']):
+        assert a <= 1.5 * b + 1e-7, (errs['1'], errs['0'])
