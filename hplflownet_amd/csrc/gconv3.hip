@@ -42,14 +42,19 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define HPL_ABLATE 0
 #endif
 // (5 = 3 + 4: matrix instructions, barriers and waits only; 6 = 5 without the half-step barriers)
-constexpr bool ABL_LOADS = HPL_ABLATE == 1 || HPL_ABLATE == 3 || HPL_ABLATE >= 5;
-constexpr bool ABL_STORES = HPL_ABLATE == 2 || HPL_ABLATE == 3 || HPL_ABLATE >= 5;
-constexpr bool ABL_FRAGS = HPL_ABLATE >= 4;
+constexpr bool ABL_LOADS_A = HPL_ABLATE == 1 || HPL_ABLATE == 3 || HPL_ABLATE == 5 || HPL_ABLATE == 6 || HPL_ABLATE == 7;   // (7: gathered rows only)
+constexpr bool ABL_LOADS_B = HPL_ABLATE == 1 || HPL_ABLATE == 3 || HPL_ABLATE == 5 || HPL_ABLATE == 6 || HPL_ABLATE == 8;   // (8: weight fragments only)
+constexpr bool ABL_STORES = HPL_ABLATE == 2 || HPL_ABLATE == 3 || HPL_ABLATE == 5 || HPL_ABLATE == 6;
+constexpr bool ABL_FRAGS = HPL_ABLATE >= 4 && HPL_ABLATE <= 6;
 
 // Fragment prefetch across the half-step barrier: 0 = none (all 12 fragment reads behind the barrier), 1 = the hi plane of
 // the gathered rows, 2 = hi planes of rows and weights (the weight ring then needs its loads landed one half-step earlier)
 #ifndef HPL_PF
 #define HPL_PF 1
+#endif
+// Ping-pong schedule of the 8-wave tile (see k_gconv3): 1 = on
+#ifndef HPL_PP
+#define HPL_PP 1
 #endif
 
 namespace {
@@ -88,7 +93,14 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
     constexpr int B_CHUNKS_PER_WAVE = 3;            // 6 * WGN chunks of 1 KiB per half-step over 2 * WGN waves
     constexpr int KLIST = 1024;
     // (a 3-stage weight ring has its next half-step still in flight; the 4-wave tile runs two workgroups per CU in 128 registers)
-    constexpr int PF = WGN != 4 ? 0 : NB == 4 ? HPL_PF : (HPL_PF ? 1 : 0);
+    // PP: the two wave rows of the 8-wave tile (waves 0-3 / 4-7: one wave of each on every SIMD) run half a half-step apart.
+    // A half-step is a MEMORY phase (fragment reads of this half-step, the LDS-direct weight loads, the gathered loads, split +
+    // store of the rows staged for later) and a COMPUTE phase (its 24 MFMAs), each closed by a workgroup barrier; the second
+    // wave row enters one barrier late, so while one wave of a SIMD issues its MFMAs the other does its LDS / memory work
+    // under them -- without the offset both waves of a SIMD reach the same phase together and the matrix pipe idles through
+    // every memory phase (ablation: 39 % of the dense launch's time is not MFMA issue).
+    constexpr bool PP = WGN == 4 && HPL_PP != 0;
+    constexpr int PF = PP ? 0 : WGN != 4 ? 0 : NB == 4 ? HPL_PF : (HPL_PF ? 1 : 0);
     static_assert(A_PASSES == 2 || A_PASSES == 4, "two halves of a slice per thread");
     // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NA * A_STAGE + NB * B_STAGE + (F_LDS * BM + BM + 8) * 4 + KLIST * 2];
@@ -220,7 +232,7 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
     };
     auto load_a_issue = [&](auto set_tag) {
         constexpr int SET = decltype(set_tag)::value;
-        if (ABL_LOADS) return;
+        if (ABL_LOADS_A) return;
         const int32x4_t rs = rsrc_a;                  // (asm operands inside a generic lambda must be its own locals)
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
@@ -266,7 +278,7 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
     // weight fragments of half h of slice kt straight into stage st: wave (wm, wn) fetches k-block wm of the half for
     // the 64 columns of column block wn, one 1 KiB LDS-direct load per plane
     auto load_b = [&](int kt, int h, int st) {
-        if (ABL_LOADS) return;
+        if (ABL_LOADS_B) return;
         const unsigned kbg = (unsigned)(kt * (BK / 8) + h * 2 + wm);
         const unsigned col = (unsigned)(n0 + wn * 64 + lane);
         const unsigned off = (col < (unsigned)p.ldw) ? kbg * ldw16 + col * 16u : OOB;
@@ -321,6 +333,8 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
         wait_vm_lgkm0(S0{});
         asm volatile("s_barrier" ::: "memory");
 
+        if (PP && wm == 1 && HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");      // the second wave row runs one phase behind
+
         int sta = 0, stb = 0;                        // stages of the half-step being multiplied (A ring, B ring)
         // hi-plane fragments of the half-step about to be multiplied: read from LDS behind the last-but-one product of the
         // half-step before (whose last product, mid x mid, does not use the hi registers), so that the first product of a
@@ -357,6 +371,61 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
                     need[i] = !blockskip || (((bmask[i] >> f_lo) | (two ? (bmask[i] >> (f_lo + 1)) : 0)) & 1);
             }
             u32x4 af[3][2], bf[3][2];
+            constexpr int PA[6] = {0, 0, 1, 0, 2, 1};
+            constexpr int PB[6] = {0, 1, 0, 2, 0, 1};
+            if constexpr (PP) {
+                // ---- memory phase.  Its critical path is what the other wave row's 24 MFMAs have to cover: the weight loads and
+                // the index reads of the gathered rows go out first, the fragment reads behind them (LDS answers in order: the
+                // gathered loads then wait for the two index reads only, not for the twelve fragment reads), and the split of the
+                // staged rows runs while the fragments are on their way.
+                if constexpr (B) load_b(kt_b, hb_b, stb2);
+                if constexpr (L) load_a_rows(kt_l);
+                if (ABL_FRAGS) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) { af[pl][i] = u32x4{(unsigned)sta, 1u, 2u, 3u}; bf[pl][i] = u32x4{4u, 5u, (unsigned)h, 7u}; }
+                } else
+                if (need[0] || need[1]) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            af[pl][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i] + pl * 2 * BM * 16);
+                            bf[pl][i] = *reinterpret_cast<const u32x4 *>(sb + b_rofs + pl * 2 * BN * 16 + i * 32 * 16);
+                        }
+                }
+                if constexpr (W) { if (h == 0) pin(setw_tag); }
+                if constexpr (L) load_a_issue(setl_tag);
+                if constexpr (W) {
+#pragma unroll
+                    for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, sta2, j);
+                }
+                wait_vm_lgkm0(inflight_tag);
+                __builtin_amdgcn_sched_barrier(0);
+                if (HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- compute phase: one block of 12 MFMAs per 32-row block that has a tap of this slice.  (One code path per
+                // block, accumulators updated in place: an if / else over "both blocks" / "one block" made hipcc keep two homes
+                // for the 64 accumulator registers and copy them -- 32 v_mov_b64 behind a drained matrix pipe -- every half-step.)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if (need[i]) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
+                                                                                    __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
+                                                                                    acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                sta = sta == 2 ? 0 : sta + 1;
+                stb = stb == NB - 1 ? 0 : stb + 1;
+                return;
+            }
             if (ABL_FRAGS) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
@@ -387,48 +456,14 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
             if constexpr (W) { if (h == 0) pin(setw_tag); }
             // products a_i * b_j with i + j <= 2 in the order their fragments arrive from LDS (planes are read hi, mid, lo: the
             // hi x hi product starts after the first four reads instead of after all twelve)
-            constexpr int PA[6] = {0, 0, 1, 0, 2, 1};
-            constexpr int PB[6] = {0, 1, 0, 2, 0, 1};
-            if (need[0] && need[1]) {
-                // the common case, straight-line
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
-                                                                                __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
-                                                                                acc[i][j], 0, 0, 0);
-                    if (q == 0) {
-                        // the gathered loads go out behind the first product: their row indices have come back from LDS by now
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (L) load_a_issue(setl_tag);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (q == 4) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        read_hi(sta1, stb1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                if constexpr (W) {
-#pragma unroll
-                    for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, sta2, j);
-                    // (measured: the forced interleave gains 3 % on the 128-wide tile and loses 5 % on the 256-wide one,
-                    // whose 8 waves cover each other's conversion blocks)
-#pragma unroll
-                    for (int k = 0; k < (WGN == 2 ? 24 : 0); ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // 3 VALU
-                        if (k % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
-                    }
-                }
-            } else {
+            // one block of 12 MFMAs per 32-row block that has a tap of this slice, accumulators updated in place (a separate
+            // straight-line path for "both blocks" made hipcc keep two homes for the 64 accumulator registers and copy them
+            // behind a drained matrix pipe every half-step)
+            {
                 if constexpr (L) load_a_issue(setl_tag);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    if (need[i]) {                      // wave-uniform: the 32-row block has a tap of this slice
+                    if (need[i]) {                      // wave-uniform
 #pragma unroll
                         for (int q = 0; q < 6; ++q)
 #pragma unroll
@@ -515,6 +550,7 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
             if (sl + 1 < nsl) slice_tail(sl + 1, S1{});
             if constexpr (ASETS == 3) { if (sl + 2 < nsl) slice_tail(sl + 2, S2{}); }
         }
+        if (PP && wm == 0 && HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");      // (the second wave row's last compute phase)
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

@@ -598,7 +598,9 @@ class GConvFn(torch.autograd.Function):
             rows = A.shape[0]
             if bwd_mode == 'dense':
                 WtT = _train_relayout(weight, O, C, 1, Ctot * F, F, 1, base=c0 * F)
-                gA_c = gconv_raw(g, None, M, O, 1, WtT, C)
+                # wide 1x1 layers: the data gradient is a dense GEMM of the same class as their forward (split operands)
+                W3 = split3_of(WtT) if (SPLIT3 and C >= SPLIT3_MIN_N and O >= SPLIT3_MIN_C) else None
+                gA_c = gconv_raw(g, None, M, O, 1, WtT, C, Wt3=W3)
             elif bwd_mode == 'mirror':
                 if rows != M:
                     raise _lib.HplError('mirror backward needs a table over the same vertex set')

@@ -23,7 +23,7 @@ for v in range(4):
     print('variant %d: %d workgroups/CU, %d B LDS, %d registers' % (v, a.value, b.value, c.value))
 reps = int(os.environ.get('REPS', '5'))
 rounds = int(os.environ.get('ROUNDS', '3'))
-cases = [('bcn1_ g0', 0, 580, 1024, 0, 8), ('bcn1_ g1', 0, 580, 1024, 8, 15), ('bcn2_ g0', 1, 324, 512, 0, 8),
+cases = [('dgrad bcn1_ g0', 0, 1024, 580, 0, 8), ('dgrad bcn2_ g0', 1, 512, 324, 0, 8), ('bcn1_ g0', 0, 580, 1024, 0, 8), ('bcn1_ g1', 0, 580, 1024, 8, 15), ('bcn2_ g0', 1, 324, 512, 0, 8),
          ('bcn2_ g1', 1, 324, 512, 8, 15), ('dense 25841x4640x1024', -1, 4640, 1024, 0, 1), ('1x1 25841x1024x1024', -1, 1024, 1024, 0, 1)]
 
 
