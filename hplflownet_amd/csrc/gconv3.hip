@@ -52,9 +52,18 @@ constexpr bool ABL_FRAGS = HPL_ABLATE >= 4 && HPL_ABLATE <= 6;
 #ifndef HPL_PF
 #define HPL_PF 1
 #endif
+// Diagnostic build (-DHPL_PHASE_PROBE=1, tools/gpu/phase_probe.sh): every wave of the sampled workgroups accumulates the shader
+// cycles it spends in the four parts of a ping-pong half-step (memory phase up to its wait, first barrier, compute phase,
+// second barrier) into clock_probe[8 + 4 * wave row ..]; timing only (the stamps are scalar memory reads: they add waits)
+#ifndef HPL_PHASE_PROBE
+#define HPL_PHASE_PROBE 0
+#endif
 // Ping-pong schedule of the 8-wave tile (see k_gconv3): 1 = on
 #ifndef HPL_PP
 #define HPL_PP 1
+#endif
+#ifndef HPL_PRIO
+#define HPL_PRIO 1
 #endif
 
 namespace {
@@ -177,7 +186,7 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
             const unsigned long long bal = __ballot(need);
             if (need) {
                 int e = kt;
-                if (blockskip) e |= (f_lo << 10) | (((kt * BK + BK - 1) / p.C > f_lo && f_lo + 1 < p.F) ? (1 << 14) : 0);
+                e |= (f_lo << 10) | ((blockskip && (kt * BK + BK - 1) / p.C > f_lo && f_lo + 1 < p.F) ? (1 << 14) : 0);
                 Ks[count + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
             }
             count += __popcll(bal);
@@ -209,22 +218,21 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
     // leaves only that half-step's own loads in flight (loads complete in order), so a register set is complete one
     // half-step after its loads were issued; `pin` then orders the compiler's reads behind that wait.
     float4_t ra[ASETS][A_PASSES];
-    int f0_u = 0, c0_u = 0, k_u = 0;
     // load_a_rows: (f, c) of this thread's float4 columns in slice kt and the LDS reads of their source rows;
     // load_a_issue: the loads.  Two calls, so that the LDS round trip of the indices sits behind the first MFMAs of a
     // half-step instead of in front of them.
     int a_rows[A_PASSES], a_c[A_PASSES];
     bool a_ok[A_PASSES];
-    auto load_a_rows = [&](int kt) {
-        const int k0 = kt * BK;
-        c0_u += k0 - k_u;
-        k_u = k0;
-        while (c0_u >= p.C) { c0_u -= p.C; ++f0_u; }
+    auto load_a_rows = [&](int e) {               // e: slice-list entry (slice | first tap << 10): no running state, no loop
+        const int f0 = (e >> 10) & 15;
+        const int c0 = (e & 1023) * BK - f0 * p.C;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             const int kqi = kq ^ ((i & 1) << 2);      // (full 128-byte lines per instruction; every thread ends up with
-            int c = c0_u + kqi * 4, f = f0_u;         //  HALF_PASSES float4 of each half-slice)
-            if (c >= p.C) { c -= p.C; ++f; }
+            int c = c0 + kqi * 4, f = f0;             //  HALF_PASSES float4 of each half-slice)
+            const bool wrap = c >= p.C;                // (C >= 32: a slice touches at most two taps)
+            c = wrap ? c - p.C : c;
+            f += wrap ? 1 : 0;
             a_rows[i] = Is[min(f, F_LDS - 1) * BM + arow0 + i * ROWS_PP];
             a_c[i] = c;
             a_ok[i] = f < p.F;
@@ -237,12 +245,15 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             float4_t &dst = ra[SET][i];
-            const unsigned o = (a_ok[i] && a_rows[i] >= 0) ? (unsigned)a_rows[i] * lda_b + (unsigned)a_c[i] * 4u : OOB;
+            // (offset computed unconditionally: a conditional multiply becomes a branch, and the compute phase has to stay one block)
+            unsigned val = (unsigned)(HPL_ABLATE == 9 ? (a_rows[i] & 63) : a_rows[i]) * lda_b + (unsigned)a_c[i] * 4u;      // (9: every gathered load hits 64 cached rows)
+            asm("" : "+v"(val));
+            const unsigned o = (a_ok[i] && a_rows[i] >= 0) ? val : OOB;
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(o), "s"(rs) : "memory");
         }
     };
-    auto load_a = [&](auto set_tag, int kt) {
-        load_a_rows(kt);
+    auto load_a = [&](auto set_tag, int e) {
+        load_a_rows(e);
         load_a_issue(set_tag);
     };
     auto pin = [&](auto set_tag) {
@@ -268,8 +279,17 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
         const float4_t v = odd ? ra[SET][2 * j + 1] : ra[SET][2 * j];
         const int row = arow0 + (2 * j + (odd ? 1 : 0)) * ROWS_PP;
         unsigned h0, m0_, l0, h1, m1, l1;
-        split2(v.x, v.y, h0, m0_, l0);
-        split2(v.z, v.w, h1, m1, l1);
+        if (HPL_ABLATE == 12) {          // (12: the LDS stores without the conversion)
+            h0 = __builtin_bit_cast(unsigned, v.x); h1 = __builtin_bit_cast(unsigned, v.y); m0_ = __builtin_bit_cast(unsigned, v.z);
+            m1 = __builtin_bit_cast(unsigned, v.w); l0 = h0; l1 = h1;
+        } else {
+            split2(v.x, v.y, h0, m0_, l0);
+            split2(v.z, v.w, h1, m1, l1);
+        }
+        if (HPL_ABLATE == 11) {          // (11: the conversion without the LDS stores)
+            asm volatile("" :: "v"(h0), "v"(h1), "v"(m0_), "v"(m1), "v"(l0), "v"(l1));
+            return;
+        }
         unsigned char *base = smem + st * A_STAGE + (kb_w * BM + a_slot(row, kb_w)) * 16 + (t & 1) * 8;
         *reinterpret_cast<u32x2 *>(base) = u32x2{h0, h1};
         *reinterpret_cast<u32x2 *>(base + 2 * BM * 16) = u32x2{m0_, m1};
@@ -279,9 +299,11 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
     // the 64 columns of column block wn, one 1 KiB LDS-direct load per plane
     auto load_b = [&](int kt, int h, int st) {
         if (ABL_LOADS_B) return;
-        const unsigned kbg = (unsigned)(kt * (BK / 8) + h * 2 + wm);
+        const unsigned kbg = HPL_ABLATE == 10 ? (unsigned)(h * 2 + wm) : (unsigned)(kt * (BK / 8) + h * 2 + wm);      // (10: every weight load hits the first slice)
         const unsigned col = (unsigned)(n0 + wn * 64 + lane);
-        const unsigned off = (col < (unsigned)p.ldw) ? kbg * ldw16 + col * 16u : OOB;
+        unsigned val = kbg * ldw16 + col * 16u;
+        asm("" : "+v"(val));
+        const unsigned off = (col < (unsigned)p.ldw) ? val : OOB;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -317,25 +339,40 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
 
     using S2 = std::integral_constant<int, 2>;
     if (nsl > 0) {
-        auto kt_at = [&](int sl) { return (int)(Ks[sl] & 1023); };
+        // the slice list is read through a register: lane l holds entry ks_cb + l (refilled every 32 slices), an entry is a
+        // v_readlane -- no LDS round trip (+ the in-order wait behind whatever else is queued there) in front of the half-steps
+        int ks_cb = 0;
+        int ks_reg = (int)Ks[min(lane, KLIST - 1)];
+        auto ks_at = [&](int x) { return __builtin_amdgcn_readlane(ks_reg, x - ks_cb); };
+        auto ks_advance = [&](int sl) {
+            if (sl - ks_cb >= 32) { ks_cb += 32; ks_reg = (int)Ks[min(ks_cb + lane, KLIST - 1)]; }
+        };
+        auto kt_at = [&](int sl) { return ks_at(sl) & 1023; };
         // ---- fill: weight fragments of the first NB - 1 half-steps, slice 0 -> A stages 0 and 1, slices 1 .. ASETS-1 -> their
         // register sets; everything has landed before the first barrier (the first half-step stages slice 1 at once)
 #pragma unroll
         for (int g = 0; g < NB - 1; ++g)
             if (g / 2 < nsl) load_b(kt_at(g / 2), g & 1, g);
-        load_a(S0{}, kt_at(0));
+        load_a(S0{}, ks_at(0));
         wait_vm_lgkm0(S0{});
         pin(S0{});
 #pragma unroll
         for (int j = 0; j < HALF_PASSES; ++j) { store_a(S0{}, 0, 0, j); store_a(S0{}, 1, 1, j); }
-        if (nsl > 1) load_a(S1{}, kt_at(1));
-        if constexpr (ASETS == 3) { if (nsl > 2) load_a(S2{}, kt_at(2)); }
+        if (nsl > 1) load_a(S1{}, ks_at(1));
+        if constexpr (ASETS == 3) { if (nsl > 2) load_a(S2{}, ks_at(2)); }
         wait_vm_lgkm0(S0{});
         asm volatile("s_barrier" ::: "memory");
 
         if (PP && wm == 1 && HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");      // the second wave row runs one phase behind
 
         int sta = 0, stb = 0;                        // stages of the half-step being multiplied (A ring, B ring)
+        unsigned long long ph_t = HPL_PHASE_PROBE ? __builtin_readcyclecounter() : 0ull, ph_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+        auto stamp = [&](int k) {
+            if (!HPL_PHASE_PROBE) return;
+            const unsigned long long now = __builtin_readcyclecounter();
+            ph_acc[k] += now - ph_t;
+            ph_t = now;
+        };
         // hi-plane fragments of the half-step about to be multiplied: read from LDS behind the last-but-one product of the
         // half-step before (whose last product, mid x mid, does not use the hi registers), so that the first product of a
         // half-step issues right behind the barrier instead of behind the 8 waves' 96 fragment reads
@@ -374,19 +411,13 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
             constexpr int PA[6] = {0, 0, 1, 0, 2, 1};
             constexpr int PB[6] = {0, 1, 0, 2, 0, 1};
             if constexpr (PP) {
-                // ---- memory phase.  Its critical path is what the other wave row's 24 MFMAs have to cover: the weight loads and
-                // the index reads of the gathered rows go out first, the fragment reads behind them (LDS answers in order: the
-                // gathered loads then wait for the two index reads only, not for the twelve fragment reads), and the split of the
-                // staged rows runs while the fragments are on their way.
-                if constexpr (B) load_b(kt_b, hb_b, stb2);
-                if constexpr (L) load_a_rows(kt_l);
+                // ---- memory phase: only what has to wait for the barrier -- the twelve fragment reads of this half-step.
                 if (ABL_FRAGS) {
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                         for (int i = 0; i < 2; ++i) { af[pl][i] = u32x4{(unsigned)sta, 1u, 2u, 3u}; bf[pl][i] = u32x4{4u, 5u, (unsigned)h, 7u}; }
-                } else
-                if (need[0] || need[1]) {
+                } else {
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -395,32 +426,64 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
                             bf[pl][i] = *reinterpret_cast<const u32x4 *>(sb + b_rofs + pl * 2 * BN * 16 + i * 32 * 16);
                         }
                 }
-                if constexpr (W) { if (h == 0) pin(setw_tag); }
-                if constexpr (L) load_a_issue(setl_tag);
-                if constexpr (W) {
-#pragma unroll
-                    for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, sta2, j);
-                }
+                // the loads of the compute phase before last have landed (in flight: the last compute phase's); fragments here,
+                // the LDS stores of the last compute phase done
+                const unsigned long long ph_issue = HPL_PHASE_PROBE ? __builtin_readcyclecounter() : 0ull;      // (read behind the wait)
                 wait_vm_lgkm0(inflight_tag);
+                if (HPL_PHASE_PROBE) ph_acc[4] += ph_issue - ph_t;
                 __builtin_amdgcn_sched_barrier(0);
+                stamp(0);
                 if (HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");
+                stamp(1);
                 __builtin_amdgcn_sched_barrier(0);
-                // ---- compute phase: one block of 12 MFMAs per 32-row block that has a tap of this slice.  (One code path per
-                // block, accumulators updated in place: an if / else over "both blocks" / "one block" made hipcc keep two homes
-                // for the 64 accumulator registers and copy them -- 32 v_mov_b64 behind a drained matrix pipe -- every half-step.)
+                // ---- compute phase: the 24 MFMAs of the wave's 64 rows and, in their shadow, everything else of the half-step
+                // that does not depend on the barrier: the weight loads three half-steps ahead, index reads + gathered loads,
+                // split + store of the rows staged for the half-step after next.  One basic block, so that hipcc can interleave
+                // (the 32-row block skip of the non-ping-pong path would cut it into four); a wave whose 64 rows have no tap in the
+                // slice skips the MFMAs altogether.
+                // Measured (cycles per half-step and wave, -DHPL_PHASE_PROBE=1): memory phase 515, compute phase 1160 -- every
+                // interleaved group (weight loads / gathered loads / split + store) adds 110-140 to the 840 of the bare MFMAs;
+                // with all three in the memory phase instead 1190 / 790, with the gathered loads and the stores there 617 us
+                // against 597 us for the launch: this split is the fastest of the four tried.
+                auto others = [&]() {
+                    if constexpr (B) load_b(kt_b, hb_b, stb2);
+                    // (the row indices of these loads were read from LDS one slice ago -- no wait on the LDS queue, which the
+                    // other wave row's fragment reads fill, in front of the MFMAs behind this point; kt_l = the NEXT slice's entry)
+                    if constexpr (L) { load_a_issue(setl_tag); load_a_rows(kt_l); }
+                    if constexpr (W) {
+                        if (h == 0) pin(setw_tag);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    if (need[i]) {
+                        for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, sta2, j);
+                    }
+                };
+                if (need[0] || need[1]) {
 #pragma unroll
-                        for (int q = 0; q < 6; ++q)
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
                                                                                     __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
                                                                                     acc[i][j], 0, 0, 0);
+                    others();
+                    // interleave: one MFMA, then a few of the other instructions
+#pragma unroll
+                    for (int k = 0; k < 24; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);      // 4 VALU / SALU
+                        if (k % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+                        if (k % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+                        if (k % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
                     }
+                } else {
+                    others();
+                }
+                // (own LDS stores: waited for at the end of the next memory phase, one barrier before anybody reads them)
                 __builtin_amdgcn_sched_barrier(0);
+                stamp(2);
                 if (HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");
+                stamp(3);
                 __builtin_amdgcn_sched_barrier(0);
                 sta = sta == 2 ? 0 : sta + 1;
                 stb = stb == NB - 1 ? 0 : stb + 1;
@@ -491,8 +554,14 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
             constexpr int U = decltype(u_tag)::value;
             using SW = std::integral_constant<int, (U + 1) % ASETS>;
             using SL = std::integral_constant<int, U % ASETS>;
-            const int e = (int)Ks[sl];
-            const int k1 = kt_at(sl + 1), kl = kt_at(sl + ASETS);
+            ks_advance(sl);
+            const int e = ks_at(sl);
+            const int k1 = kt_at(sl + 1), kl = ks_at(sl + ASETS);
+            if constexpr (PP) {
+                // (the wait closes the memory phase: in flight = what the compute phase of the half-step before issued)
+                halfstep(e, 0, T{}, k1, 1, T{}, SW{}, T{}, SL{}, ks_at(sl + ASETS + 1), std::integral_constant<int, NLB>{});
+                halfstep(e, 1, T{}, kt_at(sl + 2), 0, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB + NLA>{});
+            } else
             if constexpr (NB == 4 && PF == 2) {
                 // as below, but the weight fragments of half-step g + 1 have landed when half-step g starts (its hi plane is read
                 // during g): the end-of-half-step wait leaves only that half-step's own loads in flight
@@ -514,9 +583,10 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
             using SW = std::integral_constant<int, (U + 1) % ASETS>;
             using SL = std::integral_constant<int, U % ASETS>;
             using Z = std::integral_constant<int, 0>;
-            const int e = (int)Ks[sl];
+            ks_advance(sl);
+            const int e = ks_at(sl);
             const bool w = sl + 1 < nsl, l = sl + ASETS < nsl;
-            const int k1 = w ? kt_at(sl + 1) : 0, kl = l ? kt_at(sl + ASETS) : 0;
+            const int k1 = w ? kt_at(sl + 1) : 0, kl = l ? ks_at(sl + ASETS + (PP ? 1 : 0)) : 0;      // (ping-pong: indices one slice ahead)
             // half 0
             {
                 const int gb = 2 * sl + NB - 1;                 // half-step whose weight fragments are fetched now
@@ -538,6 +608,7 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
                 else halfstep(e, 1, Fl{}, 0, 0, Fl{}, SW{}, Fl{}, SL{}, 0, Z{});
             }
         };
+        if constexpr (PP) load_a_rows(ks_at(ASETS));      // (row indices of the first gathered loads issued inside the loop)
         int sl = 0;
         // steady state: every load / staging of the ASETS slices of an iteration exists -- no conditions inside
         for (; sl + 2 * ASETS < nsl; sl += ASETS) {
@@ -551,6 +622,12 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
             if constexpr (ASETS == 3) { if (sl + 2 < nsl) slice_tail(sl + 2, S2{}); }
         }
         if (PP && wm == 0 && HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");      // (the second wave row's last compute phase)
+        if (HPL_PHASE_PROBE && p.clock_probe && (blockIdx.x & 15) == 0 && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 8 + 4 * wm + k, ph_acc[k]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 20 + wm, ph_acc[4]);
+            if (wn == 0) atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 16 + wm, (unsigned long long)(2 * nsl));
+        }
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -655,7 +732,8 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     static const int wide = getenv("HPL_SPLIT3_BN") ? atoi(getenv("HPL_SPLIT3_BN")) : 256;
     // any N: columns past N are neither loaded (the image's row length bounds the loads) nor stored; the wider tile unless
     // its padding costs more than it gains (N = 580, the data gradient of bcn1_: 3 x 256 = 768 vs 5 x 128 = 640 columns)
-    const bool bn256 = wide == 256 && cdiv(p.N, 256) * 256 * 100 <= cdiv(p.N, 128) * 128 * 108;
+    static const int pct = getenv("HPL_SPLIT3_BN256_PCT") ? atoi(getenv("HPL_SPLIT3_BN256_PCT")) : 108;
+    const bool bn256 = wide == 256 && cdiv(p.N, 256) * 256 * 100 <= cdiv(p.N, 128) * 128 * pct;
     const int BN = bn256 ? 256 : 128;
     p.tiles_n = (int)cdiv(p.N, BN);
     if (p.tile_bm != BM3) p.tile_idx = nullptr;
