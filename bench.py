@@ -365,18 +365,18 @@ def main():
                     help='HIP streams the forwards of consecutive pairs alternate over (pairs in flight)')
     ap.add_argument('--lattice-streams', type=int, default=1,
                     help='HIP streams the lattice builds of consecutive pairs alternate over')
-    ap.add_argument('--lattice-depth', type=int, default=2,
+    ap.add_argument('--lattice-depth', type=int, default=3,
                     help='pairs whose lattice is under construction at once on the lattice stream (1: block on every '
-                         'read-back of vertex counts)')
+                         'read-back of vertex counts; measured at N=8192: 2: 272, 3: 292, 4: 292 pairs/s)')
     ap.add_argument('--arch', default='HPLFlowNet', choices=['HPLFlowNet', 'HPLFlowNetShallow'],
                     help='HPLFlowNetShallow + --points 4096 is BASELINE config 2')
     ap.add_argument('--data', default='frustum', choices=['frustum', 'surface'],
                     help='frustum: the uniform FT3D-like frustum of SURVEY.md 8(d1) (the headline workload); surface: points on '
                          'smooth patches, the dense extreme (few lattice vertices per point)')
-    ap.add_argument('--lattice-thread', action='store_true',
-                    help='run the native lattice builds on a producer host thread (the builder spends its time in C calls made '
-                         'with the GIL released): pays when the step is host-bound (shallow model N=4096: 896 -> 942 pairs/s), '
-                         'costs ~2 %% of jitter when it is GPU-bound (the default workload)')
+    ap.add_argument('--no-lattice-thread', dest='lattice_thread', action='store_false',
+                    help='drive the native lattice builds from the main thread instead of a producer host thread (the builder '
+                         'spends its time in C calls made with the GIL released, so the forward enqueue overlaps it on a second '
+                         'core: N=8192 292 -> 299 pairs/s, shallow model N=4096 896 -> 942)')
     ap.add_argument('--python-lattice', action='store_true',
                     help='drive the lattice build stage by stage from Python instead of the native builder')
     ap.add_argument('--python-forward', action='store_true',

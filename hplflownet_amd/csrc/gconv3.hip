@@ -84,12 +84,8 @@ constexpr int BM3 = 128;
 
 // NB = stages of the weight-fragment ring (3 or 4); the gathered rows use NB - 1 register sets: with NB = 4 every load has one
 // more half-step to land (the end-of-half-step wait then leaves the loads of TWO half-steps in flight)
-#define HPL_VGPR_ATTR
-#ifndef HPL_WAVES_EU
-#define HPL_WAVES_EU 2
-#endif
-template <int WGN, int F_LDS, int NB = 3>
-__global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv3(const GParams p) {
+template <int WGN, int F_LDS, int NB>
+__device__ __forceinline__ void gconv3_body(const GParams &p) {
     constexpr int BM = BM3, BN = 64 * WGN, NT = 128 * WGN;
     constexpr int ROWS_PP = NT / 8;                 // rows covered by one gathered load instruction of the workgroup
     constexpr int A_PASSES = BM / ROWS_PP;          // float4 per thread and slice: 4 (WGN = 2) or 2 (WGN = 4)
@@ -658,6 +654,27 @@ __global__ void __launch_bounds__(128 * WGN, HPL_WAVES_EU) HPL_VGPR_ATTR k_gconv
     }
 }
 
+template <int WGN, int F_LDS, int NB = 3>
+__global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
+    gconv3_body<WGN, F_LDS, NB>(p);
+}
+
+// The 8-wave tile with a register budget (-DHPL_VGPR_CAP=n, in units of 2 registers on gfx950's unified file; 0 = none): the
+// tile keeps its CU to itself (142 KB of LDS), and with 2 x 240 of a SIMD's 512 registers taken no wave of another stream's
+// small kernels (lattice build, narrow layers) fits beside it; a cap leaves room for them.
+#ifndef HPL_VGPR_CAP
+#define HPL_VGPR_CAP 0
+#endif
+#if HPL_VGPR_CAP > 0
+#define HPL_VGPR_ATTR __attribute__((amdgpu_num_vgpr(HPL_VGPR_CAP)))
+#else
+#define HPL_VGPR_ATTR
+#endif
+template <int F_LDS, int NB>
+__global__ void __launch_bounds__(512, 2) HPL_VGPR_ATTR k_gconv3w(const GParams p) {
+    gconv3_body<4, F_LDS, NB>(p);
+}
+
 // Wt [k_rows][ldw] fp32 -> three bf16 planes [k_rows/8][ldw][8]
 __global__ void __launch_bounds__(256) k_weight_split3(const float *__restrict__ Wt, int64_t k_rows, int64_t ldw,
                                                         unsigned char *__restrict__ dst, int64_t plane_stride) {
@@ -699,7 +716,7 @@ extern "C" int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, v
 extern "C" int hpl_split3_info(int variant, int *blocks_per_cu, int *lds_bytes, int *vgprs) {
     HPL_REQUIRE(variant >= 0 && variant < 4 && blocks_per_cu && lds_bytes && vgprs, "hpl_split3_info: bad arguments");
     const void *fn = variant == 0 ? (const void *)k_gconv3<2, 8> : variant == 1 ? (const void *)k_gconv3<2, 15>
-                   : variant == 2 ? (const void *)k_gconv3<4, 8> : (const void *)k_gconv3<4, 15>;
+                   : variant == 2 ? (const void *)k_gconv3w<8, 4> : (const void *)k_gconv3w<15, 4>;
     hipFuncAttributes at;
     if (hipFuncGetAttributes(&at, fn) != hipSuccess) { set_error("hpl_split3_info: hipFuncGetAttributes failed"); return HPL_EHIP; }
     int nb = 0;
@@ -751,9 +768,9 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // HPL_SPLIT3_NB=3: the three-stage pipeline for the 256-wide tile too (A/B runs)
     static const int nb = getenv("HPL_SPLIT3_NB") ? atoi(getenv("HPL_SPLIT3_NB")) : 4;
     if (bn256 && nb == 4) {
-        if (p.F == 1) k_gconv3<4, 1, 4><<<grid, 512, 0, s>>>(p);
-        else if (p.F <= 8) k_gconv3<4, 8, 4><<<grid, 512, 0, s>>>(p);
-        else k_gconv3<4, 15, 4><<<grid, 512, 0, s>>>(p);
+        if (p.F == 1) k_gconv3w<1, 4><<<grid, 512, 0, s>>>(p);
+        else if (p.F <= 8) k_gconv3w<8, 4><<<grid, 512, 0, s>>>(p);
+        else k_gconv3w<15, 4><<<grid, 512, 0, s>>>(p);
     } else if (bn256) {
         if (p.F == 1) k_gconv3<4, 1><<<grid, 512, 0, s>>>(p);
         else if (p.F <= 8) k_gconv3<4, 8><<<grid, 512, 0, s>>>(p);
