@@ -45,8 +45,16 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s 
 def split3_takes(M, N, C, F, scat=False):
     """Mirror of hpl_gc::launch_split3 (csrc/gconv3.hip): which launches run on the bf16 MFMA with split operands."""
     from hplflownet_amd import ops
-    return (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N >= 256 and F <= 15 and
-            M >= int(os.environ.get('HPL_SPLIT3_MIN_ROWS', 8192)) and (F == 1 or M >= int(os.environ.get('HPL_SPLIT3_MIN_ROWS_STENCIL', 16384))))
+    if not (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N >= 256 and F <= 15 and
+            M >= int(os.environ.get('HPL_SPLIT3_MIN_ROWS', 8192))):
+        return False
+    if F == 1 or M >= int(os.environ.get('HPL_SPLIT3_MIN_ROWS_STENCIL', 16384)):
+        return True
+    # mid-size stencils: only split over K into one round of workgroups (partial tiles in the split-K workspace)
+    tiles = -(-M // 128) * -(-N // 256)
+    splitk = min(8, 256 // max(1, tiles), (-(-F * C // 32)) // 16)
+    return (os.environ.get('HPL_SPLIT3_MID_SPLITK', '1') != '0' and splitk >= 2 and N % 256 == 0 and M * N <= (8 << 20) and
+            splitk * M * N * 4 <= (256 << 20))
 
 
 def gconv_class(M, N, K=1 << 20):

@@ -1215,6 +1215,10 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     hipStream_t s = to_stream(stream);
     const bool avec = (p.C % 4 == 0) && (p.lda % 4 == 0) && aligned16(p.A);
     if (avec && p.Wt3 && launch_split3(p, s)) {
+        if (p.splits > 1) {       // (mid-size stencils: partial tiles over slice ranges, summed in fixed order)
+            const int g = (int)imin(cdiv(p.M * p.N, 256), 2048);
+            k_gconv_finish<<<g, 256, 0, s>>>(p);
+        }
         HPL_CHECK_LAUNCH("hpl_gconv_forward");
         return HPL_OK;
     }

@@ -190,7 +190,36 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         if (lane == 0) tapmask_s[1] = count;
     }
     __syncthreads();
-    const int nsl = __builtin_amdgcn_readfirstlane(tapmask_s[1]);
+    int nsl = __builtin_amdgcn_readfirstlane(tapmask_s[1]);
+    // split-K (mid-size stencils: too few tiles for 256 CUs): this workgroup takes the list entries whose slice INDEX lies in
+    // its share of [0, nk) -- cut points that do not depend on the tile, so a row's partial sums cover the same k ranges
+    // wherever the row order puts it -- and writes a partial tile (k_gconv_finish adds the shares in split order)
+    int split = 0;
+    if (p.splits > 1) {
+        const int ngrid = p.row_perm && p.col_share > 0 ? p.tiles_n * p.col_share * p.col_rows : p.tiles_m * p.tiles_n;
+        split = blockIdx.x / ngrid;
+        const int k_lo = (int)((int64_t)nk * split / p.splits), k_hi = (int)((int64_t)nk * (split + 1) / p.splits);
+        auto below = [&](int kt) {           // list entries with slice index < kt (the list is ascending)
+            int a = 0, b = nsl;
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if ((int)(Ks[mid] & 1023) < kt) a = mid + 1; else b = mid;
+            }
+            return a;
+        };
+        const int lo = below(k_lo), hi_e = below(k_hi);
+        __syncthreads();
+        if (lo > 0) {                        // compact this share to the front of the list
+            unsigned short mine[KLIST / (128 * WGN) + 1];
+            int cnt = 0;
+            for (int i = t; i < hi_e - lo; i += NT) mine[cnt++] = Ks[lo + i];
+            __syncthreads();
+            cnt = 0;
+            for (int i = t; i < hi_e - lo; i += NT) Ks[i] = mine[cnt++];
+        }
+        __syncthreads();
+        nsl = hi_e - lo;
+    }
 
     // ---- staging state
     constexpr unsigned OOB = 0x80000000u;
@@ -639,6 +668,10 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = Vs[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
                 if (m < 0) continue;
+                if (p.splits > 1) {          // raw partial sum
+                    p.partial[((int64_t)split * p.M + m) * p.N + n] = acc[i][j][r];
+                    continue;
+                }
                 float v = acc[i][j][r] + bsv;
                 if (p.res) v += p.res[(int64_t)((int)m < res_mod ? (int)m : (int)m % res_mod) * p.ldres + n];
                 if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
@@ -742,7 +775,17 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // single-pass stencils of the mid-size levels (bcn3_: 9 433 rows x 15 taps x 388 channels) run faster on the fp32 kernel's
     // 64 x 64 tiles (0.31 vs 0.45 ms: a 128-row tile unites many more tap masks); dense launches gain from 8 192 rows on
     static const int min_rows_stencil = getenv("HPL_SPLIT3_MIN_ROWS_STENCIL") ? atoi(getenv("HPL_SPLIT3_MIN_ROWS_STENCIL")) : 16384;
-    if (p.M < min_rows || p.N < 256 || (p.F > 1 && p.M < min_rows_stencil)) return false;
+    if (p.M < min_rows || p.N < 256) return false;
+    // Stencils below min_rows_stencil rows leave most CUs without a tile (bcn3_: 74 row tiles x 1 column tile): they run here
+    // only split over K into enough workgroups for one round (partial tiles in the caller's workspace), else on the fp32 kernel
+    int splitk = 1;
+    if (p.F > 1 && p.M < min_rows_stencil) {
+        static const int mid_split = getenv("HPL_SPLIT3_MID_SPLITK") ? atoi(getenv("HPL_SPLIT3_MID_SPLITK")) : 1;
+        const int64_t tiles = cdiv(p.M, BM3) * cdiv(p.N, 256);
+        const int nk_all = (p.K + BK - 1) / BK;
+        splitk = (int)imin(imin(8, 256 / imax(1, tiles)), nk_all / 16);
+        if (!mid_split || !p.ws || p.scat || splitk < 2 || (int64_t)splitk * p.M * p.N * 4 > p.ws_bytes || p.N % 256 > 0) return false;
+    }
     p.tiles_m = (int)cdiv(p.M, BM3);
     // 128 x 256 tiles (8 waves, one workgroup per CU) where N allows: 5-12 % faster than 128 x 128 on every wide launch of
     // the model (profiles/r03c_split3_kernel_ab.txt) although they leave fewer tiles per CU
@@ -750,13 +793,17 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // any N: columns past N are neither loaded (the image's row length bounds the loads) nor stored; the wider tile unless
     // its padding costs more than it gains (N = 580, the data gradient of bcn1_: 3 x 256 = 768 vs 5 x 128 = 640 columns)
     static const int pct = getenv("HPL_SPLIT3_BN256_PCT") ? atoi(getenv("HPL_SPLIT3_BN256_PCT")) : 108;
-    const bool bn256 = wide == 256 && cdiv(p.N, 256) * 256 * 100 <= cdiv(p.N, 128) * 128 * pct;
+    const bool bn256 = splitk > 1 || (wide == 256 && cdiv(p.N, 256) * 256 * 100 <= cdiv(p.N, 128) * 128 * pct);
     const int BN = bn256 ? 256 : 128;
     p.tiles_n = (int)cdiv(p.N, BN);
     if (p.tile_bm != BM3) p.tile_idx = nullptr;
     p.splits = 1; p.partial = nullptr;
     int grid = p.tiles_m * p.tiles_n;
     p.col_share = 0; p.col_rows = 0;
+    if (splitk > 1) {
+        p.splits = splitk;
+        p.partial = p.ws;
+    }
     if (p.row_perm) {
         int g = 8, b = p.tiles_n % 8;
         while (b) { const int tt = g % b; g = b; b = tt; }
@@ -764,6 +811,7 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
         p.col_rows = p.col_share == 1 ? p.tiles_m : (int)cdiv(p.tiles_m, COL_CHUNK * p.col_share) * COL_CHUNK;
         grid = p.tiles_n * p.col_share * p.col_rows;
     }
+    grid *= p.splits;
     // instances by the taps whose indices a tile stages in LDS: 1 (dense GEMMs), <= 8 (tap-group passes), <= 15
     // HPL_SPLIT3_NB=3: the three-stage pipeline for the 256-wide tile too (A/B runs)
     static const int nb = getenv("HPL_SPLIT3_NB") ? atoi(getenv("HPL_SPLIT3_NB")) : 4;

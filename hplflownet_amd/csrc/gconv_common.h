@@ -79,7 +79,7 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
         // robin.  The grid is rounded up to 8 equal runs; surplus workgroups get tm = -1.
         const int gsz = p.tiles_n * p.col_share * p.col_rows;
         const int q2 = gsz / 8, r2 = gsz % 8;
-        const int b2 = blockIdx.x;
+        const int b2 = p.splits > 1 ? blockIdx.x % gsz : blockIdx.x;      // (split-K: grid = splits x gsz)
         const int x2 = b2 % 8, pos2 = b2 / 8;
         const int id2 = (x2 < r2 ? x2 * (q2 + 1) : r2 * (q2 + 1) + (x2 - r2) * q2) + pos2;
         const int v = id2 / p.col_rows, pos = id2 - v * p.col_rows;
