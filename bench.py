@@ -636,18 +636,22 @@ def main():
         # frac = achieved / peak = busy cycles / (1024 SIMDs x duration x 2.4 GHz), a fraction <= 1 whatever the operand type.
         # The executed work per launch is MEASURED (rocprofv3 --pmc on this command, tools/pmc_mfma.py -> profiles/r03_mfma_pmc.json,
         # used only when its stamp matches the kernel sources and tile configuration of this run) or, failing that, mirrored
-        # on the host from the lattice tables (the kernel skips the MFMAs of a 32-row block for slices whose taps it lacks).
+        # on the host from the lattice tables (the kernel skips the MFMAs of a wave's 64 rows -- 32 in the fp32 kernel -- for slices whose taps they lack).
         wide = [(0, 580, 1024), (1, 324, 512)] if full else []
         alg_gf = [2.0 * lat0.levels[L].H[0] * 15 * c * o / 1e9 for L, c, o in wide]          # fp32 multiply-adds, GF
         ex = kernels.get(dominant, {})
         roofline = {'bound': 'mfma', 'unit': 'TFLOP/s', 'traffic': None}
         if full:
+            # rows whose MFMAs are skipped together: a wave's 64 rows in the ping-pong split-operand kernel (its compute phase
+            # is one block of 24 MFMAs), a 32-row MFMA block in the fp32 kernel
+            skip_rows = 64 if split3 else 32
+
             def executed(tbl, c):
                 groups = tbl.groups()
                 if not groups:
-                    return needed_slice_fraction(tbl, c, BM=32)
+                    return needed_slice_fraction(tbl, c, BM=skip_rows)
                 F = tbl.t.shape[0]
-                return sum((f1 - f0) * needed_slice_fraction(types.SimpleNamespace(t=tbl.t[f0:f1], perm=p), c, BM=32)
+                return sum((f1 - f0) * needed_slice_fraction(types.SimpleNamespace(t=tbl.t[f0:f1], perm=p), c, BM=skip_rows)
                            for f0, f1, p in groups) / F
             fr = [executed(lat0.levels[L].blur[0], c) for L, c, _ in wide]
             mirror_gf = sum(a_ * b_ for a_, b_ in zip(alg_gf, fr))                              # executed fp32-equivalent GF / step
@@ -656,7 +660,7 @@ def main():
             peak = MFMA_BF16_PEAK_TFLOPS if split3 else MFMA_F32_PEAK_TFLOPS
             products = SPLIT3_PRODUCTS if split3 else 1
             busy_per_launch = mirror_gf * 1e9 * products / flop_per_busy / lps                # matrix-pipe cycles per launch
-            src = 'host mirror of the kernel\'s slice lists and 32-row block masks (bench.needed_slice_fraction)'
+            src = 'host mirror of the kernel\'s slice lists and %d-row block masks (bench.needed_slice_fraction)' % skip_rows
             stamp = source_stamp()
             pmc_path = os.path.join(ROOT, 'profiles', 'r03_mfma_pmc.json')
             pmc_note = None
@@ -696,8 +700,9 @@ def main():
             roofline.update(peak=peak, launches_per_step=lps, gflop_per_step_algorithmic_f32=sum(alg_gf),
                             executed_fraction=mirror_gf / sum(alg_gf), executed_source=src,
                             mfma_busy_cycles_per_launch=busy_per_launch,
-                            kernel=('k_gconv3<4,8> (gather-GEMM on the bf16 MFMA, every fp32 operand split exactly into 3 bf16 terms, 6 partial '
-                                    'products accumulated in fp32; 128x256 tiles, 8 waves; blur convs of bcn1_/bcn2_ as two tap-group passes each)')
+                            kernel=('k_gconv3w<8,4> (gather-GEMM on the bf16 MFMA, every fp32 operand split exactly into 3 bf16 terms, 6 partial '
+                                    'products accumulated in fp32; 128x256 tiles, 8 waves in two ping-pong rows; blur convs of bcn1_/bcn2_ as two '
+                                    'tap-group passes each)')
                             if split3 else 'k_gconv<64,128,2,4,true,8,COMPACT> (fp32-MFMA gather-GEMM, 64x128 tiles, 8 waves, 3 workgroups per CU)')
             # Kernel quality is what the kernel does alone on the GPU: with several forward streams the launches inside the timed
             # loop share the CUs with kernels of other pairs.  Headline = the single-stream pass right after the timed loop (same
