@@ -136,7 +136,12 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             const int64_t m = m0 + r;
             Vs[r] = (m < p.M) ? (p.row_perm ? p.row_perm[m] : (int)m) : -1;
         }
-        for (int i = t; i < F_LDS * BM; i += NT) Is[i] = (i < p.F * BM) ? ti[i] : -1;
+        // (the table holds the BYTE offset of a source row, -1 for an absent one: the gathered loads add the column offset,
+        // no 32-bit multiply per load; a_bytes < 2^31 by contract)
+        for (int i = t; i < F_LDS * BM; i += NT) {
+            const int row = (i < p.F * BM) ? ti[i] : -1;
+            Is[i] = row >= 0 ? row * (int)(p.lda * 4) : -1;
+        }
     } else {
         if (t < 8) tapmask_s[t] = 0;
         for (int r = t; r < BM; r += NT) {
@@ -150,7 +155,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             const int v = Vs[r];
             int row = -1;
             if (v >= 0 && f < p.F) row = p.nbr ? p.nbr[(int64_t)f * p.nbr_stride + v] : (int)((int64_t)f * p.reg_stride + v);
-            Is[i] = row;
+            Is[i] = row >= 0 ? row * (int)(p.lda * 4) : -1;
             mybits |= (row >= 0) ? (1 << f) : 0;
         }
         if (mybits) {
@@ -224,7 +229,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     // ---- staging state
     constexpr unsigned OOB = 0x80000000u;
     const int32x4_t rsrc_a = make_rsrc(p.A, (int)p.a_bytes);
-    const unsigned lda_b = (unsigned)p.lda * 4u;
     const int kq = t & 7, arow0 = t >> 3, hb = (t >> 2) & 1;
     // weight planes: rows of the image that exist = p.w_bytes / (ldw * 4) (a multiple of 8 by contract)
     const unsigned w3_bytes = (unsigned)(p.w_bytes / 2);                  // (rows / 8) * ldw * 16 bytes per plane
@@ -271,7 +275,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         for (int i = 0; i < A_PASSES; ++i) {
             float4_t &dst = ra[SET][i];
             // (offset computed unconditionally: a conditional multiply becomes a branch, and the compute phase has to stay one block)
-            unsigned val = (unsigned)(HPL_ABLATE == 9 ? (a_rows[i] & 63) : a_rows[i]) * lda_b + (unsigned)a_c[i] * 4u;      // (9: every gathered load hits 64 cached rows)
+            unsigned val = (unsigned)(HPL_ABLATE == 9 ? (a_rows[i] & 0xffff) : a_rows[i]) + (unsigned)a_c[i] * 4u;      // (9: every gathered load hits the first 64 KB)
             asm("" : "+v"(val));
             const unsigned o = (a_ok[i] && a_rows[i] >= 0) ? val : OOB;
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(o), "s"(rs) : "memory");
@@ -544,28 +548,38 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             if constexpr (W) { if (h == 0) pin(setw_tag); }
             // products a_i * b_j with i + j <= 2 in the order their fragments arrive from LDS (planes are read hi, mid, lo: the
             // hi x hi product starts after the first four reads instead of after all twelve)
-            // one block of 12 MFMAs per 32-row block that has a tap of this slice, accumulators updated in place (a separate
-            // straight-line path for "both blocks" made hipcc keep two homes for the 64 accumulator registers and copy them
-            // behind a drained matrix pipe every half-step)
-            {
+            // The 24 MFMAs of the wave's 64 rows and the rest of the half-step (gathered loads, split + store) in ONE basic
+            // block, so that hipcc can put the other instructions into the MFMAs' shadows; a wave whose 64 rows lack the taps of
+            // the slice skips the MFMAs.  (A path per 32-row block cuts the block in three -- no interleave; an if / else over
+            // "both blocks" / "one block" made hipcc keep two homes for the 64 accumulator registers and copy them every half-step.)
+            auto rest = [&]() {
                 if constexpr (L) load_a_issue(setl_tag);
+                if constexpr (W) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (need[i]) {                      // wave-uniform
-#pragma unroll
-                        for (int q = 0; q < 6; ++q)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
-                                                                                    __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
-                                                                                    acc[i][j], 0, 0, 0);
-                    }
-                    if constexpr (W) {
-                        if (HALF_PASSES == 2) store_a(setw_tag, h, sta2, i);
-                        else if (i == 0) store_a(setw_tag, h, sta2, 0);
-                    }
+                    for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, sta2, j);
                 }
                 read_hi(sta1, stb1);
+            };
+            if (need[0] || need[1]) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
+                                                                                __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
+                                                                                acc[i][j], 0, 0, 0);
+                rest();
+#pragma unroll
+                for (int k = 0; k < 24; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);      // 4 VALU / SALU
+                    if (k % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+                    if (k % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
+                }
+            } else {
+                rest();
             }
             // everything older than the last NB - 2 half-steps' loads has landed (loads complete in order); own LDS stores done
             wait_vm_lgkm0(inflight_tag);
