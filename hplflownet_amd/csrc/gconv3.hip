@@ -15,11 +15,19 @@
 //
 // Geometry: 128 x (64*WGN) output tile, 2 x WGN waves, each wave 64 x 64 (2 x 2 MFMA tiles of 32 x 32, 64 accumulator
 // registers).  The contraction runs over the tile's list of needed 32-wide slices (as gconv.hip: slices whose taps are
-// absent for the whole tile are skipped) in HALF-slices of 16 -- one MFMA k-step -- through a ring of three LDS stages:
-// while half-step g is multiplied, the gathered rows of half-step g+2 are split and stored, and its weight fragments
-// arrive by LDS-direct loads (the three planes are stored [k/8][n][8] in HBM, i.e. already in MFMA B-fragment order).
-// Gathered rows are loaded as full 128-byte lines (8 lanes x 16 B), two register sets, one slice ahead.
-// LDS per workgroup: 3 x 24 KB + indices (128 x 128 tile): two workgroups per CU.
+// absent for the whole tile are skipped; a wave whose 64 rows lack the taps of a slice skips its MFMAs) in HALF-slices of
+// 16 -- one MFMA k-step, 24 MFMAs per wave.  Gathered rows: fp32 from HBM as full 128-byte lines (inline-asm buffer loads,
+// completion counted by hand), NB - 1 register sets, split while they are staged into a ring of three LDS stages
+// [plane][k-block][row][8 bf16] (row slots XOR-swizzled).  Weights: LDS-direct loads of the split image (the three planes
+// are stored [k/8][n][8] in HBM, i.e. already in MFMA B-fragment order) into a ring of NB stages, NB - 1 half-steps ahead.
+//
+// WGN = 4 (128 x 256, 8 waves, one workgroup per CU: the wide forward launches) runs a PING-PONG schedule: a half-step is a
+// memory phase (its 12 fragment reads) and a compute phase (its 24 MFMAs with everything else of the half-step -- weight
+// loads, index reads + gathered loads, split + store -- interleaved in one basic block), each closed by a workgroup barrier;
+// the second wave row enters one barrier late, so on every SIMD one wave computes while the other reads (see PP below).
+// WGN = 2 (128 x 128, 4 waves, two workgroups per CU: N that would pad a 256-wide tile by > 8 %, i.e. the data gradients)
+// keeps one barrier per half-step, MFMAs and the rest likewise in one block.
+// Mid-size stencils (too few tiles for 256 CUs) are split over K: shares of the slice range -> partial tiles -> k_gconv_finish.
 #include "common.h"
 #include "gconv_common.h"
 
@@ -99,11 +107,14 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     constexpr int KLIST = 1024;
     // (a 3-stage weight ring has its next half-step still in flight; the 4-wave tile runs two workgroups per CU in 128 registers)
     // PP: the two wave rows of the 8-wave tile (waves 0-3 / 4-7: one wave of each on every SIMD) run half a half-step apart.
-    // A half-step is a MEMORY phase (fragment reads of this half-step, the LDS-direct weight loads, the gathered loads, split +
-    // store of the rows staged for later) and a COMPUTE phase (its 24 MFMAs), each closed by a workgroup barrier; the second
-    // wave row enters one barrier late, so while one wave of a SIMD issues its MFMAs the other does its LDS / memory work
-    // under them -- without the offset both waves of a SIMD reach the same phase together and the matrix pipe idles through
-    // every memory phase (ablation: 39 % of the dense launch's time is not MFMA issue).
+    // A half-step is a MEMORY phase (the 12 fragment reads of this half-step -- what has to wait for the barrier) and a
+    // COMPUTE phase (its 24 MFMAs; weight loads, index reads + gathered loads, split + store of the rows staged for later are
+    // interleaved with them), each closed by a workgroup barrier; the second wave row enters one barrier late, so while one
+    // wave of a SIMD issues its MFMAs the other waits for its fragments -- without the offset both waves of a SIMD reach
+    // the same phase together and the matrix pipe idles through every memory phase (ablation of the one-barrier form: 39 %
+    // of the dense launch's time was not MFMA issue).  Hazards: an A stage is written two half-steps and a weight stage three
+    // half-steps before it is read, i.e. >= 3 barriers before the first reader of either row; a stage's last reader (the
+    // late row, one barrier behind) is still >= 1 barrier ahead of its next writer.
     constexpr bool PP = WGN == 4 && HPL_PP != 0;
     constexpr int PF = PP ? 0 : WGN != 4 ? 0 : NB == 4 ? HPL_PF : (HPL_PF ? 1 : 0);
     static_assert(A_PASSES == 2 || A_PASSES == 4, "two halves of a slice per thread");

@@ -224,6 +224,13 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
         wait_vm(N6{});
         pin_rows(ready);
         store_lds(cur ^ 1, ready);
+        // the split of the next stage in the shadows of this stage's MFMAs (one basic block: nothing here is conditional)
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // 4 VALU
+            if (k % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
+        }
         __syncthreads();
     };
     // (index sets alternate with the steps: ix0 holds the indices of even stages; row sets: r1 holds odd stages)
