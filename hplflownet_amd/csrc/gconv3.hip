@@ -55,11 +55,6 @@ constexpr bool ABL_LOADS_B = HPL_ABLATE == 1 || HPL_ABLATE == 3 || HPL_ABLATE ==
 constexpr bool ABL_STORES = HPL_ABLATE == 2 || HPL_ABLATE == 3 || HPL_ABLATE == 5 || HPL_ABLATE == 6;
 constexpr bool ABL_FRAGS = HPL_ABLATE >= 4 && HPL_ABLATE <= 6;
 
-// Fragment prefetch across the half-step barrier: 0 = none (all 12 fragment reads behind the barrier), 1 = the hi plane of
-// the gathered rows, 2 = hi planes of rows and weights (the weight ring then needs its loads landed one half-step earlier)
-#ifndef HPL_PF
-#define HPL_PF 1
-#endif
 // Diagnostic build (-DHPL_PHASE_PROBE=1, tools/gpu/phase_probe.sh): every wave of the sampled workgroups accumulates the shader
 // cycles it spends in the four parts of a ping-pong half-step (memory phase up to its wait, first barrier, compute phase,
 // second barrier) into clock_probe[8 + 4 * wave row ..]; timing only (the stamps are scalar memory reads: they add waits)
@@ -69,9 +64,6 @@ constexpr bool ABL_FRAGS = HPL_ABLATE >= 4 && HPL_ABLATE <= 6;
 // Ping-pong schedule of the 8-wave tile (see k_gconv3): 1 = on
 #ifndef HPL_PP
 #define HPL_PP 1
-#endif
-#ifndef HPL_PRIO
-#define HPL_PRIO 1
 #endif
 
 namespace {
@@ -116,7 +108,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     // half-steps before it is read, i.e. >= 3 barriers before the first reader of either row; a stage's last reader (the
     // late row, one barrier behind) is still >= 1 barrier ahead of its next writer.
     constexpr bool PP = WGN == 4 && HPL_PP != 0;
-    constexpr int PF = PP ? 0 : WGN != 4 ? 0 : NB == 4 ? HPL_PF : (HPL_PF ? 1 : 0);
     static_assert(A_PASSES == 2 || A_PASSES == 4, "two halves of a slice per thread");
     // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NA * A_STAGE + NB * B_STAGE + (F_LDS * BM + BM + 8) * 4 + KLIST * 2];
@@ -413,21 +404,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             ph_acc[k] += now - ph_t;
             ph_t = now;
         };
-        // hi-plane fragments of the half-step about to be multiplied: read from LDS behind the last-but-one product of the
-        // half-step before (whose last product, mid x mid, does not use the hi registers), so that the first product of a
-        // half-step issues right behind the barrier instead of behind the 8 waves' 96 fragment reads
-        u32x4 ah[2], bh[2];
-        auto read_hi = [&](int st_a, int st_b) {
-            if (ABL_FRAGS || PF == 0) return;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const u32x4 *>(smem + st_a * A_STAGE + a_rofs[i]);
-                if (PF == 2) bh[i] = *reinterpret_cast<const u32x4 *>(smem + st_b * B_STAGE + b_rofs + i * 32 * 16);
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { ah[i] = u32x4{0u, 1u, 2u, 3u}; bh[i] = u32x4{4u, 5u, 6u, 7u}; }
-        read_hi(0, 0);
         // One half-step g = 2*s + h: multiply (A stage sta, B stage stb; slice entry e_cur);
         //   B: LDS-direct loads of the weight fragments of half-step g + NB - 1 (slice kt_b, half hb) -> B stage (stb + NB - 1) % NB
         //   W: split + store half h of slice s + 1 (register set SETW) -> A stage (sta + 2) % 3
@@ -537,23 +513,13 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             } else
             if (need[0] || need[1]) {
 #pragma unroll
-                for (int pl = 1; pl < 3; ++pl)
+                for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         af[pl][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i] + pl * 2 * BM * 16);
                         bf[pl][i] = *reinterpret_cast<const u32x4 *>(sb + b_rofs + pl * 2 * BN * 16 + i * 32 * 16);
                     }
             }
-            if (!ABL_FRAGS) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (PF >= 1) af[0][i] = ah[i];
-                    else if (need[0] || need[1]) af[0][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i]);
-                    if (PF == 2) bf[0][i] = bh[i];
-                    else if (need[0] || need[1]) bf[0][i] = *reinterpret_cast<const u32x4 *>(sb + b_rofs + i * 32 * 16);
-                }
-            }
-            const int sta1 = sta == 2 ? 0 : sta + 1, stb1 = stb == NB - 1 ? 0 : stb + 1;      // the next half-step's stages
             if constexpr (B) load_b(kt_b, hb_b, stb2);
             if constexpr (L) load_a_rows(kt_l);
             if constexpr (W) { if (h == 0) pin(setw_tag); }
@@ -569,7 +535,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
 #pragma unroll
                     for (int j = 0; j < HALF_PASSES; ++j) store_a(setw_tag, h, sta2, j);
                 }
-                read_hi(sta1, stb1);
             };
             if (need[0] || need[1]) {
 #pragma unroll
@@ -612,12 +577,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 halfstep(e, 0, T{}, k1, 1, T{}, SW{}, T{}, SL{}, ks_at(sl + ASETS + 1), std::integral_constant<int, NLB>{});
                 halfstep(e, 1, T{}, kt_at(sl + 2), 0, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB + NLA>{});
             } else
-            if constexpr (NB == 4 && PF == 2) {
-                // as below, but the weight fragments of half-step g + 1 have landed when half-step g starts (its hi plane is read
-                // during g): the end-of-half-step wait leaves only that half-step's own loads in flight
-                halfstep(e, 0, T{}, k1, 1, T{}, SW{}, T{}, SL{}, kl, std::integral_constant<int, NLB + NLA>{});
-                halfstep(e, 1, T{}, kt_at(sl + 2), 0, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB>{});
-            } else
             if constexpr (NB == 3) {
                 halfstep(e, 0, T{}, k1, 0, T{}, SW{}, T{}, SL{}, kl, std::integral_constant<int, NLB + NLA>{});
                 halfstep(e, 1, T{}, k1, 1, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB>{});
@@ -636,7 +595,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             ks_advance(sl);
             const int e = ks_at(sl);
             const bool w = sl + 1 < nsl, l = sl + ASETS < nsl;
-            const int k1 = w ? kt_at(sl + 1) : 0, kl = l ? ks_at(sl + ASETS + (PP ? 1 : 0)) : 0;      // (ping-pong: indices one slice ahead)
+            const int kl = l ? ks_at(sl + ASETS + (PP ? 1 : 0)) : 0;      // (ping-pong: indices one slice ahead)
             // half 0
             {
                 const int gb = 2 * sl + NB - 1;                 // half-step whose weight fragments are fetched now
