@@ -270,7 +270,11 @@ int hpl_gconv_forward_naive(const hpl_gconv_desc *desc /* HOST */, hplStream str
  * tap_m / tap_row / tap_ptr (optional, from hpl_tap_lists; tap_max = longest list, M if the
  * centre tap is always present): the sum of tap f then runs over its present vertices only.
  * dbias (optional, [N], zero-initialised by the caller): dbias[n] += sum_m dY[m, n], the bias
- * gradient, from the dY tiles the kernel loads anyway. */
+ * gradient, from the dY tiles the kernel loads anyway.
+ * Wide layers (N >= 256, N % 4 == 0, C >= 128, C % 4 == 0, M >= 8192, 16-byte aligned operands, tap lists given or a dense
+ * 1x1 layer without a table, rows_a * lda * 4 and M * lddy * 4 below 2^31) run with both fp32 operands split exactly into
+ * three bf16 terms on the bf16 matrix pipe (csrc/wgrad3.hip: fp32-class accuracy, tests/test_gpu_wgrad3.py); HPL_WGRAD3=0 or
+ * HPL_MATH=f32 in the environment keep the fp32-MFMA kernel. */
 int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, const int32_t *nbr,
                     int64_t nbr_stride, int64_t reg_stride, int64_t M, int C, int F,
                     const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
