@@ -87,8 +87,12 @@ constexpr int BM3 = 128;
 template <int WGN, int F_LDS, int NB>
 __device__ __forceinline__ void gconv3_body(const GParams &p) {
     constexpr int BM = BM3, BN = 64 * WGN, NT = 128 * WGN;
-    constexpr int ROWS_PP = NT / 8;                 // rows covered by one gathered load instruction of the workgroup
-    constexpr int A_PASSES = BM / ROWS_PP;          // float4 per thread and slice: 4 (WGN = 2) or 2 (WGN = 4)
+    // Gathered loads: a thread's pass p fetches float4 column (t & 3) of HALF p & 1 of tile row t / 4 + (p / 2) * ROWS_PP: four
+    // lanes = the 64 bytes a row contributes to a half-slice.  (Eight lanes per full 128-byte line would give every thread one
+    // float4 of each half too, but WHICH pass holds which half would depend on the lane: the half-step's stores then select
+    // per lane -- 8 v_cndmask + 4 v_mov_b64 per slice beside the MFMAs, where every VALU instruction costs 5-10 cycles.)
+    constexpr int ROWS_PP = NT / 4;                 // rows covered by one gathered load instruction of the workgroup
+    constexpr int A_PASSES = 2 * BM / ROWS_PP;      // float4 per thread and slice: 4 (WGN = 2) or 2 (WGN = 4)
     constexpr int HALF_PASSES = A_PASSES / 2;
     constexpr int A_STAGE = 3 * 2 * BM * 16;        // bytes: [plane][kb 0..1][row][8 bf16]
     constexpr int B_STAGE = 3 * 2 * BN * 16;        //        [plane][kb 0..1][n][8 bf16]
@@ -108,6 +112,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     // half-steps before it is read, i.e. >= 3 barriers before the first reader of either row; a stage's last reader (the
     // late row, one barrier behind) is still >= 1 barrier ahead of its next writer.
     constexpr bool PP = WGN == 4 && HPL_PP != 0;
+    constexpr bool PP1 = PP && HPL_PP == 2;      // one barrier per half-step (see the compute phase)
     static_assert(A_PASSES == 2 || A_PASSES == 4, "two halves of a slice per thread");
     // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NA * A_STAGE + NB * B_STAGE + (F_LDS * BM + BM + 8) * 4 + KLIST * 2];
@@ -231,7 +236,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     // ---- staging state
     constexpr unsigned OOB = 0x80000000u;
     const int32x4_t rsrc_a = make_rsrc(p.A, (int)p.a_bytes);
-    const int kq = t & 7, arow0 = t >> 3, hb = (t >> 2) & 1;
+    const int k4 = t & 3, arow0 = t >> 2;
     // weight planes: rows of the image that exist = p.w_bytes / (ldw * 4) (a multiple of 8 by contract)
     const unsigned w3_bytes = (unsigned)(p.w_bytes / 2);                  // (rows / 8) * ldw * 16 bytes per plane
     __amdgpu_buffer_rsrc_t rsrc_b[3];
@@ -259,12 +264,11 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         const int c0 = (e & 1023) * BK - f0 * p.C;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
-            const int kqi = kq ^ ((i & 1) << 2);      // (full 128-byte lines per instruction; every thread ends up with
-            int c = c0 + kqi * 4, f = f0;             //  HALF_PASSES float4 of each half-slice)
+            int c = c0 + ((i & 1) * 4 + k4) * 4, f = f0;      // (pass i: half i & 1)
             const bool wrap = c >= p.C;                // (C >= 32: a slice touches at most two taps)
             c = wrap ? c - p.C : c;
             f += wrap ? 1 : 0;
-            a_rows[i] = Is[min(f, F_LDS - 1) * BM + arow0 + i * ROWS_PP];
+            a_rows[i] = Is[min(f, F_LDS - 1) * BM + arow0 + (i >> 1) * ROWS_PP];
             a_c[i] = c;
             a_ok[i] = f < p.F;
         }
@@ -295,8 +299,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             asm volatile("" : "+v"(x));
         }
     };
-    // half h of register set `set`: split + store into stage `st` (a thread holds float4 column (t & 3) of the half in
-    // its passes of parity hb ^ h)
+    // half h of register set `set`: split + store into stage `st` (a thread holds float4 column (t & 3) of half h in its
+    // passes 2 * j + h)
     // LDS slot of tile row r in k-block kb of a stage: r ^ swz(r, kb), swz = 2 * (r / 32) ^ 4 * kb (bits 1..2 of the
     // row).  Without it the 16 lanes of a store group differ only in address bits that do not reach the bank index
     // (k-blocks are 2 KiB apart, the two row sets of a thread 32 or 64 rows): 4-way conflicts, half of the LDS cycles
@@ -306,9 +310,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     auto store_a = [&](auto set_tag, int h, int st, int j) {
         constexpr int SET = decltype(set_tag)::value;
         if (ABL_STORES) return;
-        const bool odd = (hb ^ h) != 0;
-        const float4_t v = odd ? ra[SET][2 * j + 1] : ra[SET][2 * j];
-        const int row = arow0 + (2 * j + (odd ? 1 : 0)) * ROWS_PP;
+        const float4_t v = h ? ra[SET][2 * j + 1] : ra[SET][2 * j];      // (h is a literal at every call site)
+        const int row = arow0 + j * ROWS_PP;
         unsigned h0, m0_, l0, h1, m1, l1;
         if (HPL_ABLATE == 12) {          // (12: the LDS stores without the conversion)
             h0 = __builtin_bit_cast(unsigned, v.x); h1 = __builtin_bit_cast(unsigned, v.y); m0_ = __builtin_bit_cast(unsigned, v.z);
@@ -445,11 +448,12 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 // the loads of the compute phase before last have landed (in flight: the last compute phase's); fragments here,
                 // the LDS stores of the last compute phase done
                 const unsigned long long ph_issue = HPL_PHASE_PROBE ? __builtin_readcyclecounter() : 0ull;      // (read behind the wait)
-                wait_vm_lgkm0(inflight_tag);
+                if constexpr (PP1) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): fragments here, last compute phase's LDS stores done
+                else wait_vm_lgkm0(inflight_tag);
                 if (HPL_PHASE_PROBE) ph_acc[4] += ph_issue - ph_t;
                 __builtin_amdgcn_sched_barrier(0);
                 stamp(0);
-                if (HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");
+                if (HPL_ABLATE != 6 && (!PP1 || wm == 0)) asm volatile("s_barrier" ::: "memory");
                 stamp(1);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- compute phase: the 24 MFMAs of the wave's 64 rows and, in their shadow, everything else of the half-step
@@ -462,6 +466,14 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 // with all three in the memory phase instead 1190 / 790, with the gathered loads and the stores there 617 us
                 // against 597 us for the launch: this split is the fastest of the four tried.
                 auto others = [&]() {
+#ifdef HPL_DUMMY_VALU      // diagnostic: what one more VALU instruction beside the MFMAs costs
+                    {
+                        int dummy = lane;
+#pragma unroll
+                        for (int k = 0; k < HPL_DUMMY_VALU; ++k) asm volatile("v_add_u32 %0, %0, %0" : "+v"(dummy));
+                        asm volatile("" :: "v"(dummy));
+                    }
+#endif
                     if constexpr (B) load_b(kt_b, hb_b, stb2);
                     // (the row indices of these loads were read from LDS one slice ago -- no wait on the LDS queue, which the
                     // other wave row's fragment reads fill, in front of the MFMAs behind this point; kt_l = the NEXT slice's entry)
@@ -497,8 +509,21 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 }
                 // (own LDS stores: waited for at the end of the next memory phase, one barrier before anybody reads them)
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PP1) {
+                    // ONE barrier per half-step: the first wave row has it between its memory and compute phase, the second
+                    // (which entered one barrier late) behind its compute phase -- between two barriers the first row runs
+                    // compute(g), memory(g+1), the second memory(g), compute(g): the phases of a SIMD's two waves still
+                    // alternate, but a wave no longer idles at a barrier between ITS OWN phases.  The second row's loads and
+                    // LDS stores of this phase's predecessor must be visible one barrier earlier than the first row's:
+                    // in flight behind this wait = this compute phase's loads (second row) / this and the last one's (first).
+                    constexpr int TIGHT = (B ? B_CHUNKS_PER_WAVE : 0) + (L ? A_PASSES : 0), INFL = decltype(inflight_tag)::value;
+                    if constexpr (INFL == 0) wait_vm_lgkm0(std::integral_constant<int, 0>{});      // (tail: drain)
+                    else if (wm == 1) wait_vm_lgkm0(std::integral_constant<int, TIGHT>{});
+                    else wait_vm_lgkm0(std::integral_constant<int, TIGHT + INFL>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 stamp(2);
-                if (HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");
+                if (HPL_ABLATE != 6 && (!PP1 || wm == 1)) asm volatile("s_barrier" ::: "memory");
                 stamp(3);
                 __builtin_amdgcn_sched_barrier(0);
                 sta = sta == 2 ? 0 : sta + 1;
