@@ -115,9 +115,9 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     constexpr bool PP1 = PP && HPL_PP == 2;      // one barrier per half-step (see the compute phase)
     static_assert(A_PASSES == 2 || A_PASSES == 4, "two halves of a slice per thread");
     // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NA * A_STAGE + NB * B_STAGE + (F_LDS * BM + BM + 8) * 4 + KLIST * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NA * A_STAGE + NB * B_STAGE + ((F_LDS + 1) * BM + BM + 8) * 4 + KLIST * 2];
     int *Is = reinterpret_cast<int *>(smem + NA * A_STAGE + NB * B_STAGE);
-    int *Vs = Is + F_LDS * BM;
+    int *Vs = Is + (F_LDS + 1) * BM;               // (the index table has one more tap than F_LDS: a row of absent entries)
     int *tapmask_s = Vs + BM;                       // [0] taps of the tile, [1] slices needed, [2..5] taps of its 32-row blocks
     unsigned short *Ks = reinterpret_cast<unsigned short *>(tapmask_s + 8);
 
@@ -143,11 +143,12 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             const int64_t m = m0 + r;
             Vs[r] = (m < p.M) ? (p.row_perm ? p.row_perm[m] : (int)m) : -1;
         }
-        // (the table holds the BYTE offset of a source row, -1 for an absent one: the gathered loads add the column offset,
-        // no 32-bit multiply per load; a_bytes < 2^31 by contract)
-        for (int i = t; i < F_LDS * BM; i += NT) {
+        // (the table holds the BYTE offset of a source row, 0x80000000 for an absent one -- adding a column offset keeps that
+        // beyond the buffer's range, so a gathered load needs neither a multiply nor a validity select; a_bytes < 2^31 by
+        // contract.  Taps F .. F_LDS are all absent: a slice that straddles the end of the last tap reads them.)
+        for (int i = t; i < (F_LDS + 1) * BM; i += NT) {
             const int row = (i < p.F * BM) ? ti[i] : -1;
-            Is[i] = row >= 0 ? row * (int)(p.lda * 4) : -1;
+            Is[i] = row >= 0 ? row * (int)(p.lda * 4) : (int)0x80000000;
         }
     } else {
         if (t < 8) tapmask_s[t] = 0;
@@ -162,9 +163,10 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             const int v = Vs[r];
             int row = -1;
             if (v >= 0 && f < p.F) row = p.nbr ? p.nbr[(int64_t)f * p.nbr_stride + v] : (int)((int64_t)f * p.reg_stride + v);
-            Is[i] = row >= 0 ? row * (int)(p.lda * 4) : -1;
+            Is[i] = row >= 0 ? row * (int)(p.lda * 4) : (int)0x80000000;
             mybits |= (row >= 0) ? (1 << f) : 0;
         }
+        for (int i = F_LDS * BM + t; i < (F_LDS + 1) * BM; i += NT) Is[i] = (int)0x80000000;
         if (mybits) {
             atomicOr(tapmask_s, mybits);
             atomicOr(tapmask_s + 2 + ((t % BM) >> 5), mybits);
@@ -258,7 +260,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     // load_a_issue: the loads.  Two calls, so that the LDS round trip of the indices sits behind the first MFMAs of a
     // half-step instead of in front of them.
     int a_rows[A_PASSES], a_c[A_PASSES];
-    bool a_ok[A_PASSES];
     auto load_a_rows = [&](int e) {               // e: slice-list entry (slice | first tap << 10): no running state, no loop
         const int f0 = (e >> 10) & 15;
         const int c0 = (e & 1023) * BK - f0 * p.C;
@@ -267,10 +268,9 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             int c = c0 + ((i & 1) * 4 + k4) * 4, f = f0;      // (pass i: half i & 1)
             const bool wrap = c >= p.C;                // (C >= 32: a slice touches at most two taps)
             c = wrap ? c - p.C : c;
-            f += wrap ? 1 : 0;
-            a_rows[i] = Is[min(f, F_LDS - 1) * BM + arow0 + (i >> 1) * ROWS_PP];
+            f += wrap ? 1 : 0;                         // (<= F <= F_LDS: tap F of the table is all absent)
+            a_rows[i] = Is[f * BM + arow0 + (i >> 1) * ROWS_PP];
             a_c[i] = c;
-            a_ok[i] = f < p.F;
         }
     };
     auto load_a_issue = [&](auto set_tag) {
@@ -280,10 +280,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             float4_t &dst = ra[SET][i];
-            // (offset computed unconditionally: a conditional multiply becomes a branch, and the compute phase has to stay one block)
-            unsigned val = (unsigned)(HPL_ABLATE == 9 ? (a_rows[i] & 0xffff) : a_rows[i]) + (unsigned)a_c[i] * 4u;      // (9: every gathered load hits the first 64 KB)
-            asm("" : "+v"(val));
-            const unsigned o = (a_ok[i] && a_rows[i] >= 0) ? val : OOB;
+            // (an absent row's entry is 0x80000000: with the column offset still beyond the descriptor's range -> zeros)
+            const unsigned o = (unsigned)(HPL_ABLATE == 9 ? (a_rows[i] & 0x8000ffff) : a_rows[i]) + (unsigned)a_c[i] * 4u;      // (9: every gathered load hits the first 64 KB)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(o), "s"(rs) : "memory");
         }
     };
@@ -329,15 +327,13 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         *reinterpret_cast<u32x2 *>(base + 2 * BM * 16) = u32x2{m0_, m1};
         *reinterpret_cast<u32x2 *>(base + 4 * BM * 16) = u32x2{l0, l1};
     };
+    const unsigned b_colofs = ((unsigned)(n0 + wn * 64 + lane) < (unsigned)p.ldw) ? (unsigned)(n0 + wn * 64 + lane) * 16u : OOB;
     // weight fragments of half h of slice kt straight into stage st: wave (wm, wn) fetches k-block wm of the half for
     // the 64 columns of column block wn, one 1 KiB LDS-direct load per plane
     auto load_b = [&](int kt, int h, int st) {
         if (ABL_LOADS_B) return;
         const unsigned kbg = HPL_ABLATE == 10 ? (unsigned)(h * 2 + wm) : (unsigned)(kt * (BK / 8) + h * 2 + wm);      // (10: every weight load hits the first slice)
-        const unsigned col = (unsigned)(n0 + wn * 64 + lane);
-        unsigned val = kbg * ldw16 + col * 16u;
-        asm("" : "+v"(val));
-        const unsigned off = (col < (unsigned)p.ldw) ? val : OOB;
+        const unsigned off = kbg * ldw16 + b_colofs;      // (b_colofs = 0x80000000 for a column past the image: stays out of range)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
