@@ -660,7 +660,56 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         }
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Measured: with 64-bit addresses, an LDS read of the output row and (second tap-group pass) a load -> add -> store chain
+    // per element, the epilogue took 30 k of a tile's 355 k cycles -- 4 700 VALU instructions.  Fast path (every operand below
+    // 2 GB, the residual not wrapped): per 32 x 32 block the 16 output rows of a lane by four 16-byte LDS reads, 32-bit byte
+    // offsets (v_mul_u32_u24), buffer loads / stores whose offset is out of range for rows past M, columns past N and rows
+    // past rows2 -- no branches; all residual loads of a block before its stores.
+    typedef int int32x4v __attribute__((ext_vector_type(4)));
+    const bool fast_epi = p.epi_fast != 0;
+    if (fast_epi) {
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+            p.splits > 1 ? (void *)(p.partial + (int64_t)split * p.M * p.N) : (void *)p.Y, (short)0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+            p.res ? (void *)const_cast<float *>(p.res) : (void *)p.Y, (short)0, p.res ? 0x7fffffff : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(
+            p.Y2 ? (void *)p.Y2 : (void *)p.Y, (short)0, p.Y2 ? 0x7fffffff : 0, 0x00020000);
+        const unsigned ldy_b = (unsigned)(p.splits > 1 ? p.N : p.ldy) * 4u, ldr_b = (unsigned)p.ldres * 4u, ldy2_b = (unsigned)p.ldy2 * 4u;
+        const bool plain = p.splits <= 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + li;
+                const unsigned nb = n < p.N ? (unsigned)n * 4u : OOB;
+                const float bsv = (p.bias && plain && n < p.N) ? p.bias[n] : 0.f;
+                int mrow[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int32x4v mv = *reinterpret_cast<const int32x4v *>(Vs + wm * 64 + i * 32 + 8 * q + 4 * hi);
+                    mrow[4 * q + 0] = mv.x; mrow[4 * q + 1] = mv.y; mrow[4 * q + 2] = mv.z; mrow[4 * q + 3] = mv.w;
+                }
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldr_b) + nb : OOB;      // (nb = 0x80000000 for a column past N: the sum stays out of range)
+                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)ro, 0, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if (plain) {
+                        v = v + bsv + rv[r];
+                        if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
+                    }
+                    const unsigned yo = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldy_b) + nb : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (int)yo, 0, 0);
+                    const unsigned y2o = (mrow[r] >= 0 && mrow[r] < (int)p.rows2) ? __umul24((unsigned)mrow[r], ldy2_b) + nb : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y2, (int)y2o, 0, 0);
+                }
+            }
+    } else
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -817,6 +866,16 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
         grid = p.tiles_n * p.col_share * p.col_rows;
     }
     grid *= p.splits;
+    // the epilogue's 32-bit buffer addressing: every destination / residual below 2 GB, rows below 2^24, the residual not wrapped
+    {
+        const int64_t lim = (int64_t)0x7fffffff;
+        const int64_t rows_y = p.M;
+        p.epi_fast = (rows_y < (1 << 24) && rows_y * (p.splits > 1 ? p.N : p.ldy) * 4 < lim && p.ldy * 4 < (1 << 24) &&
+                      (!p.res || ((p.res_mod == 0 || p.res_mod >= p.M) && rows_y * p.ldres * 4 < lim && p.ldres * 4 < (1 << 24))) &&
+                      (!p.Y2 || (p.rows2 * p.ldy2 * 4 < lim && p.ldy2 * 4 < (1 << 24)))) ? 1 : 0;
+        static const int epi = getenv("HPL_SPLIT3_EPILOGUE") ? atoi(getenv("HPL_SPLIT3_EPILOGUE")) : 1;
+        if (!epi) p.epi_fast = 0;
+    }
     // instances by the taps whose indices a tile stages in LDS: 1 (dense GEMMs), <= 8 (tap-group passes), <= 15
     // HPL_SPLIT3_NB=3: the three-stage pipeline for the 256-wide tile too (A/B runs)
     static const int nb = getenv("HPL_SPLIT3_NB") ? atoi(getenv("HPL_SPLIT3_NB")) : 4;
