@@ -341,7 +341,8 @@ def source_stamp():
     for f in ('gconv.hip', 'gconv3.hip', 'gconv_common.h', 'executor.hip', 'row_order.hip'):
         h.update(open(os.path.join(ROOT, 'hplflownet_amd', 'csrc', f), 'rb').read())
     for k in ('HPL_MATH', 'HPL_SPLIT3_BN', 'HPL_TAP_GROUPS', 'HPL_TILE', 'HPL_WG3', 'HPL_PERSISTENT', 'HPL_SPLIT3_MIN_ROWS', 'HPL_SPLIT3_MIN_ROWS_STENCIL',
-              'HPL_SPLIT3_NB', 'HPL_SPLIT3_BN256_PCT', 'HPL_SPLIT3_MID_SPLITK', 'HPL_ROW_ORDER', 'HPL_FUSE_NARROW'):
+              'HPL_SPLIT3_NB', 'HPL_SPLIT3_BN256_PCT', 'HPL_SPLIT3_MID_SPLITK', 'HPL_ROW_ORDER', 'HPL_FUSE_NARROW', 'HPL_SPLIT3_EPILOGUE',
+              'HPL_GCONV_EPILOGUE'):
         h.update(('%s=%s;' % (k, os.environ.get(k, ''))).encode())
     return h.hexdigest()
 

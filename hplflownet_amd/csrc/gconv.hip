@@ -545,6 +545,54 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
         }
     }
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Fast form (gconv3.hip's: every operand below 2 GB, residual not wrapped, no scatter): output rows by 16-byte LDS reads,
+    // 32-bit byte offsets, out-of-range offsets instead of branches, the residual loads of a block before its stores.  The
+    // generic form below pays a 64-bit modulo and a load -> add -> store chain per element.
+    if (p.epi_fast && !p.scat) {
+        typedef int int32x4v __attribute__((ext_vector_type(4)));
+        constexpr unsigned OOB_E = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+            p.splits > 1 ? (void *)(p.partial + (int64_t)split * p.M * p.N) : (void *)p.Y, (short)0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+            p.res ? (void *)const_cast<float *>(p.res) : (void *)p.Y, (short)0, p.res ? 0x7fffffff : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(
+            p.Y2 ? (void *)p.Y2 : (void *)p.Y, (short)0, p.Y2 ? 0x7fffffff : 0, 0x00020000);
+        const unsigned ldy_b = (unsigned)(p.splits > 1 ? p.N : p.ldy) * 4u, ldr_b = (unsigned)p.ldres * 4u, ldy2_b = (unsigned)p.ldy2 * 4u;
+        const bool plain = p.splits <= 1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + li;
+                const unsigned nb = n < p.N ? (unsigned)n * 4u : OOB_E;      // (a column past N keeps every sum below out of range)
+                const float bsv = (p.bias && plain && n < p.N) ? p.bias[n] : 0.f;
+                int mrow[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int32x4v mv = *reinterpret_cast<const int32x4v *>(Vs + wm * WTM + i * 32 + 8 * q + 4 * hi);
+                    mrow[4 * q + 0] = mv.x; mrow[4 * q + 1] = mv.y; mrow[4 * q + 2] = mv.z; mrow[4 * q + 3] = mv.w;
+                }
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldr_b) + nb : OOB_E;
+                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)ro, 0, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if (plain) {
+                        v = v + bsv;
+                        if (p.res) v += rv[r];
+                        if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
+                    }
+                    const unsigned yo = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldy_b) + nb : OOB_E;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (int)yo, 0, 0);
+                    const unsigned y2o = (mrow[r] >= 0 && mrow[r] < (int)p.rows2) ? __umul24((unsigned)mrow[r], ldy2_b) + nb : OOB_E;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y2, (int)y2o, 0, 0);
+                }
+            }
+    } else
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1079,6 +1127,7 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.ws = d->ws; p.ws_bytes = d->ws ? d->ws_bytes : 0; p.splits = 1; p.partial = nullptr;
     p.Wt3 = d->Wt3; p.w3_plane_stride = d->wt3_plane_stride;
     p.post_Wt = d->post_Wt; p.post_ldw = d->post_ldw; p.post_N = d->post_N; p.post_bias = d->post_bias; p.post_act = d->post_act;
+    p.epi_fast = 0;
     if (p.post_Wt) {
         HPL_REQUIRE(!d->scat && d->N <= 64 && d->N % 2 == 0 && d->post_N >= 1 && d->post_N <= 64 && d->post_ldw >= d->post_N &&
                         (d->post_act == HPL_ACT_NONE || d->post_act == HPL_ACT_LEAKY) && d->ldy >= d->post_N &&
@@ -1166,6 +1215,13 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
         }
     }
     int grid = tiles * p.splits;
+    {   // the epilogue's 32-bit buffer addressing (see k_gconv): every destination / residual below 2 GB, rows below 2^24
+        const int64_t lim = (int64_t)0x7fffffff;
+        static const int epi = getenv("HPL_GCONV_EPILOGUE") ? atoi(getenv("HPL_GCONV_EPILOGUE")) : 1;
+        p.epi_fast = (epi && !p.scat && !p.post_Wt && p.M < (1 << 24) && p.M * (p.splits > 1 ? p.N : p.ldy) * 4 < lim && p.ldy * 4 < (1 << 24) &&
+                      (!p.res || (p.res_mod >= p.M && p.M * p.ldres * 4 < lim && p.ldres * 4 < (1 << 24))) &&
+                      (!p.Y2 || (p.rows2 * p.ldy2 * 4 < lim && p.ldy2 * 4 < (1 << 24)))) ? 1 : 0;
+    }
     p.col_share = 0; p.col_rows = 0;
     static const int col_order = getenv("HPL_TILE_ORDER") ? atoi(getenv("HPL_TILE_ORDER")) : 1;
     if (col_order && p.row_perm && p.splits == 1) {

@@ -700,7 +700,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r];
                     if (plain) {
-                        v = v + bsv + rv[r];
+                        v = v + bsv;
+                        if (p.res) v += rv[r];
                         if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
                     }
                     const unsigned yo = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldy_b) + nb : OOB;

@@ -55,7 +55,7 @@ struct GParams {
     // optional trailing 1x1 conv fused into the epilogue (N, post_N <= 64: one column tile holds a whole row):
     // Y = act2(post_bias + act(bias + res + A*Wt) * post_Wt)
     const float *post_Wt; int64_t post_ldw; int post_N; const float *post_bias; int post_act;
-    int epi_fast;                       // gconv3: 32-bit buffer addressing in the epilogue (set by launch_split3)
+    int epi_fast;                       // 32-bit buffer addressing in the epilogue (set by the launch functions)
 };
 
 __device__ __forceinline__ int64_t src_row(const GParams &p, int f, int64_t m) {

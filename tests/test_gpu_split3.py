@@ -101,3 +101,41 @@ def test_split3_is_deterministic_and_order_independent():
     c = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3, split_k=False)
     d = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3, row_perm=torch.randperm(M, device=DEV).int(), split_k=False)
     assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+
+
+def test_split3_generic_epilogue_is_bit_identical():
+    """The epilogue has a fast form (32-bit buffer addressing; what every launch of the model takes) and the generic form it falls
+    back to for operands of 2 GB and more: HPL_SPLIT3_EPILOGUE=0 forces the generic one -- same bits, with bias, LeakyReLU, a
+    residual (the second tap-group pass of a layer) and a second destination."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from hplflownet_amd import ops\n"
+        "torch.manual_seed(3)\n"
+        "M, C, F, N = 16500, 64, 8, 512\n"
+        "A = torch.randn(M + 11, C, device='cuda')\n"
+        "Wt = torch.randn(ops.round_up(F * C, 32), N, device='cuda') / (F * C) ** 0.5\n"
+        "g = torch.Generator(device='cpu').manual_seed(9)\n"
+        "nbr = torch.randint(0, M + 11, (F, M), generator=g, dtype=torch.int32)\n"
+        "nbr[torch.rand((F, M), generator=g) > 0.7] = -1\n"
+        "nbr = nbr.cuda()\n"
+        "perm = ops.tap_order(nbr)\n"
+        "res = torch.randn(M, N, device='cuda')\n"
+        "out2 = torch.zeros(9000, N, device='cuda')\n"
+        "y = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=ops.weight_split3(Wt), bias=torch.randn(N, device='cuda'), act=ops.ACT_LEAKY,\n"
+        "                  res=res, row_perm=perm, tiles=ops.tile_index(nbr, perm, BM=128), split_k=False, out2=out2, rows2=9000)\n"
+        "torch.save((y.cpu(), out2.cpu()), sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ('1', '0'):
+            f = os.path.join(d, 'y%s.pt' % mode)
+            r = subprocess.run([sys.executable, '-c', code, f], env=dict(os.environ, HPL_SPLIT3_EPILOGUE=mode), capture_output=True,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+            outs.append(torch.load(f))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].abs().max()) > 0 and torch.equal(outs[0][0][:9000], outs[0][1])
