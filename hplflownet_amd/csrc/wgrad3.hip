@@ -240,17 +240,21 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
     }
     wait_vm(N0{});
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Buffer atomics with
+    // 32-bit byte offsets (the image is far below 2 GB: checked by launch_wgrad3), out of range for rows past C / columns past N
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.dWt, (short)0, 0x7fffffff, 0x00020000);
+    const unsigned ldw_b = (unsigned)p.ldw * 4u;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + li;
-            if (n >= p.N) continue;
+            const unsigned nb = n < p.N ? (unsigned)n * 4u : OOB;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (c0_tile + kr < p.C) atomicAdd(p.dWt + (int64_t)(k0 + kr) * p.ldw + n, acc[i][j][r]);
+                const unsigned o = (c0_tile + kr < p.C) ? __umul24((unsigned)(k0 + kr), ldw_b) + nb : OOB;
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][r], rs_w, (int)o, 0, 0);
             }
         }
 }
@@ -266,6 +270,7 @@ bool hpl_gc::launch_wgrad3(WParams &p, bool tap, int64_t m_len, hipStream_t s) {
     if (p.N < 256 || p.N % 4 != 0 || p.C < 128 || p.C % 4 != 0 || p.M < min_rows) return false;
     // (32-bit byte offsets in the buffer loads)
     if (p.rows_a <= 0 || p.rows_a * p.lda * 4 >= (int64_t)0x7fffffff || p.M * p.lddy * 4 >= (int64_t)0x7fffffff) return false;
+    if ((int64_t)p.K * p.ldw * 4 >= (int64_t)0x7fffffff || p.K >= (1 << 24) || p.ldw * 4 >= (1 << 24)) return false;
     p.c_tiles = (int)cdiv(p.C, W3_BKR);
     p.tiles_n = (int)cdiv(p.N, W3_BN);
     const int tiles = (tap ? p.F : 1) * p.c_tiles * p.tiles_n;
