@@ -162,7 +162,7 @@ struct Runner {
             pl.pool.push_back(e);
         }
         (void)stop;
-        hipEventRecord(pl.pool[pl.pool_used++], s);
+        (void)hipEventRecord(pl.pool[pl.pool_used++], s);
     }
 
     int gconv(const hpl_op &op) {
@@ -422,7 +422,7 @@ extern "C" hpl_plan *hpl_plan_create(const hpl_op *ops, int n_ops, const hpl_buf
 
 extern "C" void hpl_plan_destroy(hpl_plan *plan) {
     if (!plan) return;
-    for (hipEvent_t e : plan->pool) hipEventDestroy(e);
+    for (hipEvent_t e : plan->pool) (void)hipEventDestroy(e);
     delete plan;
 }
 

@@ -457,10 +457,11 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 // split + store of the rows staged for the half-step after next.  One basic block, so that hipcc can interleave
                 // (the 32-row block skip of the non-ping-pong path would cut it into four); a wave whose 64 rows have no tap in the
                 // slice skips the MFMAs altogether.
-                // Measured (cycles per half-step and wave, -DHPL_PHASE_PROBE=1): memory phase 515, compute phase 1160 -- every
-                // interleaved group (weight loads / gathered loads / split + store) adds 110-140 to the 840 of the bare MFMAs;
-                // with all three in the memory phase instead 1190 / 790, with the gathered loads and the stores there 617 us
-                // against 597 us for the launch: this split is the fastest of the four tried.
+                // Measured (cycles per half-step and wave, -DHPL_PHASE_PROBE=1, profiles/r03s_phase_probe.txt): memory phase 450-480,
+                // compute phase 975-1015 -- the interleaved groups (weight loads / gathered loads / split + store) add 50-110 each
+                // to the 815-835 of the bare MFMAs: an instruction beside the MFMAs costs 5-10 cycles of issue, nothing is free.
+                // With all three groups in the memory phase instead: 1190 / 790 (before the instruction trims); with the gathered
+                // loads and the stores there 617 us against 597 us for the launch: this split is the fastest of the four tried.
                 auto others = [&]() {
 #ifdef HPL_DUMMY_VALU      // diagnostic: what one more VALU instruction beside the MFMAs costs
                     {
