@@ -559,6 +559,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
             p.Y2 ? (void *)p.Y2 : (void *)p.Y, (short)0, p.Y2 ? 0x7fffffff : 0, 0x00020000);
         const unsigned ldy_b = (unsigned)(p.splits > 1 ? p.N : p.ldy) * 4u, ldr_b = (unsigned)p.ldres * 4u, ldy2_b = (unsigned)p.ldy2 * 4u;
         const bool plain = p.splits <= 1;
+        const bool res_wrap = p.res && p.res_mod < p.M;      // (uniform)
+        const float res_inv = res_wrap ? 1.0f / (float)p.res_mod : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -575,7 +577,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
                 float rv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldr_b) + nb : OOB_E;
+                    int rr = mrow[r];
+                    if (res_wrap) {              // residual row = m % res_mod (the correlation layer: rows f * H + v add row v): m < 2^24 is
+                        // exact in fp32, the quotient by reciprocal is off by at most one
+                        const int q = (int)((float)rr * res_inv);
+                        rr -= (int)__umul24((unsigned)q, (unsigned)p.res_mod);
+                        rr = rr < 0 ? rr + (int)p.res_mod : (rr >= (int)p.res_mod ? rr - (int)p.res_mod : rr);
+                    }
+                    const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)rr, ldr_b) + nb : OOB_E;
                     rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)ro, 0, 0));
                 }
 #pragma unroll
@@ -1219,7 +1228,7 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
         const int64_t lim = (int64_t)0x7fffffff;
         static const int epi = getenv("HPL_GCONV_EPILOGUE") ? atoi(getenv("HPL_GCONV_EPILOGUE")) : 1;
         p.epi_fast = (epi && !p.scat && !p.post_Wt && p.M < (1 << 24) && p.M * (p.splits > 1 ? p.N : p.ldy) * 4 < lim && p.ldy * 4 < (1 << 24) &&
-                      (!p.res || (p.res_mod >= p.M && p.M * p.ldres * 4 < lim && p.ldres * 4 < (1 << 24))) &&
+                      (!p.res || (p.res_mod > 0 && p.res_mod < (1 << 24) && imin(p.res_mod, p.M) * p.ldres * 4 < lim && p.ldres * 4 < (1 << 24))) &&
                       (!p.Y2 || (p.rows2 * p.ldy2 * 4 < lim && p.ldy2 * 4 < (1 << 24)))) ? 1 : 0;
     }
     p.col_share = 0; p.col_rows = 0;

@@ -678,6 +678,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             p.Y2 ? (void *)p.Y2 : (void *)p.Y, (short)0, p.Y2 ? 0x7fffffff : 0, 0x00020000);
         const unsigned ldy_b = (unsigned)(p.splits > 1 ? p.N : p.ldy) * 4u, ldr_b = (unsigned)p.ldres * 4u, ldy2_b = (unsigned)p.ldy2 * 4u;
         const bool plain = p.splits <= 1;
+        const bool res_wrap = p.res && p.res_mod < p.M;      // (uniform)
+        const float res_inv = res_wrap ? 1.0f / (float)p.res_mod : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -694,7 +696,14 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 float rv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldr_b) + nb : OOB;      // (nb = 0x80000000 for a column past N: the sum stays out of range)
+                    int rr = mrow[r];
+                    if (res_wrap) {              // residual row = m % res_mod (the correlation layer: rows f * H + v add row v): m < 2^24 is
+                        // exact in fp32, the quotient by reciprocal is off by at most one
+                        const int q = (int)((float)rr * res_inv);
+                        rr -= (int)__umul24((unsigned)q, (unsigned)p.res_mod);
+                        rr = rr < 0 ? rr + (int)p.res_mod : (rr >= (int)p.res_mod ? rr - (int)p.res_mod : rr);
+                    }
+                    const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)rr, ldr_b) + nb : OOB;
                     rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)ro, 0, 0));
                 }
 #pragma unroll
@@ -873,7 +882,7 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
         const int64_t lim = (int64_t)0x7fffffff;
         const int64_t rows_y = p.M;
         p.epi_fast = (rows_y < (1 << 24) && rows_y * (p.splits > 1 ? p.N : p.ldy) * 4 < lim && p.ldy * 4 < (1 << 24) &&
-                      (!p.res || ((p.res_mod == 0 || p.res_mod >= p.M) && rows_y * p.ldres * 4 < lim && p.ldres * 4 < (1 << 24))) &&
+                      (!p.res || (p.res_mod > 0 && p.res_mod < (1 << 24) && imin(p.res_mod, rows_y) * p.ldres * 4 < lim && p.ldres * 4 < (1 << 24))) &&
                       (!p.Y2 || (p.rows2 * p.ldy2 * 4 < lim && p.ldy2 * 4 < (1 << 24)))) ? 1 : 0;
         static const int epi = getenv("HPL_SPLIT3_EPILOGUE") ? atoi(getenv("HPL_SPLIT3_EPILOGUE")) : 1;
         if (!epi) p.epi_fast = 0;
