@@ -469,3 +469,50 @@ def test_fused_trailing_conv_is_bit_identical_to_two_launches(ops, M, C, F, N1, 
     want = ops.gconv_raw(ops.gconv_raw(A, nbr, M, C, F, Wt, N1, bias=b1, act=ops.ACT_LEAKY, split_k=ws), None, M, N1, 1, W2, N2,
                          split_k=False)
     assert torch.equal(got, want)
+
+
+def test_fast_and_generic_epilogues_are_bit_identical():
+    """hpl_gconv_forward's epilogue has a fast form (32-bit buffer addressing, residual loads batched per block) and the
+    generic form it falls back to for operands of 2 GB and more; HPL_GCONV_EPILOGUE=0 forces the generic one.  Same bits on:
+    a wrapped residual (the correlation layer: row m adds residual row m % res_mod), a plain residual + second destination,
+    a split-K launch (partial tiles), with bias and LeakyReLU, ragged M / N."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from hplflownet_amd import ops\n"
+        "torch.manual_seed(11)\n"
+        "outs = []\n"
+        "for M, rows, C, F, N, res_mod, rows2 in ((15 * 613, 700, 64, 15, 32, 613, 0), (5003, 5003, 68, 15, 64, 5003, 3001),\n"
+        "                                         (301, 400, 260, 15, 128, 0, 0), (20000, 20000, 32, 1, 40, 0, 0)):\n"
+        "    g = torch.Generator(device='cpu').manual_seed(M)\n"
+        "    A = torch.randn(rows, C, device='cuda')\n"
+        "    Wt = torch.zeros(ops.round_up(F * C, 32), ops.round_up(N, 4), device='cuda')\n"
+        "    Wt[:F * C, :N] = torch.randn(F * C, N, device='cuda') / (F * C) ** 0.5\n"
+        "    nbr = None\n"
+        "    if F > 1:\n"
+        "        nbr = torch.randint(0, rows, (F, M), generator=g, dtype=torch.int32)\n"
+        "        nbr[torch.rand((F, M), generator=g) > 0.6] = -1\n"
+        "        nbr = nbr.cuda()\n"
+        "    res = torch.randn(res_mod, N, device='cuda') if res_mod else None\n"
+        "    out2 = torch.zeros(rows2, N, device='cuda') if rows2 else None\n"
+        "    y = ops.gconv_raw(A, nbr, M, C, F, Wt, N, bias=torch.randn(N, device='cuda'), act=ops.ACT_LEAKY, res=res,\n"
+        "                      res_mod=res_mod, out2=out2, rows2=rows2)\n"
+        "    outs.append(y.cpu())\n"
+        "    if out2 is not None:\n"
+        "        outs.append(out2.cpu())\n"
+        "torch.save(outs, sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    got = []
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ('1', '0'):
+            f = os.path.join(d, 'y%s.pt' % mode)
+            r = subprocess.run([sys.executable, '-c', code, f], env=dict(os.environ, HPL_GCONV_EPILOGUE=mode), capture_output=True,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+            got.append(torch.load(f))
+    assert len(got[0]) == len(got[1]) == 5
+    for a, b in zip(*got):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
