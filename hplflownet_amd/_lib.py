@@ -81,7 +81,8 @@ class LatticeSpec(ctypes.Structure):
     """Mirror of `hpl_lattice_spec`."""
     _fields_ = [('n_levels', c_i32), ('scale', c_f32 * 8), ('bcn_radius', c_i32 * 8), ('corr_filter_radius', c_i32 * 8),
                 ('corr_corr_radius', c_i32 * 8), ('next_divisor', c_f32 * 8), ('wide_up', c_i32 * 8), ('n_groups', c_i32),
-                ('group_cut', c_i32 * 5), ('groups_min_sparsity', c_f32), ('perm_min_rows', c_i64), ('group_tile_bm', c_i32)]
+                ('group_cut', c_i32 * 5), ('groups_min_sparsity', c_f32), ('perm_min_rows', c_i64), ('group_tile_bm', c_i32),
+                ('fused', c_i32)]
 
 
 _SIGNATURES = {
@@ -132,6 +133,9 @@ _SIGNATURES = {
     'hpl_lattice_next_points': (ctypes.c_int, [c_vp, c_i64, c_i64, c_f32, c_vp, c_vp]),
     'hpl_lattice_create': (c_vp, [ctypes.POINTER(LatticeSpec)]),
     'hpl_lattice_destroy': (None, [c_vp]),
+    'hpl_lattice_arena_bytes': (c_i64, [c_vp, c_i64, c_i64]),
+    'hpl_lattice_set_bounds': (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64)]),
+    'hpl_lattice_stats': (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32)]),
     'hpl_lattice_begin': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     'hpl_lattice_ready': (ctypes.c_int, [c_vp]),
     'hpl_lattice_advance': (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int)]),

@@ -3,7 +3,15 @@
 // (hpl_lattice_keys_pair, hpl_lattice_hash, hpl_lattice_neighbors, hpl_csr_build_pair, hpl_tap_order,
 // hpl_tile_index) with the same arguments -- the tables are bit-identical -- but without ~35 ctypes round trips and
 // ~60 tensor allocations per pair: every array is carved out of one caller-owned arena.
+//
+// Two drivers behind the same hpl_lattice_* calls:
+//   staged (spec.fused == 0, or the fallback of a fused build that overflowed its bounds): level by level, the vertex
+//          counts of each level read back to size the next arrays -- 7 host round trips and ~260 launches per pair;
+//   fused  (spec.fused != 0; csrc/lattice_fused.hip): hpl_lattice_begin enqueues the WHOLE build (33 launches for 7
+//          levels), the counts stay on the device and come back once; hpl_lattice_advance only waits for that one
+//          read-back and fills in the tables.
 #include "common.h"
+#include "lattice_fused.h"
 
 #include <new>
 #include <stdlib.h>
@@ -27,6 +35,7 @@ struct hpl_lattice {
     int level = 0;                 // level whose counts are pending
     bool active = false, done = false, overflow = false;
     int64_t n[2] = {0, 0};
+    int64_t n_start[2] = {0, 0};
     int64_t n_vert[2] = {0, 0};    // vertices of the level being finished
     const float *pc[2] = {nullptr, nullptr};
     // per level scratch kept until its second half
@@ -40,6 +49,15 @@ struct hpl_lattice {
     int32_t *counts_host = nullptr;   // pinned, 2 per level
     hipEvent_t ev[HPL_MAX_LEVELS];
     bool ev_ok = false;
+    // fused driver
+    bool fused_run = false;           // the build in progress was enqueued by the fused driver
+    fused::Plan plan;
+    fused::Level *lv_stage = nullptr; // pinned: source of the level-descriptor copy
+    int32_t *dims_host = nullptr;     // pinned: the one read-back
+    hipEvent_t counts_ev = nullptr;
+    int64_t bounds[HPL_MAX_LEVELS] = {0};
+    int32_t stat_launches = 0, stat_fallbacks = 0, stat_fused = 0;
+    bool last_fused = false;          // the last finished build came from the fused driver
 
     template <class T> T *take(int64_t count) {
         const int64_t bytes = (count * (int64_t)sizeof(T) + 255) / 256 * 256;
@@ -202,6 +220,64 @@ int level_tail(hpl_lattice *b) {
     return HPL_OK;
 }
 
+
+// fused driver: the counts have landed -> the hpl_level_tables of every level (the same decisions level_tail makes)
+int fused_finish(hpl_lattice *b) {
+    const hpl_lattice_spec &sp = b->spec;
+    const fused::Plan &P = b->plan;
+    int64_t n0 = b->n[0], n1 = b->n[1];
+    for (int L = 0; L < sp.n_levels; ++L) {
+        const fused::Level &V = P.lv[L];
+        const int32_t *d = b->dims_host + fused::DIM_INTS * (1 + L);
+        const int64_t H0 = d[fused::D_H0], H1 = d[fused::D_H1];
+        HPL_REQUIRE(H0 > 0 && H1 > 0 && H0 <= 4 * n0 && H1 <= 4 * n1, "hpl_lattice: implausible vertex counts %lld / %lld at level %d",
+                    (long long)H0, (long long)H1, L);
+        const int64_t Hp = H0 + H1;
+        hpl_level_tables &t = b->tab[L];
+        t = hpl_level_tables{};
+        t.n0 = n0; t.n1 = n1; t.H0 = H0; t.H1 = H1;
+        t.emg_pair = V.emg;
+        t.bary0 = V.bary[0]; t.off0 = V.off[0];
+        b->bary1[L] = V.bary[1]; b->off1[L] = V.off[1];
+        t.csr_ptr = V.csr_ptr; t.csr_pt = V.csr_pt; t.csr_w = V.csr_w; t.csr_norm = V.norm;
+        t.blur = V.blur; t.blur_stride = Hp;
+        t.tile_bm = TILE_BM;
+        t.group_tile_bm = sp.group_tile_bm == 128 ? 128 : TILE_BM;
+        const bool has_corr = sp.corr_filter_radius[L] != -1;
+        if (has_corr) { t.corr1 = V.blur; t.corr1_stride = Hp; t.corr2 = V.corr2; }
+        const int wide = sp.wide_up[L];
+        const bool sparse = (double)H0 / (double)n0 >= (double)sp.groups_min_sparsity;
+        const bool grouped = H0 >= sp.perm_min_rows && wide != 0 && sp.n_groups >= 2 && sparse;
+        const bool single = H0 >= sp.perm_min_rows && (!(grouped && wide == 1) || has_corr);
+        for (int q = 0; q < V.n_jobs; ++q) {
+            const fused::SortJob &J = V.job[q];
+            if (J.role == 0 && Hp >= sp.perm_min_rows) {
+                t.blur_perm = J.perm; t.blur_perm_tidx = J.tidx; t.blur_perm_tmask = J.tmask;
+            } else if (J.role == 1 && single) {
+                t.up_perm = J.perm; t.up_perm_tidx = J.tidx; t.up_perm_tmask = J.tmask;
+            } else if (J.role >= 2 && grouped) {
+                const int g = J.role - 2;
+                t.up_group_perm[g] = J.perm; t.up_group_tidx[g] = J.tidx; t.up_group_tmask[g] = J.tmask;
+                t.up_group_cut[g] = J.f0; t.up_group_cut[g + 1] = J.f0 + J.F;
+            }
+        }
+        if (grouped) t.n_up_groups = sp.n_groups;
+        if (has_corr) { t.corr1_perm = t.up_perm; t.corr1_perm_tidx = t.up_perm_tidx; t.corr1_perm_tmask = t.up_perm_tmask; }
+        n0 = H0; n1 = H1;
+    }
+    return HPL_OK;
+}
+
+int fused_begin(hpl_lattice *b) {
+    const int64_t need = fused::layout(b->spec, b->n[0], b->n[1], b->bounds, b->pc[0], b->pc[1], b->arena, b->plan);
+    if (need < 0) { set_error("hpl_lattice (fused): clouds too large"); return HPL_EINVAL; }
+    if (need > b->end - b->arena) return HPL_ENOMEM;
+    b->cur = b->arena + need;
+    const int rc = fused::enqueue(b->plan, b->lv_stage, b->dims_host, b->counts_ev, b->s);
+    b->stat_launches = b->plan.launches;
+    return rc;
+}
+
 }  // namespace
 
 extern "C" hpl_lattice *hpl_lattice_create(const hpl_lattice_spec *spec) {
@@ -223,12 +299,25 @@ extern "C" hpl_lattice *hpl_lattice_create(const hpl_lattice_spec *spec) {
     for (int i = 0; i < HPL_MAX_LEVELS; ++i) ok = ok && hipEventCreateWithFlags(&b->ev[i], hipEventDisableTiming) == hipSuccess;
     b->ev_ok = ok;
     if (!ok) { set_error("hpl_lattice_create: event creation failed"); hpl_lattice_destroy(b); return nullptr; }
+    if (spec->fused) {
+        if (!fused::supported(*spec)) { set_error("hpl_lattice_create: this spec needs the staged builder (fused = 0)"); hpl_lattice_destroy(b); return nullptr; }
+        if (hipHostMalloc(reinterpret_cast<void **>(&b->lv_stage), sizeof(fused::Level) * HPL_MAX_LEVELS, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&b->dims_host), sizeof(int32_t) * fused::DIM_INTS * (1 + HPL_MAX_LEVELS), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&b->counts_ev, hipEventDisableTiming) != hipSuccess) {
+            set_error("hpl_lattice_create: no pinned memory / event for the fused driver");
+            hpl_lattice_destroy(b);
+            return nullptr;
+        }
+    }
     return b;
 }
 
 extern "C" void hpl_lattice_destroy(hpl_lattice *b) {
     if (!b) return;
     if (b->counts_host) (void)hipHostFree(b->counts_host);
+    if (b->lv_stage) (void)hipHostFree(b->lv_stage);
+    if (b->dims_host) (void)hipHostFree(b->dims_host);
+    if (b->counts_ev) (void)hipEventDestroy(b->counts_ev);
     if (b->ev_ok) for (int i = 0; i < HPL_MAX_LEVELS; ++i) (void)hipEventDestroy(b->ev[i]);
     delete b;
 }
@@ -242,13 +331,36 @@ extern "C" int hpl_lattice_begin(hpl_lattice *b, const float *pc1, const float *
     b->hs = stream; b->s = to_stream(stream);
     b->level = 0; b->active = true; b->done = false; b->overflow = false;
     b->n[0] = n0; b->n[1] = n1; b->pc[0] = pc1; b->pc[1] = pc2;
-    const int rc = level_head(b);
+    b->n_start[0] = n0; b->n_start[1] = n1;
+    b->fused_run = b->spec.fused != 0;
+    b->last_fused = false;
+    const int rc = b->fused_run ? fused_begin(b) : level_head(b);
     if (rc) b->active = false;
     return rc;
 }
 
+extern "C" int64_t hpl_lattice_arena_bytes(const hpl_lattice *b, int64_t n0, int64_t n1) {
+    if (!b || n0 <= 0 || n1 <= 0) return -1;
+    if (!b->spec.fused) return 0;
+    fused::Plan tmp;
+    return fused::layout(b->spec, n0, n1, b->bounds, nullptr, nullptr, nullptr, tmp);
+}
+
+extern "C" int hpl_lattice_set_bounds(hpl_lattice *b, const int64_t *bounds) {
+    HPL_REQUIRE(b && (!b->active || b->done), "hpl_lattice_set_bounds: no builder, or a build is in progress");
+    for (int L = 0; L < HPL_MAX_LEVELS; ++L) b->bounds[L] = bounds ? bounds[L] : 0;
+    return HPL_OK;
+}
+
+extern "C" int hpl_lattice_stats(const hpl_lattice *b, int32_t *out) {
+    HPL_REQUIRE(b && out, "hpl_lattice_stats: null argument");
+    out[0] = b->stat_launches; out[1] = b->last_fused ? 1 : 0; out[2] = b->stat_fallbacks;
+    return HPL_OK;
+}
+
 extern "C" int hpl_lattice_ready(hpl_lattice *b) {
     if (!b || !b->active || b->done) return 1;
+    if (b->fused_run) return hipEventQuery(b->counts_ev) == hipSuccess ? 1 : 0;
     return hipEventQuery(b->ev[b->level]) == hipSuccess ? 1 : 0;
 }
 
@@ -257,6 +369,29 @@ extern "C" int hpl_lattice_advance(hpl_lattice *b, int *done) {
     *done = b->done ? 1 : 0;
     if (b->done) return HPL_OK;
     HPL_REQUIRE(b->active, "hpl_lattice_advance: no build in progress");
+    if (b->fused_run) {
+        if (hipEventSynchronize(b->counts_ev) != hipSuccess) { set_error("hpl_lattice_advance: event wait failed"); return HPL_EHIP; }
+        if (!b->dims_host[fused::HDR_OVERFLOW]) {
+            const int rc = fused_finish(b);
+            if (rc) { b->active = false; return rc; }
+            ++b->stat_fused;
+            b->last_fused = true;
+            b->done = true;
+            *done = 1;
+            return HPL_OK;
+        }
+        // a level outgrew its bound: the pair is rebuilt level by level with exact sizes in the same arena (the fused
+        // launches still in flight on this stream only touch memory the staged build rewrites behind them)
+        ++b->stat_fallbacks;
+        b->last_fused = false;
+        b->fused_run = false;
+        b->cur = b->arena;
+        b->level = 0;
+        b->n[0] = b->n_start[0]; b->n[1] = b->n_start[1];
+        const int rc = level_head(b);
+        if (rc) b->active = false;
+        return rc;
+    }
     if (hipEventSynchronize(b->ev[b->level]) != hipSuccess) { set_error("hpl_lattice_advance: event wait failed"); return HPL_EHIP; }
     int rc = level_tail(b);
     if (rc) { b->active = false; return rc; }

@@ -312,6 +312,13 @@ class _FlowNetBase(nn.Module):
         if not pc1.is_cuda:
             raise _lib.HplError('the HIP path needs device tensors (no CPU fallback)')
         native_lat = getattr(generated_data, 'device_lattice', None)       # lattice.NativeLattice
+        # a natively built lattice lives in one arena, usually allocated on the lattice stream: tell the allocator that this
+        # stream reads it, so that dropping the lattice right after the call cannot hand the memory to the next build early
+        arena = getattr(generated_data, 'arena', None)
+        if arena is None:
+            arena = getattr(generated_data, '_arena', None)
+        if arena is not None:
+            arena.record_stream(torch.cuda.current_stream(dev))
         if self.native_forward and self.pair_batched and not torch.is_grad_enabled() and \
                 (native_lat is not None or isinstance(generated_data, DeviceLattice)):
             plan = self.forward_plan()

@@ -18,6 +18,7 @@ them in steady state (bench.py and engine.Trainer feed the forward this way).
 import collections
 import ctypes
 import math
+import os
 
 import numpy as np
 import time
@@ -392,8 +393,10 @@ class NativeLattice(object):
                     cuts = list(t.up_group_cut[:t.n_up_groups + 1])
                     up._groups = [(cuts[g], cuts[g + 1], self._t(t.up_group_perm[g], torch.int32, (H0,)))
                                   for g in range(t.n_up_groups)]
-                    up._group_tiles = [(self._t(t.up_group_tidx[g], torch.int32, (tiles0, cuts[g + 1] - cuts[g], 64)),
-                                       self._t(t.up_group_tmask[g], torch.int32, (tiles0, 8))) for g in range(t.n_up_groups)]
+                    gbm = int(t.group_tile_bm) or 64          # (128: the split-operand kernel's tile height)
+                    tg = (H0 + gbm - 1) // gbm
+                    up._group_tiles = [(self._t(t.up_group_tidx[g], torch.int32, (tg, cuts[g + 1] - cuts[g], gbm)),
+                                       self._t(t.up_group_tmask[g], torch.int32, (tg, 8))) for g in range(t.n_up_groups)]
                 if t.up_perm:
                     up._perm = self._t(t.up_perm, torch.int32, (H0,))
                     up._perm_tiles = (self._t(t.up_perm_tidx, torch.int32, (tiles0, F, 64)),
@@ -455,10 +458,21 @@ class NativeBuilder(object):
         sp.groups_min_sparsity = NbrTable.GROUPS_MIN_SPARSITY
         sp.perm_min_rows = NbrTable.PERM_MIN_ROWS
         sp.group_tile_bm = ops.GROUP_TILE_BM
+        # fused driver (csrc/lattice_fused.hip): the whole build enqueued by hpl_lattice_begin, one read-back per pair.
+        # HPL_LATTICE_FUSED=0 keeps the staged driver (one read-back per level); specs it cannot build stay staged too.
+        self.fused = os.environ.get('HPL_LATTICE_FUSED', '1') != '0' and \
+            all(int(lvl[1]) == 1 and (int(lvl[2]), int(lvl[3])) in ((-1, -1), (1, 1)) for lvl in sfm) and \
+            os.environ.get('HPL_ROW_ORDER', '0') != '1'
+        sp.fused = 1 if self.fused else 0
         self.spec = sp
         self.free = []
-        self.bytes_per_point = 6000            # arena hint, doubled on HPL_ENOMEM
+        self.bytes_per_point = 6000            # arena hint of the staged driver, doubled on HPL_ENOMEM
         self.n_levels = n
+        # fused builds: per-level vertex bounds (per cloud) = twice the largest count seen so far, rounded up to a power of
+        # two (so that the arena layout changes rarely); 0 = the library's default of 16 x the cloud size
+        self.bounds = [0] * 8
+        self.seen = [0] * 8
+        self.fallbacks = 0
 
     def acquire(self):
         if self.free:
@@ -467,6 +481,16 @@ class NativeBuilder(object):
         if not h:
             raise _lib.HplError('hpl_lattice_create: %s' % self.lib.hpl_last_error().decode())
         return h
+
+    def observe(self, counts):
+        """Vertex counts of a finished pair -> the bounds of the next fused builds."""
+        for L, (h0, h1) in enumerate(counts):
+            m = max(h0, h1)
+            if m > self.seen[L]:
+                self.seen[L] = m
+                want = 1 << max(10, (2 * m - 1).bit_length())
+                if want > self.bounds[L] or self.bounds[L] == 0:
+                    self.bounds[L] = want
 
     def release(self, h):
         self.free.append(h)
@@ -496,8 +520,15 @@ class NativeLatticeBuild(object):
 
     def _begin(self):
         n0, n1 = int(self.pc[0].shape[1]), int(self.pc[1].shape[1])
+        lib = self.nb.lib
+        if self.nb.fused:
+            arr = (ctypes.c_int64 * 8)(*self.nb.bounds)
+            check(lib.hpl_lattice_set_bounds(self.handle, arr), 'hpl_lattice_set_bounds')
         while True:
             nbytes = (32 << 20) + self.nb.bytes_per_point * (n0 + n1)
+            if self.nb.fused:
+                # the fused layout is known up front; the staged fallback (a pair that outgrew a bound) reuses the arena
+                nbytes = max(nbytes, int(lib.hpl_lattice_arena_bytes(self.handle, n0, n1)) + 4096)
             with torch.cuda.stream(self.stream):
                 self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.pc[0].device)
                 rc = self.nb.lib.hpl_lattice_begin(self.handle, ptr(self.pc[0]), ptr(self.pc[1]), n0, n1,
@@ -530,6 +561,12 @@ class NativeLatticeBuild(object):
                 extras = (ctypes.c_void_p * (2 * n))()
                 used = ctypes.c_int64(0)
                 check(self.nb.lib.hpl_lattice_extras(self.handle, extras, ctypes.byref(used)), 'hpl_lattice_extras')
+                if self.nb.fused:
+                    st = (ctypes.c_int32 * 3)()
+                    self.nb.lib.hpl_lattice_stats(self.handle, st)
+                    self.nb.launches = int(st[0])
+                    self.nb.fallbacks += 0 if st[1] else 1
+                    self.nb.observe([(int(arr[L].H0), int(arr[L].H1)) for L in range(n)])
                 self.nb.release(self.handle)
                 self.handle = None
                 lat = NativeLattice(self.arena, arr, n, [int(e or 0) for e in extras], self.gen.wide_up)

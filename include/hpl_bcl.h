@@ -553,12 +553,23 @@ typedef struct hpl_lattice_spec {
     float groups_min_sparsity;                   /* groups only where H0 / n0 >= this */
     int64_t perm_min_rows;                       /* row orders only for tables with at least this many rows */
     int32_t group_tile_bm;                       /* tile height of the tap-group tile tables: 64 or 128 (0 = 64) */
+    int32_t fused;                               /* != 0: hpl_lattice_begin enqueues the whole build, the vertex counts stay on the
+                                                    device and are read back once (csrc/lattice_fused.hip); radius-1 specs only */
 } hpl_lattice_spec;
 
 typedef struct hpl_lattice hpl_lattice;   /* one pair under construction per builder; use several builders to overlap pairs */
 
 hpl_lattice *hpl_lattice_create(const hpl_lattice_spec *spec /* HOST */);
 void hpl_lattice_destroy(hpl_lattice *b);
+/* Fused builds size every array by a bound: a level's vertices per cloud <= min(4 x its input points, bounds[L]), bounds[L]
+ * = 0 meaning 16 x max(n0, n1).  hpl_lattice_arena_bytes: the arena a build of (n0, n1) points needs under the current bounds
+ * (0 for a staged builder: its arena is a guess that HPL_ENOMEM corrects).  A pair that outgrows a bound is rebuilt by the
+ * staged driver inside the same hpl_lattice_advance protocol (hpl_lattice_stats counts it), so bounds only cost memory and
+ * idle workgroups -- e.g. twice the largest counts seen so far.  hpl_lattice_stats: out[0] = kernel launches of the last
+ * fused enqueue, out[1] = 1 if the last finished build came from the fused driver, out[2] = builds of this handle that fell back to the staged one. */
+int64_t hpl_lattice_arena_bytes(const hpl_lattice *b, int64_t n0, int64_t n1);
+int hpl_lattice_set_bounds(hpl_lattice *b, const int64_t *bounds /* HOST, HPL_MAX_LEVELS entries, or NULL */);
+int hpl_lattice_stats(const hpl_lattice *b, int32_t *out /* HOST, 3 */);
 /* pc1 (3, n0), pc2 (3, n1) float32 DEVICE, must stay valid until the build is complete */
 int hpl_lattice_begin(hpl_lattice *b, const float *pc1, const float *pc2, int64_t n0, int64_t n1, void *arena,
                       int64_t arena_bytes, hplStream stream);
