@@ -19,6 +19,7 @@
 #include "lattice_fused.h"
 
 #include <limits.h>
+#include <stdlib.h>
 #include <string.h>
 
 using namespace hpl;
@@ -27,13 +28,12 @@ using namespace hpl::fused;
 
 namespace {
 
-constexpr int LSLOTS = 2048;            // LDS dedup table of the insert stage (256 points x 4 vertices, load <= 0.5)
 constexpr int SORT_CHUNK = 2048;        // rows per workgroup pass of the row sort (4 waves x 8 rounds x 64 lanes)
 constexpr int SCAN_CHUNK = 1024;        // elements per workgroup of the scans
 
 enum TaskKind {
     T_KEYS = 1, T_INSERT, T_FLAGS, T_IDS, T_OFF, T_BLUR, T_CORR2, T_CSR_SUMS, T_SORT1, T_CSR_SCAN, T_SORT2, T_FILL, T_TILE,
-    T_CSR_RANK, T_TILE_RANK
+    T_CSR_RANK, T_TILE_RANK, T_HIST2
 };
 
 struct Task {
@@ -84,6 +84,20 @@ __device__ __forceinline__ int block_scan_excl(int v, int *scr, int *total) {
     return base + inc - v;
 }
 
+// counter[idx] += 1 for every lane with `valid`; lanes of the wave that name the same counter are combined into ONE atomic
+// (most rows of a chunk carry the same key -- all 15 neighbours present -- and a per-lane atomicAdd would queue thousands of
+// operations on one address).  Must be reached by the whole wave.
+__device__ __forceinline__ void wave_count(int32_t *counter, int idx, bool valid) {
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lead_idx = __shfl(idx, leader, 64);
+        const unsigned long long same = __ballot(valid && idx == lead_idx);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&counter[lead_idx], (int)__popcll(same));
+        todo &= ~same;
+    }
+}
+
 __device__ __forceinline__ int block_sum(int v, int *scr) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -96,49 +110,55 @@ __device__ __forceinline__ int block_sum(int v, int *scr) {
 // ------------------------------------------------------------------------------------------------ phase 1: keys
 // keys + barycentric + el_minus_gr of both clouds (transforms.py:300-353), the joint key range (:384-385), and the
 // clearing of everything the later phases of this level accumulate into
-__device__ void task_keys(const Level &L, int b, int nblk, const Elev &E) {
+__device__ void task_keys(const Level &L, int b, int nblk, const Elev &E, int *scr) {
     const int n0 = npts(L, 0), n1 = npts(L, 1);
     const int t0 = b * 256 + threadIdx.x, nth = nblk * 256;
-    int lo[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX}, hi[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
-    for (int i = t0; i < n0 + n1; i += nth) {
-        const int c = i >= n0 ? 1 : 0;
-        const int p = c ? i - n0 : i, N = c ? n1 : n0;
-        float q[3];
-        if (L.pc[0]) {
-            const float *pc = L.pc[c];
-            q[0] = pc[p]; q[1] = pc[N + p]; q[2] = pc[2 * N + p];
-        } else {        // the points are the vertices of the level above (transforms.py:461-467)
-            const int32_t *vk = L.prev_vk[c];
-            const int64_t vs = L.prev_vstride[c];
-            float v[4];
+    // the points go to the first few workgroups (4 per lane): every workgroup that has points ends in 8 atomics on the
+    // SAME 8 words of the dims block, and a thousand of them would be a chain longer than the rest of the phase
+    const int pblk = min(nblk, max(1, dcdiv(n0 + n1, 1024)));
+    if (b < pblk) {
+        int lo[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX}, hi[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+        for (int i = t0; i < n0 + n1; i += pblk * 256) {
+            const int c = i >= n0 ? 1 : 0;
+            const int p = c ? i - n0 : i, N = c ? n1 : n0;
+            float q[3];
+            if (L.pc[0]) {
+                const float *pc = L.pc[c];
+                q[0] = pc[p]; q[1] = pc[N + p]; q[2] = pc[2 * N + p];
+            } else {        // the points are the vertices of the level above (transforms.py:461-467)
+                const int32_t *vk = L.prev_vk[c];
+                const int64_t vs = L.prev_vstride[c];
+                float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (float)vk[j * vs + p] / L.prev_div;
+                for (int j = 0; j < 4; ++j) v[j] = (float)vk[j * vs + p] / L.prev_div;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float acc = E.e[0 * 3 + k] * v[0];
-                acc = fmaf(E.e[1 * 3 + k], v[1], acc);
-                acc = fmaf(E.e[2 * 3 + k], v[2], acc);
-                acc = fmaf(E.e[3 * 3 + k], v[3], acc);
-                q[k] = acc;
+                for (int k = 0; k < 3; ++k) {
+                    float acc = E.e[0 * 3 + k] * v[0];
+                    acc = fmaf(E.e[1 * 3 + k], v[1], acc);
+                    acc = fmaf(E.e[2 * 3 + k], v[2], acc);
+                    acc = fmaf(E.e[3 * 3 + k], v[3], acc);
+                    q[k] = acc;
+                }
             }
+            lattice_point(q[0], q[1], q[2], p, N, L.scale, E, L.keys[c], L.bary[c], L.emg + (c ? 4 * (int64_t)n0 : 0), 4, lo, hi);
         }
-        lattice_point(q[0], q[1], q[2], p, N, L.scale, E, L.keys[c], L.bary[c], L.emg + (c ? 4 * (int64_t)n0 : 0), 4, lo, hi);
-    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {       // (lanes without points hold the neutral values)
-        int l = lo[j], h = hi[j];
+        for (int j = 0; j < 4; ++j) {       // (lanes without points hold the neutral values)
+            int l = lo[j], h = hi[j];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            l = min(l, __shfl_xor(l, o));
-            h = max(h, __shfl_xor(h, o));
+            for (int o = 32; o > 0; o >>= 1) {
+                l = min(l, __shfl_xor(l, o));
+                h = max(h, __shfl_xor(h, o));
+            }
+            if ((threadIdx.x & 63) == 0) { scr[(threadIdx.x >> 6) * 8 + j] = l; scr[(threadIdx.x >> 6) * 8 + 4 + j] = h; }
         }
-        lo[j] = l; hi[j] = h;
-    }
-    if ((threadIdx.x & 63) == 0 && lo[0] != INT_MAX) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            atomicMin(&L.dims[D_MM + j], lo[j]);
-            atomicMax(&L.dims[D_MM + 4 + j], hi[j]);
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const int j = threadIdx.x;
+            int v = scr[j];
+            for (int w = 1; w < 4; ++w) v = j < 4 ? min(v, scr[w * 8 + j]) : max(v, scr[w * 8 + j]);
+            if (j < 4) { if (v != INT_MAX) atomicMin(&L.dims[D_MM + j], v); }
+            else if (v != INT_MIN) atomicMax(&L.dims[D_MM + j], v);
         }
     }
 #pragma unroll
@@ -153,68 +173,40 @@ __device__ void task_keys(const Level &L, int b, int nblk, const Elev &E) {
     for (int q = 0; q < L.n_jobs; ++q) {
         const SortJob &J = L.job[q];
         const int ch = min(J.chunks_b, dcdiv(ne, SORT_CHUNK)) * 256;
-        for (int i = t0; i < ch; i += nth) { J.hist1[i] = 0; J.hist2[i] = 0; }
+        for (int i = t0; i < ch; i += nth) J.hist1[i] = 0;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ phase 2: insert
-// 256 points (1024 keys) per round: deduplicated in an LDS table first, only the distinct keys of the round CAS into the
-// cloud's global open-addressing table, each with the smallest entry index j = 4 * point + remainder seen (lattice.hip)
-__device__ void task_insert(const Level &L, int b, int nblk, char *smem) {
-    unsigned long long *lkeys = reinterpret_cast<unsigned long long *>(smem);     // [LSLOTS]
-    int *lmin = reinterpret_cast<int *>(smem + LSLOTS * 8);                          // [LSLOTS]
-    int *lglob = lmin + LSLOTS;                                                      // [LSLOTS]
+// One lane per entry j = 4 * point + remainder: CAS of the packed key into the cloud's open-addressing table, atomicMin of
+// j into the slot (the owner = first appearance).  The staged builder deduplicates 1024 keys in LDS first, which saves
+// global atomics; here the build is bound by the LENGTH of its dependency chains, not by atomic throughput (<= 2^18 keys),
+// and the direct form is two dependent global operations per lane instead of a workgroup-serial LDS round.
+__device__ void task_insert(const Level &L, int b, int nblk) {
     const int n0 = npts(L, 0), n1 = npts(L, 1);
-    const int ch0 = dcdiv(n0, 256), ch1 = dcdiv(n1, 256);
     const int32_t *mm = L.dims + D_MM;
-    for (int q = b; q < ch0 + ch1; q += nblk) {
-        const int c = q >= ch0 ? 1 : 0;
-        const int n = c ? n1 : n0;
+    const int nth = nblk * 256;
+    const uint64_t mask0 = (uint64_t)dev_pow2(8 * n0) - 1, mask1 = (uint64_t)dev_pow2(8 * n1) - 1;
+    for (int i = b * 256 + threadIdx.x; i < 4 * (n0 + n1); i += nth) {
+        const int c = i >= 4 * n0 ? 1 : 0;
+        const int j = c ? i - 4 * n0 : i, n = c ? n1 : n0;
         const int32_t *__restrict__ keys = L.keys[c];
         int64_t *__restrict__ tkeys = L.tkeys[c];
-        int32_t *__restrict__ tfirst = L.tfirst[c];
-        const uint64_t mask = (uint64_t)dev_pow2(8 * n) - 1;
-        for (int i = threadIdx.x; i < LSLOTS; i += 256) { lkeys[i] = (unsigned long long)EMPTY; lmin[i] = INT_MAX; }
-        __syncthreads();
-        const int pnt = (c ? q - ch0 : q) * 256 + threadIdx.x;
-        int ls[4] = {-1, -1, -1, -1};
-        if (pnt < n) {
+        const uint64_t mask = c ? mask1 : mask0;
+        const int p = j >> 2, r = j & 3;
+        int k[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int k[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) k[j] = keys[((int64_t)j * n + pnt) * 4 + r];
-                const unsigned long long packed = (unsigned long long)pack_key(k, mm);
-                int s = (int)(mix64(packed) & (LSLOTS - 1));
-                while (true) {
-                    const unsigned long long prev = atomicCAS(&lkeys[s], (unsigned long long)EMPTY, packed);
-                    if (prev == (unsigned long long)EMPTY || prev == packed) break;
-                    s = (s + 1) & (LSLOTS - 1);
-                }
-                atomicMin(&lmin[s], pnt * 4 + r);
-                ls[r] = s;
-            }
+        for (int x = 0; x < 4; ++x) k[x] = keys[((int64_t)x * n + p) * 4 + r];
+        const unsigned long long packed = (unsigned long long)pack_key(k, mm);
+        uint64_t sl = mix64(packed) & mask;
+        while (true) {
+            const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&tkeys[sl]),
+                                                      (unsigned long long)EMPTY, packed);
+            if (prev == (unsigned long long)EMPTY || prev == packed) break;
+            sl = (sl + 1) & mask;
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < LSLOTS; i += 256) {
-            const unsigned long long packed = lkeys[i];
-            if (packed == (unsigned long long)EMPTY) continue;
-            uint64_t s = mix64(packed) & mask;
-            while (true) {
-                const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&tkeys[s]),
-                                                          (unsigned long long)EMPTY, packed);
-                if (prev == (unsigned long long)EMPTY || prev == packed) break;
-                s = (s + 1) & mask;
-            }
-            atomicMin(&tfirst[s], lmin[i]);
-            lglob[i] = (int)s;
-        }
-        __syncthreads();
-        if (pnt < n) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) L.slot[c][pnt * 4 + r] = lglob[ls[r]];
-        }
-        __syncthreads();
+        atomicMin(&L.tfirst[c][sl], j);
+        L.slot[c][j] = (int)sl;
     }
 }
 
@@ -314,35 +306,68 @@ __device__ void task_blur(const Level &L, int b, int nblk, const Off15 &o) {
 #pragma unroll
     for (int q = 0; q < MAX_JOBS; ++q) rows[q] = q < L.n_jobs ? job_rows(L, L.job[q]) : 0;
     const int nth = nblk * 256;
-    for (int h = b * 256 + threadIdx.x; h < Hp; h += nth) {
-        const int c = h >= H0 ? 1 : 0;
-        const int hh = c ? h - H0 : h;
-        const int32_t *vk = L.vk[c];
-        const int64_t vs = L.vstride[c];
-        const int64_t *tkeys = L.tkeys[c];
-        const int32_t *tid = L.tid[c];
-        const uint64_t mask = (uint64_t)dev_pow2(8 * (c ? n1 : n0)) - 1;
-        const int shift = c ? H0 : 0;
-        int kv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) kv[j] = vk[j * vs + hh];
+    for (int h0 = b * 256; h0 < Hp; h0 += nth) {            // wave-uniform trip count (wave_count below)
+        const int h = h0 + threadIdx.x;
+        const bool valid = h < Hp;
         uint32_t bits = 0;
+        if (valid) {
+            const int c = h >= H0 ? 1 : 0;
+            const int hh = c ? h - H0 : h;
+            const int32_t *vk = L.vk[c];
+            const int64_t vs = L.vstride[c];
+            const int64_t *tkeys = L.tkeys[c];
+            const int32_t *tid = L.tid[c];
+            const uint64_t mask = (uint64_t)dev_pow2(8 * (c ? n1 : n0)) - 1;
+            const int shift = c ? H0 : 0;
+            int kv[4];
 #pragma unroll
-        for (int f = 0; f < 15; ++f) {
-            int k[4];
+            for (int j = 0; j < 4; ++j) kv[j] = vk[j * vs + hh];
+            // the 15 probes of a vertex are independent: hash all, load all first slots, load all ids; only a collision (rare
+            // at load <= 0.5) walks on.  One dependent round trip per vertex instead of fifteen.
+            int64_t pk[15];
+            uint32_t sl[15];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) k[j] = kv[j] + o.v[f * 4 + j];
-            const int32_t id = lookup(tkeys, tid, mask, pack_key(k, mm));
-            L.blur[(int64_t)f * Hp + h] = id >= 0 ? id + shift : -1;
-            bits |= id >= 0 ? (1u << f) : 0u;
+            for (int f = 0; f < 15; ++f) {
+                int k[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) k[j] = kv[j] + o.v[f * 4 + j];
+                pk[f] = pack_key(k, mm);
+                sl[f] = (uint32_t)(mix64((uint64_t)pk[f]) & mask);
+            }
+            int64_t k0[15], k1[15];
+#pragma unroll
+            for (int f = 0; f < 15; ++f) { k0[f] = tkeys[sl[f]]; k1[f] = tkeys[(sl[f] + 1) & (uint32_t)mask]; }
+            int32_t tv[15], tw[15];
+#pragma unroll
+            for (int f = 0; f < 15; ++f) { tv[f] = tid[sl[f]]; tw[f] = tid[(sl[f] + 1) & (uint32_t)mask]; }
+#pragma unroll
+            for (int f = 0; f < 15; ++f) {
+                int32_t id;
+                if (pk[f] < 0 || k0[f] == EMPTY) id = -1;                    // (keys of real vertices are >= 0)
+                else if (k0[f] == pk[f]) id = tv[f];
+                else if (k1[f] == EMPTY) id = -1;
+                else if (k1[f] == pk[f]) id = tw[f];
+                else {
+                    uint64_t x = ((uint64_t)sl[f] + 2) & mask;
+                    while (true) {
+                        const int64_t kk = tkeys[x];
+                        if (kk == pk[f]) { id = tid[x]; break; }
+                        if (kk == EMPTY) { id = -1; break; }
+                        x = (x + 1) & mask;
+                    }
+                }
+                L.blur[(int64_t)f * Hp + h] = id >= 0 ? id + shift : -1;
+                bits |= id >= 0 ? (1u << f) : 0u;
+            }
         }
 #pragma unroll
         for (int q = 0; q < MAX_JOBS; ++q) {
-            if (h >= rows[q]) continue;
+            if (rows[q] == 0) continue;                     // (uniform)
             const SortJob &J = L.job[q];
+            const bool mine = valid && h < rows[q];
             const uint32_t key = gray_rank((bits >> J.f0) & ((1u << J.F) - 1u));
-            J.key[h] = key;
-            atomicAdd(&J.hist1[(h / SORT_CHUNK) * 256 + (key & 255u)], 1);
+            if (mine) J.key[h] = key;
+            wave_count(J.hist1, (h / SORT_CHUNK) * 256 + (int)(key & 255u), mine);
         }
     }
 }
@@ -422,28 +447,48 @@ __device__ void task_fill(const Level &L, int b, int nblk) {
 }
 
 // a 16-lane group per vertex ranks the entries of its segment (ascending e: the summation order of the splat) and emits
-// (point, weight); then the density normaliser 1 / (sum + 1e-5) in that order (models/bilateralNN.py:168-183)
-__device__ void task_csr_rank(const Level &L, int b, int nblk) {
+// (point, weight); then the density normaliser 1 / (sum + 1e-5) in that order (models/bilateralNN.py:168-183).  Segments of
+// <= 16 entries (nearly all) live in the group's registers: ranks by shuffles, the ordered weights through LDS.
+__device__ void task_csr_rank(const Level &L, int b, int nblk, float *wbuf) {
     const int n0 = npts(L, 0), n1 = npts(L, 1), Hp = L.dims[D_H0] + L.dims[D_H1];
     const int ne0 = 4 * n0;
-    const int lg = threadIdx.x & 15;
+    const int lg = threadIdx.x & 15, grp = threadIdx.x >> 4, lane0 = threadIdx.x & 48;
     const int ngroups = nblk * 16;
-    for (int v0 = 0; v0 < Hp; v0 += ngroups) {        // uniform trip count: every lane reaches the fence
-        const int v = v0 + b * 16 + (threadIdx.x >> 4);
+    for (int v0 = 0; v0 < Hp; v0 += ngroups) {
+        const int v = v0 + b * 16 + grp;
         int bb = 0, ee = 0;
         if (v < Hp) { bb = L.csr_ptr[v]; ee = L.csr_ptr[v + 1]; }
-        for (int i = bb + lg; i < ee; i += 16) {
-            const int x = L.ent[i];
+        const int len = ee - bb;
+        if (len <= 16) {
+            const int x = lg < len ? L.ent[bb + lg] : INT_MAX;
             int rank = 0;
-            for (int j = bb; j < ee; ++j) rank += (L.ent[j] < x) ? 1 : 0;
-            L.csr_pt[bb + rank] = x < ne0 ? x % n0 : n0 + (x - ne0) % n1;
-            L.csr_w[bb + rank] = x < ne0 ? L.bary[0][x] : L.bary[1][x - ne0];
-        }
-        __threadfence_block();            // the group's stores, then its lane 0 reads them back
-        if (lg == 0 && v < Hp) {
-            float s = 0.f;
-            for (int i = bb; i < ee; ++i) s += *reinterpret_cast<volatile float *>(&L.csr_w[i]);
-            L.norm[v] = 1.0f / (s + 1e-5f);
+#pragma unroll
+            for (int o = 0; o < 16; ++o) rank += (__shfl(x, lane0 + o, 64) < x) ? 1 : 0;
+            if (lg < len) {
+                const float w = x < ne0 ? L.bary[0][x] : L.bary[1][x - ne0];
+                L.csr_pt[bb + rank] = x < ne0 ? x % n0 : n0 + (x - ne0) % n1;
+                L.csr_w[bb + rank] = w;
+                wbuf[grp * 16 + rank] = w;
+            }
+            if (lg == 0 && v < Hp) {            // (same wave: the LDS stores above are ordered before these loads)
+                float s = 0.f;
+                for (int i = 0; i < len; ++i) s += wbuf[grp * 16 + i];
+                L.norm[v] = 1.0f / (s + 1e-5f);
+            }
+        } else {
+            for (int i = bb + lg; i < ee; i += 16) {
+                const int x = L.ent[i];
+                int rank = 0;
+                for (int j = bb; j < ee; ++j) rank += (L.ent[j] < x) ? 1 : 0;
+                L.csr_pt[bb + rank] = x < ne0 ? x % n0 : n0 + (x - ne0) % n1;
+                L.csr_w[bb + rank] = x < ne0 ? L.bary[0][x] : L.bary[1][x - ne0];
+            }
+            __threadfence_block();            // the group's stores, then its lane 0 reads them back
+            if (lg == 0) {
+                float s = 0.f;
+                for (int i = bb; i < ee; ++i) s += *reinterpret_cast<volatile float *>(&L.csr_w[i]);
+                L.norm[v] = 1.0f / (s + 1e-5f);
+            }
         }
     }
 }
@@ -466,10 +511,15 @@ __device__ void task_sort(const Level &L, const SortJob &J, int pass, int b, int
     const bool to_tmp = pass == 1 && J.two_pass;
     for (int q = b; q < nch; q += nblk) {
         int before = 0, tot = 0;
-        for (int bb = 0; bb < nch; ++bb) {
-            const int v = hist[bb * 256 + d];
-            tot += v;
-            before += bb < q ? v : 0;
+        for (int b0 = 0; b0 < nch; b0 += 8) {          // 8 independent loads in flight
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = b0 + u < nch ? hist[(b0 + u) * 256 + d] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                tot += v[u];
+                before += b0 + u < q ? v[u] : 0;
+            }
         }
         const int ex = block_scan_excl(tot, scr, nullptr);
         base[d] = ex + before;
@@ -503,18 +553,44 @@ __device__ void task_sort(const Level &L, const SortJob &J, int pass, int b, int
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int row = q * SORT_CHUNK + w * 512 + s * 64 + lane;
-            if (row >= M) continue;
+            const bool valid = row < M;
             const uint32_t dg = pass == 1 ? (key[s] & 255u) : ((key[s] >> 8) & 255u);
             int pos = base[dg] + rw[s];
             for (int i = 0; i < w; ++i) pos += whist[i * 256 + dg];
-            if (to_tmp) {
-                J.tkey[pos] = key[s];
-                J.tval[pos] = val[s];
-                atomicAdd(&J.hist2[(pos / SORT_CHUNK) * 256 + ((key[s] >> 8) & 255u)], 1);
-            } else {
-                J.perm[pos] = val[s];
-            }
+            if (!valid) continue;
+            if (to_tmp) { J.tkey[pos] = key[s]; J.tval[pos] = val[s]; }
+            else J.perm[pos] = val[s];
         }
+        __syncthreads();
+    }
+}
+
+// digit counts of pass 2 per 2048-row chunk of pass 1's output (a phase of its own: counting them from pass 1's scatter
+// would be one atomic per row on a few hot words)
+__device__ void task_hist2(const Level &L, const SortJob &J, int b, int nblk, int *lh) {
+    const int M = job_rows(L, J);
+    if (M == 0 || !J.two_pass) return;
+    const int nch = dcdiv(M, SORT_CHUNK);
+    const int lane = threadIdx.x & 63;
+    for (int q = b; q < nch; q += nblk) {
+        lh[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int row = q * SORT_CHUNK + s * 256 + threadIdx.x;
+            const bool valid = row < M;
+            const uint32_t dg = valid ? ((J.tkey[row] >> 8) & 255u) : 0u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool one = (dg >> bit) & 1u;
+                const unsigned long long bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+            }
+            if (valid && lane == 63 - __clzll(peers)) atomicAdd(&lh[dg], (int)__popcll(peers));
+        }
+        __syncthreads();
+        J.hist2[q * 256 + threadIdx.x] = lh[threadIdx.x];
         __syncthreads();
     }
 }
@@ -594,7 +670,7 @@ __device__ void task_tile_rank(const Level &L, const SortJob &J, int *sm) {
 // ------------------------------------------------------------------------------------------------ the kernel
 __global__ void __launch_bounds__(256) k_lattice_fused(const Level *__restrict__ levels, const Launch l, const Elev E,
                                                        const Off15 o) {
-    __shared__ __attribute__((aligned(16))) char smem[LSLOTS * 16];        // 32 KB: the insert stage's tables; others use a corner
+    __shared__ __attribute__((aligned(16))) char smem[8192];        // the sort's digit bases and per-wave counts; scan scratch
     int ti = 0;
     for (int i = 1; i < l.n; ++i) ti = ((int)blockIdx.x >= l.t[i].blk0) ? i : ti;
     const Task t = l.t[ti];
@@ -603,8 +679,8 @@ __global__ void __launch_bounds__(256) k_lattice_fused(const Level *__restrict__
     const int b = (int)blockIdx.x - t.blk0;
     int *ism = reinterpret_cast<int *>(smem);
     switch (t.kind) {
-    case T_KEYS: task_keys(L, b, t.nblk, E); break;
-    case T_INSERT: task_insert(L, b, t.nblk, smem); break;
+    case T_KEYS: task_keys(L, b, t.nblk, E, ism); break;
+    case T_INSERT: task_insert(L, b, t.nblk); break;
     case T_FLAGS: task_flags(L, b, t.nblk, ism); break;
     case T_IDS: task_ids(L, b, t.nblk, ism); break;
     case T_OFF: task_off(L, b, t.nblk); break;
@@ -616,8 +692,9 @@ __global__ void __launch_bounds__(256) k_lattice_fused(const Level *__restrict__
     case T_SORT2: task_sort(L, L.job[t.job], 2, b, t.nblk, smem); break;
     case T_FILL: task_fill(L, b, t.nblk); break;
     case T_TILE: task_tile(L, L.job[t.job], b, t.nblk, ism); break;
-    case T_CSR_RANK: task_csr_rank(L, b, t.nblk); break;
+    case T_CSR_RANK: task_csr_rank(L, b, t.nblk, reinterpret_cast<float *>(smem)); break;
     case T_TILE_RANK: task_tile_rank(L, L.job[t.job], ism); break;
+    case T_HIST2: task_hist2(L, L.job[t.job], b, t.nblk, ism); break;
     default: break;
     }
 }
@@ -772,7 +849,7 @@ int enqueue(Plan &plan, Level *lv_stage, int32_t *dims_host, hipEvent_t counts_e
     const Offsets full = make_offsets(1);
     Off15 o;
     for (int i = 0; i < 60; ++i) o.v[i] = full.v[i];
-    const int n_launches = 4 * (nlev - 1) + 9;
+    const int n_launches = 4 * (nlev - 1) + 10;
     plan.launches = 1;
     for (int t = 0; t < n_launches; ++t) {
         Launch l;
@@ -786,13 +863,13 @@ int enqueue(Plan &plan, Level *lv_stage, int32_t *dims_host, hipEvent_t counts_e
         };
         for (int Li = 0; Li < nlev; ++Li) {
             const int k = t - 4 * Li;
-            if (k < 0 || k > 8) continue;
+            if (k < 0 || k > 9) continue;
             const Level &L = plan.lv[Li];
             const int64_t Nbp = (int64_t)L.nb[0] + L.nb[1], Hbp = (int64_t)L.Hb[0] + L.Hb[1];
             const int64_t capb = pow2_at_least(8 * (int64_t)L.nb[0]) + pow2_at_least(8 * (int64_t)L.nb[1]);
             switch (k) {
-            case 0: add(T_KEYS, Li, 0, clampi(cdiv(capb, 2048), 1, 256)); break;
-            case 1: add(T_INSERT, Li, 0, clampi(cdiv(L.nb[0], 256) + cdiv(L.nb[1], 256), 1, 512)); break;
+            case 0: add(T_KEYS, Li, 0, clampi(cdiv(capb, 512), 1, 1024)); break;
+            case 1: add(T_INSERT, Li, 0, clampi(cdiv(4 * Nbp, 256), 1, 2048)); break;
             case 2: add(T_FLAGS, Li, 0, clampi(cdiv(4 * Nbp, SCAN_CHUNK) + 1, 1, 512)); break;
             case 3: add(T_IDS, Li, 0, clampi(cdiv(4 * Nbp, SCAN_CHUNK) + 1, 1, 512)); break;
             case 4:
@@ -806,23 +883,48 @@ int enqueue(Plan &plan, Level *lv_stage, int32_t *dims_host, hipEvent_t counts_e
                 break;
             case 6:
                 add(T_CSR_SCAN, Li, 0, clampi(cdiv(Hbp, SCAN_CHUNK), 1, 256));
-                for (int q = 0; q < L.n_jobs; ++q)
-                    if (L.job[q].two_pass) add(T_SORT2, Li, q, clampi(L.job[q].chunks_b, 1, 256));
+                for (int q = 0; q < L.n_jobs; ++q) {
+                    if (L.job[q].two_pass) add(T_HIST2, Li, q, clampi(L.job[q].chunks_b, 1, 256));
+                    else add(T_TILE, Li, q, clampi(cdiv((int64_t)L.job[q].chunks_b * SORT_CHUNK, L.job[q].bm), 1, 1024));
+                }
                 break;
             case 7:
                 add(T_FILL, Li, 0, clampi(cdiv(4 * Nbp, 1024), 1, 256));
-                for (int q = 0; q < L.n_jobs; ++q)
-                    add(T_TILE, Li, q, clampi(cdiv((int64_t)L.job[q].chunks_b * SORT_CHUNK, L.job[q].bm), 1, 1024));
+                for (int q = 0; q < L.n_jobs; ++q) {
+                    if (L.job[q].two_pass) add(T_SORT2, Li, q, clampi(L.job[q].chunks_b, 1, 256));
+                    else add(T_TILE_RANK, Li, q, 1);
+                }
                 break;
             case 8:
                 add(T_CSR_RANK, Li, 0, clampi(cdiv(Hbp, 16), 1, 1024));
-                for (int q = 0; q < L.n_jobs; ++q) add(T_TILE_RANK, Li, q, 1);
+                for (int q = 0; q < L.n_jobs; ++q)
+                    if (L.job[q].two_pass) add(T_TILE, Li, q, clampi(cdiv((int64_t)L.job[q].chunks_b * SORT_CHUNK, L.job[q].bm), 1, 1024));
+                break;
+            case 9:
+                for (int q = 0; q < L.n_jobs; ++q)
+                    if (L.job[q].two_pass) add(T_TILE_RANK, Li, q, 1);
                 break;
             }
         }
         if (l.n == 0) continue;
+        static const int split = getenv("HPL_FUSED_SPLIT") ? atoi(getenv("HPL_FUSED_SPLIT")) : 0;
+        if (split) {        // diagnostic: every task as a launch of its own, so that a kernel trace times the tasks
+            static const char *names[] = {"", "keys", "insert", "flags", "ids", "off", "blur", "corr2", "csr_sums", "sort1", "csr_scan",
+                                          "sort2", "fill", "tile", "csr_rank", "tile_rank", "hist2"};
+            for (int i = 0; i < l.n; ++i) {
+                Launch one;
+                one.n = 1;
+                one.t[0] = l.t[i];
+                one.t[0].blk0 = 0;
+                k_lattice_fused<<<l.t[i].nblk, 256, 0, s>>>(plan.d_levels, one, E, o);
+                if (split > 1) fprintf(stderr, "launch %d task %s level %d job %d blocks %d\n", t, names[l.t[i].kind], l.t[i].level, l.t[i].job, l.t[i].nblk);
+            }
+            ++plan.launches;
+            goto after_launch;
+        }
         k_lattice_fused<<<blk, 256, 0, s>>>(plan.d_levels, l, E, o);
         ++plan.launches;
+    after_launch:
         if (t == 4 * (nlev - 1) + 3) {        // every level's vertex counts exist: start the one read-back of the build
             if (hipMemcpyAsync(dims_host, plan.d_dims, sizeof(int32_t) * DIM_INTS * (1 + nlev), hipMemcpyDeviceToHost, s) !=
                     hipSuccess ||
