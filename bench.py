@@ -99,48 +99,68 @@ class KernelTimers(object):
                 return out
             return inner
 
+        ef_cache = {}
+
+        def exec_frac(nbr, C, F, perm, rows):
+            """executed / algorithmic multiply-adds of a gathered launch: the kernels skip the MFMAs of a block of `rows` output
+            rows for the 32-wide contraction slices whose taps none of its rows has (host mirror: needed_slice_fraction)"""
+            if nbr is None or F == 1 or C < 32:
+                return 1.0
+            key = (nbr.data_ptr(), C, F, perm.data_ptr() if perm is not None else 0, rows)
+            if key not in ef_cache:
+                ef_cache[key] = needed_slice_fraction(types.SimpleNamespace(t=nbr, perm=perm), C, BM=rows)
+            return ef_cache[key]
+
         def d_gconv(A, nbr, M, C, F, Wt, N, **k):
             # suffix: g = gathered (15-tap stencil, template F_LDS=15), d = dense (F_LDS=1); gconv3_* = the split-operand
             # kernel (bf16 MFMA); flops = the fp32 multiply-adds the launch stands for (2*M*F*C*N)
             if k.get('Wt3') is not None and split3_takes(M, N, C, F, k.get('scat') is not None):
                 return ('gconv3_128x%d_%s%s' % (256 if -(-N // 256) * 256 * 100 <= -(-N // 128) * 128 * 108 else 128, 'g' if F > 1 else 'd', '' if M >= 16384 else '_mid'),
-                        2.0 * M * F * C * N, 0.0)
-            return ('gconv_%s_%s' % (gconv_class(M, N, F * C), 'g' if F > 1 else 'd'), 2.0 * M * F * C * N, 0.0)
+                        2.0 * M * F * C * N, 0.0, exec_frac(nbr, C, F, k.get('row_perm'), 64))
+            return ('gconv_%s_%s' % (gconv_class(M, N, F * C), 'g' if F > 1 else 'd'), 2.0 * M * F * C * N, 0.0,
+                    exec_frac(nbr, C, F, k.get('row_perm'), 32))
 
         # the HBM-bound gathers by lattice size: levels 0-2 of the N=8192 frustum move 10-140 MB per launch, the deeper
         # levels < 1 MB (pure launch latency) -- one class each, so that the big ones are not averaged away
         def d_splat(feat, csr, H, use_norm=True, out=None):
             N, C = feat.shape
-            return ('splat' if H >= 8192 else 'splat_deep', 0.0, 4.0 * C * N + 32.0 * N + 4.0 * (C + 1) * (H + 1))
+            return ('splat' if H >= 8192 else 'splat_deep', 0.0, 4.0 * C * N + 32.0 * N + 4.0 * (C + 1) * (H + 1), 1.0)
 
         def d_slice(Y, bary, off, N, vscale=None, bias=None, out=None):
             H, C = Y.shape
-            return ('slice' if H >= 8192 else 'slice_deep', 0.0, 4.0 * C * H + 32.0 * N + 4.0 * C * N)
+            return ('slice' if H >= 8192 else 'slice_deep', 0.0, 4.0 * C * H + 32.0 * N + 4.0 * C * N, 1.0)
 
         ops.gconv_raw = wrap(ops.gconv_raw, d_gconv)
         ops.splat_raw = wrap(ops.splat_raw, d_splat)
         ops.slice_raw = wrap(ops.slice_raw, d_slice)
 
     def summary(self, steps):
+        """Every `frac` of the gather-GEMM classes is the SAME quantity as roofline.frac: matrix-pipe busy time / launch time
+        = executed MFMA flops (absent-neighbour blocks skipped: host mirror of the kernels' slice lists; split classes: 6 bf16
+        MFMA flops per executed fp32 multiply-add) / launch time / the pipe's peak.  The rate of the multiply-adds the
+        REFERENCE performs stays under f32_equivalent_algorithmic_tflops."""
         if not self.records:
             return {}
         agg = {}
-        for (name, flops, nbytes), s, e in self.records:
-            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        for (name, flops, nbytes, ef), s, e in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += s.elapsed_time(e)         # ms
             a[2] += flops
             a[3] += nbytes
+            a[4] += flops * ef
         out = {}
-        for name, (cnt, ms, flops, nbytes) in sorted(agg.items()):
+        for name, (cnt, ms, flops, nbytes, flops_ex) in sorted(agg.items()):
             d = {'launches_per_step': cnt / float(steps), 'avg_launch_us': 1e3 * ms / cnt,
                  'ms_per_step': ms / steps}
             if flops:
-                # fp32-equivalent algorithmic rate; the split-operand classes are priced against the bf16 peak / 6
                 split = name.startswith('gconv3_')
-                d.update(bound='mfma', achieved=flops / (ms * 1e-3) / 1e12,
-                         peak=MFMA_BF16_PEAK_TFLOPS / SPLIT3_PRODUCTS if split else MFMA_F32_PEAK_TFLOPS,
-                         unit='TFLOP/s (fp32-equivalent, algorithmic)', gflop_per_step=flops / steps / 1e9,
+                ef = flops_ex / flops
+                alg = flops / (ms * 1e-3) / 1e12                       # fp32 multiply-adds of the reference per second
+                peak = MFMA_BF16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+                executed = alg * ef * (SPLIT3_PRODUCTS if split else 1)   # MFMA flops actually issued per second
+                d.update(bound='mfma', achieved=executed, peak=peak, unit='TFLOP/s (executed MFMA flops: %s)' % ('bf16' if split else 'fp32'),
+                         executed_fraction=ef, f32_equivalent_algorithmic_tflops=alg, gflop_per_step=flops / steps / 1e9,
                          path='3 x bf16 split operands on the bf16 MFMA' if split else 'fp32 MFMA')
             else:
                 d.update(bound='hbm', achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
@@ -340,20 +360,25 @@ def source_stamp():
     h = hashlib.sha256()
     for f in ('gconv.hip', 'gconv3.hip', 'gconv_common.h', 'executor.hip', 'row_order.hip'):
         h.update(open(os.path.join(ROOT, 'hplflownet_amd', 'csrc', f), 'rb').read())
-    for k in ('HPL_MATH', 'HPL_SPLIT3_BN', 'HPL_TAP_GROUPS', 'HPL_TILE', 'HPL_WG3', 'HPL_PERSISTENT', 'HPL_SPLIT3_MIN_ROWS', 'HPL_SPLIT3_MIN_ROWS_STENCIL',
+    for k in ('HPL_MATH', 'HPL_SPLIT3_BN', 'HPL_TAP_GROUPS', 'HPL_TILE', 'HPL_WG3', 'HPL_SPLIT3_MIN_ROWS', 'HPL_SPLIT3_MIN_ROWS_STENCIL',
               'HPL_SPLIT3_NB', 'HPL_SPLIT3_BN256_PCT', 'HPL_SPLIT3_MID_SPLITK', 'HPL_ROW_ORDER', 'HPL_FUSE_NARROW', 'HPL_SPLIT3_EPILOGUE',
               'HPL_GCONV_EPILOGUE'):
         h.update(('%s=%s;' % (k, os.environ.get(k, ''))).encode())
     return h.hexdigest()
 
 
-def host_report(host, steps):
-    """Host wall time per step inside the timed loop, and how much of it was the thread sitting idle because the
-    GPU is the limiter (waiting for a lattice's vertex counts / for a free workspace slot): busy_ms is what the
-    host would need per step if the GPU were infinitely fast."""
+def host_report(host, steps, threaded=False):
+    """Host wall time per step inside the timed loop.  lattice_build_ms: the main thread inside pipe.get() (the enqueue of
+    a build when it drives the builds itself; with the producer thread: waiting for the queue); forward_enqueue_ms: inside
+    the forward call (incl. forward_wait_ms, waiting for a free workspace slot = the GPU is the limiter);
+    lattice_wait_ms: the MAIN thread blocked because no finished lattice was there; lattice_producer_idle_ms: the producer
+    thread waiting for the one count read-back of the pair it builds ahead (idle by design: it runs pairs ahead of the
+    consumer); busy_ms: what the main thread would need per step if the GPU were infinitely fast."""
     from hplflownet_amd import lattice as lat_mod, plan as plan_mod
     d = {k: v / steps for k, v in host.items()}
-    d['lattice_wait_ms'] = lat_mod.WAIT['s'] * 1e3 / steps
+    spin = lat_mod.WAIT['s'] * 1e3 / steps
+    d['lattice_wait_ms'] = d['lattice_build_ms'] if threaded else spin
+    d['lattice_producer_idle_ms'] = spin if threaded else 0.0
     d['forward_wait_ms'] = plan_mod.WAIT['s'] * 1e3 / steps
     d['busy_ms'] = d['lattice_build_ms'] + d['forward_enqueue_ms'] - d['lattice_wait_ms'] - d['forward_wait_ms']
     return d
@@ -486,7 +511,7 @@ def main():
     fwd_streams = [torch.cuda.Stream(device=dev, priority=-1 if prio == 'forward' else 0) for _ in range(n_fwd)] \
         if overlap else None
 
-    def run_pipelined(first, count):
+    def run_pipelined(first, count, fixed=None):
         """count steps; the lattices of the next pairs are built on a second HIP stream while the forward
         of pair i runs on the main streams (the reference overlaps the same two stages with DataLoader
         worker processes, main.py:85-92); up to --lattice-depth pairs are under construction at once so
@@ -495,11 +520,18 @@ def main():
         import collections
         from hplflownet_amd.lattice import LatticePipeline
 
-        pipe = LatticePipeline(gen, lambda i: pairs[i % a.pool], first, count, depth=a.lattice_depth, stream=side,
-                               for_training=a.train, native=native and not a.python_lattice,
-                               threaded=native and not a.python_lattice and a.lattice_thread)
+        pipe = None if fixed is not None else LatticePipeline(
+            gen, lambda i: pairs[i % a.pool], first, count, depth=a.lattice_depth, stream=side, for_training=a.train,
+            native=native and not a.python_lattice, threaded=native and not a.python_lattice and a.lattice_thread)
+        done_ev = torch.cuda.Event()
+        done_ev.record()
+        nxt = [first]
 
         def build():
+            if fixed is not None:                  # (forward-only rate: the same loop on lattices that exist already)
+                i = nxt[0]
+                nxt[0] += 1
+                return i, fixed[i % a.pool], done_ev
             t = time.perf_counter()
             (i, _), lat, ev = pipe.get()
             host['lattice_build_ms'] += (time.perf_counter() - t) * 1e3
@@ -570,6 +602,32 @@ def main():
             native_prof = plan.profile_read()
         parallel.barrier()
         elapsed = parallel.max_over_ranks(elapsed, device=dev)
+        host_line = host_report(host, a.steps, threaded=native and not a.python_lattice and a.lattice_thread) if overlap else None      # (the regions below run the same loop: snapshot first)
+        # The contract times EXACTLY --steps steps; a short region (the driver passes 20: 60 ms) is at the mercy of one
+        # scheduling hiccup, so a second region of >= 1 s of the same loop is timed right behind it and reported beside it
+        steady = None
+        if overlap and not a.train and elapsed < 1.0:
+            n2 = max(a.steps, int(1.2 * a.steps / max(elapsed, 1e-3)))
+            sync_all()
+            t1 = time.perf_counter()
+            run_pipelined(PREWARM + a.warmup + a.steps, n2)
+            torch.cuda.synchronize()
+            e2 = parallel.max_over_ranks(time.perf_counter() - t1, device=dev)
+            steady = {'steps': n2, 'value': world * n2 / e2, 'ms_per_step': 1e3 * e2 / n2,
+                      'note': 'the same pipelined loop over >= 1 s, timed right behind the contract region of %d steps' % a.steps}
+        # forward-only rate: the same streams and loop on lattices that already exist (what the lattice build costs the step)
+        fwd_only = None
+        if overlap and not a.train:
+            fixed = [gen.build_native(p1, p2) if native and not a.python_lattice else gen.build(p1, p2) for p1, p2 in pairs]
+            n3 = max(20, min(a.steps, 200))
+            run_pipelined(0, 6, fixed=fixed)
+            sync_all()
+            t1 = time.perf_counter()
+            run_pipelined(0, n3, fixed=fixed)
+            torch.cuda.synchronize()
+            e3 = parallel.max_over_ranks(time.perf_counter() - t1, device=dev)
+            fwd_only = {'steps': n3, 'pairs_per_s': world * n3 / e3, 'ms_per_step': 1e3 * e3 / n3}
+            del fixed
 
     # the pipelined loop's last output against a plain single-stream forward of the same pair (inference)
     pipe_check = None
@@ -636,7 +694,7 @@ def main():
         # v_mfma_f32_32x32x2_f32 (4096 flop), 32 per v_mfma_f32_32x32x16_bf16 (32768 flop) -- at 2.4 GHz on 1024 SIMDs that is
         # the 157.3 TF fp32 / 2.5 PF bf16 datasheet peaks.  achieved = executed MFMA flops per launch / launch duration;
         # frac = achieved / peak = busy cycles / (1024 SIMDs x duration x 2.4 GHz), a fraction <= 1 whatever the operand type.
-        # The executed work per launch is MEASURED (rocprofv3 --pmc on this command, tools/pmc_mfma.py -> profiles/r03_mfma_pmc.json,
+        # The executed work per launch is MEASURED (rocprofv3 --pmc on this command, tools/pmc_mfma.py -> profiles/mfma_pmc.json,
         # used only when its stamp matches the kernel sources and tile configuration of this run) or, failing that, mirrored
         # on the host from the lattice tables (the kernel skips the MFMAs of a wave's 64 rows -- 32 in the fp32 kernel -- for slices whose taps they lack).
         wide = [(0, 580, 1024), (1, 324, 512)] if full else []
@@ -664,22 +722,22 @@ def main():
             busy_per_launch = mirror_gf * 1e9 * products / flop_per_busy / lps                # matrix-pipe cycles per launch
             src = 'host mirror of the kernel\'s slice lists and %d-row block masks (bench.needed_slice_fraction)' % skip_rows
             stamp = source_stamp()
-            pmc_path = os.path.join(ROOT, 'profiles', 'r03_mfma_pmc.json')
+            pmc_path = os.path.join(ROOT, 'profiles', 'mfma_pmc.json')
             pmc_note = None
             if os.path.exists(pmc_path) and a.points == 8192 and a.data == 'frustum' and not a.train:
                 try:
                     pj = json.load(open(pmc_path))
                     if pj.get('stamp') != stamp:
-                        pmc_note = 'profiles/r03_mfma_pmc.json ignored: it was taken with other kernel sources / configuration'
+                        pmc_note = 'profiles/mfma_pmc.json ignored: it was taken with other kernel sources / configuration'
                     elif abs(pj['dominant_launches_per_step'] - lps) > 1e-6:
-                        pmc_note = 'profiles/r03_mfma_pmc.json ignored: another tap-group schedule'
+                        pmc_note = 'profiles/mfma_pmc.json ignored: another tap-group schedule'
                     elif abs(pj['dominant_busy_cycles_per_launch'] / busy_per_launch - 1.0) > 0.05:
-                        pmc_note = ('profiles/r03_mfma_pmc.json ignored: its executed work (%.4g pipe cycles per launch) and the host '
+                        pmc_note = ('profiles/mfma_pmc.json ignored: its executed work (%.4g pipe cycles per launch) and the host '
                                     'mirror (%.4g) disagree by more than 5 %%' % (pj['dominant_busy_cycles_per_launch'], busy_per_launch))
                     else:
                         roofline['executed_host_mirror_busy_cycles'] = busy_per_launch
                         busy_per_launch = pj['dominant_busy_cycles_per_launch']
-                        src = 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES (profiles/r03_mfma_pmc.json, stamp %s)' % stamp[:12]
+                        src = 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES (profiles/mfma_pmc.json, stamp %s)' % stamp[:12]
                         if pj.get('busy_cycles_per_step'):
                             # the whole step against the same roofline: matrix-pipe cycles of ALL kernels of one pair / step time
                             t_step = elapsed / a.steps / world
@@ -689,7 +747,7 @@ def main():
                                 'note': 'matrix-pipe cycles of all kernels of one pair (PMC) / (1024 SIMDs x ms_per_step x 2.4 GHz), per GPU'}
                             del t_step
                 except Exception as e_:
-                    pmc_note = 'profiles/r03_mfma_pmc.json unreadable: %s' % e_
+                    pmc_note = 'profiles/mfma_pmc.json unreadable: %s' % e_
             if pmc_note:
                 roofline['pmc_note'] = pmc_note
 
@@ -766,10 +824,14 @@ def main():
                            'forward_issue': 'one native hpl_plan_run per pair' if native else 'python, launch by launch',
                            'lattice_issue': ('native builder (hpl_lattice_*)' + (' on a producer thread' if a.lattice_thread else ''))
                            if (native and not a.python_lattice and overlap) else 'python, stage by stage',
+                           'lattice_driver': (lambda nb: {'fused': bool(nb.fused), 'launches_per_pair': getattr(nb, 'launches', None) if nb.fused else '~260 (staged: one count read-back per level)',
+                                                          'count_readbacks_per_pair': 1 if nb.fused else len(sfm), 'staged_fallbacks': nb.fallbacks,
+                                                          'vertex_bounds_per_cloud': list(nb.bounds[:len(sfm)]) if nb.fused else None})(gen.native_builder())
+                           if (native and not a.python_lattice) else None,
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,
-                'host_ms_per_step': host_report(host, a.steps) if overlap else None,
+                'host_ms_per_step': host_line, 'steady': steady, 'forward_only': fwd_only,
                 'pipelined_output_check': pipe_check, 'single_pair_latency_ms': latency,
                 'device_memory_mb': {'max_allocated': torch.cuda.max_memory_allocated(dev) / 2 ** 20,
                                      'reserved': torch.cuda.memory_reserved(dev) / 2 ** 20}}

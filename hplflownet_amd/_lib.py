@@ -112,7 +112,6 @@ _SIGNATURES = {
                                            c_vp]),
     'hpl_tile_index': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_vp, c_vp, c_vp]),
     'hpl_gconv_forward': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
-    'hpl_set_persistent': (ctypes.c_int, [ctypes.c_int]),
     'hpl_gconv_forward_naive': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
     'hpl_gconv_wgrad': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,
                                        c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),

@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
         const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
             p.res ? (void *)const_cast<float *>(p.res) : (void *)p.Y, (short)0, p.res ? 0x7fffffff : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(
-            p.Y2 ? (void *)p.Y2 : (void *)p.Y, (short)0, p.Y2 ? 0x7fffffff : 0, 0x00020000);
+            p.Y2 ? (void *)p.Y2 : (void *)p.Y, (short)0, (p.Y2 && p.splits <= 1) ? 0x7fffffff : 0, 0x00020000);   // (split-K partials never go to Y2: k_gconv_finish writes it)
         const unsigned ldy_b = (unsigned)(p.splits > 1 ? p.N : p.ldy) * 4u, ldr_b = (unsigned)p.ldres * 4u, ldy2_b = (unsigned)p.ldy2 * 4u;
         const bool plain = p.splits <= 1;
         const bool res_wrap = p.res && p.res_mod < p.M;      // (uniform)
@@ -727,375 +727,6 @@ __global__ void k_gconv_naive(const GParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Persistent variant of k_gconv for the big row-ordered launches (bcn1_ / bcn2_ blur convs): 2 workgroups per CU
-// stay resident and pull (column tile, tile-row) items from one queue per XCD (column-major, heaviest tile-rows
-// first -- the order tile_coords gives the one-tile-per-workgroup grid).  Measured on the one-tile kernel
-// (profiles/r02e_tile_timing.txt): 6 % of a workgroup's life is its prologue, the slots sit empty 9 % of the
-// kernel (dispatch gaps between tiles, tail).  Here the stream of contraction slices simply continues across
-// tiles: the next tile's indices are staged into a second LDS index buffer during the current tile's main loop
-// and the look-ahead loads of its first slices are issued from the current tile's last steps, so a tile switch
-// costs the epilogue only.  Same arithmetic in the same order per output element: results are bit-identical.
-// ------------------------------------------------------------------------------------------
-constexpr int PERS_CTR_SLOTS = 1024;      // ring of counter sets, one per launch in flight
-constexpr int PERS_CTR_INTS = 16;         // 8 queue heads (+ padding), zeroed by the host before each launch
-
-template <int BM, int BN, int WGM, int WGN>
-__global__ void __launch_bounds__(64 * WGM * WGN, 4) k_gconv_pers(const GParams p, int *ctr) {
-    constexpr int F_LDS = 15;
-    constexpr int NT = 64 * WGM * WGN;
-    constexpr int WTM = BM / WGM, WTN = BN / WGN;
-    static_assert(WTM == 32 && WTN == 32, "one 32x32 MFMA tile per wave");
-    constexpr int LDA_S = BM + 2, LDB_S = BN;
-    constexpr int A_ROWS_PER_PASS = NT / 8, A_PASSES = BM / A_ROWS_PER_PASS;
-    constexpr int B_F4_PER_ROW = BN / 4, B_ROWS_PER_PASS = NT / B_F4_PER_ROW, B_PASSES = BK / B_ROWS_PER_PASS;
-    static_assert(A_PASSES == 1, "512 threads stage one float4 of the 64 x 32 slice each");
-    constexpr int KLIST = 1024;
-    constexpr int IDX_INTS = F_LDS * BM + BM + 8;            // Is | Vs | masks ([0] taps, [1] slices, [2..5] block masks)
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA_S + 2 * BK * LDB_S + 2 * IDX_INTS + KLIST + 8];
-    float *As = smem;
-    float *Bs = smem + 2 * BK * LDA_S;
-    int *Idx = reinterpret_cast<int *>(smem + 2 * BK * LDA_S + 2 * BK * LDB_S);
-    unsigned short *KsAll = reinterpret_cast<unsigned short *>(Idx + 2 * IDX_INTS);       // 2 x KLIST ushorts
-    int *qslot = reinterpret_cast<int *>(KsAll + 2 * KLIST);                               // pulled queue items
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int li = lane & 31, hi = lane >> 5;
-    const int kq = t & 7, arow0 = t >> 3;
-    const int bn4 = t % B_F4_PER_ROW, brow0 = t / B_F4_PER_ROW;
-    const int wave_brow0 = (wave * 64) / B_F4_PER_ROW;
-
-    const int xq = blockIdx.x & 7;                          // queue of this workgroup (= its XCD as dispatched today)
-    int *head = ctr + xq;
-
-    const bool probe = p.clock_probe && (blockIdx.x & 63) == 0 && t == 0;
-    long long probe_c = 0, probe_w = 0;
-    if (probe) { probe_c = (long long)__builtin_readcyclecounter(); probe_w = (long long)__builtin_amdgcn_s_memrealtime(); }
-
-    constexpr unsigned OOB = 0x80000000u;
-    const int32x4_t rsrc_a = make_rsrc(p.A, (int)p.a_bytes);
-    const __amdgpu_buffer_rsrc_t lrsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.Wt), (short)0,
-                                                                           (int)p.w_bytes, 0x00020000);
-    const unsigned lda_b = (unsigned)p.lda * 4u, ldw_b = (unsigned)p.ldw * 4u;
-    const int C = p.C, F = p.F;
-    const bool blockskip = C >= BK;
-
-    // ---- per-tile context
-    struct Ctx { int tm, tn, nsl; bool valid; };
-    auto make_ctx = [&](int q) {                             // queue item -> tile (column-major: see tile_coords)
-        Ctx c;
-        c.tm = c.tn = c.nsl = 0;
-        c.valid = false;
-        if (q < 0) return c;
-        const int col_share = p.col_share, tiles_m = p.tiles_m;
-        const int vcols = p.tiles_n * col_share / 8;
-        int v = xq * vcols;
-        for (int i = 0; i < vcols; ++i, ++v) {
-            const int s = v % col_share;
-            const int n = s < tiles_m ? (tiles_m - s + col_share - 1) / col_share : 0;
-            if (q < n) {
-                c.tn = v / col_share;
-                c.tm = __builtin_amdgcn_readfirstlane(p.tile_mask[(int64_t)(q * col_share + s) * 8 + 6]);    // heaviest first
-                c.valid = true;
-                break;
-            }
-            q -= n;
-        }
-        return c;
-    };
-    // this thread's byte offset of its weight-row float4 inside the tile's column panel (OOB past the image)
-    auto boff_of = [&](const Ctx &c) {
-        const int col = c.tn * BN + bn4 * 4;
-        return (c.valid && col < p.ldw) ? (unsigned)brow0 * ldw_b + (unsigned)col * 4u : OOB;
-    };
-    // staging of a tile's indices into LDS index buffer ibuf + its slice list (synchronous: two barriers)
-    auto stage = [&](Ctx &c, int ibuf) {
-        if (!c.valid) return;
-        int *I = Idx + ibuf * IDX_INTS;
-        const int32_t *ti = p.tile_idx + (int64_t)c.tm * F * BM;
-        for (int e = t; e < F_LDS * BM; e += NT) I[e] = (e < F * BM) ? ti[e] : -1;
-        if (t < BM) {
-            const int64_t m = (int64_t)c.tm * BM + t;
-            I[F_LDS * BM + t] = (m < p.M) ? p.row_perm[m] : -1;
-        }
-        if (t < 8) I[F_LDS * BM + BM + t] = p.tile_mask[(int64_t)c.tm * 8 + t];
-        __syncthreads();
-        if (wave == 0) {
-            unsigned short *Ks = KsAll + ibuf * KLIST;
-            const int tapmask = __builtin_amdgcn_readfirstlane(I[F_LDS * BM + BM]);
-            const int nk = (p.K + BK - 1) / BK;
-            int count = 0;
-            for (int base = 0; base < nk; base += 64) {
-                const int kt = base + lane;
-                bool need = false;
-                int f_lo = 0;
-                if (kt < nk) {
-                    f_lo = (kt * BK) / C;
-                    const int f_hi = min((kt * BK + BK - 1) / C, F - 1);
-                    int bits = 0;
-                    for (int f = f_lo; f <= f_hi; ++f) bits |= 1 << f;
-                    need = (tapmask & bits) != 0;
-                }
-                const unsigned long long bal = __ballot(need);
-                if (need) {
-                    int e = kt;
-                    if (blockskip) e |= (f_lo << 10) | (((kt * BK + BK - 1) / C > f_lo && f_lo + 1 < F) ? (1 << 14) : 0);
-                    Ks[count + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)e;
-                }
-                count += __popcll(bal);
-            }
-            if (lane == 0) I[F_LDS * BM + BM + 1] = count;
-        }
-        __syncthreads();
-        c.nsl = __builtin_amdgcn_readfirstlane(I[F_LDS * BM + BM + 1]);
-    };
-
-    // ---- the slice stream: slice j of the current tile, continuing into the next tile's list when linked
-    Ctx cur, nxt;
-    int ib = 0;                       // index buffer of `cur`; `nxt` uses ib ^ 1
-    bool link = false;                // the stream continues from cur into nxt (both staged, both >= 3 slices)
-    unsigned boff_cur = OOB, boff_nxt = OOB;
-
-    float4 ra[2];
-    int f0_u = 0, c0_u = 0, k_u = 1 << 30, f_t = 0, c_t = 0, row_n = -1;
-    bool load_ok = false;
-    // Stream entries: list entry (bits 0..14) | 1 << 15 (valid) | 1 << 16 (belongs to the NEXT tile: its index buffer,
-    // its weight columns).  lookup(j): stream position j >= 0 counted from the current tile's first slice.
-    constexpr int E_OK = 1 << 15, E_NXT = 1 << 16;
-    auto lookup = [&](int j) -> int {
-        if (j < cur.nsl) return (int)KsAll[ib * KLIST + j] | E_OK;
-        if (link) return (int)KsAll[(ib ^ 1) * KLIST + (j - cur.nsl)] | E_OK | E_NXT;
-        return 0;
-    };
-    auto load_begin = [&](int E) {
-        load_ok = (E & E_OK) != 0;
-        const int k0 = (E & 1023) * BK;
-        if (k0 < k_u) { f0_u = k0 / C; c0_u = k0 - f0_u * C; }              // a new tile: its list starts over
-        else { c0_u += k0 - k_u; while (c0_u >= C) { c0_u -= C; ++f0_u; } }
-        k_u = k0;
-        c_t = c0_u + kq * 4;
-        f_t = f0_u;
-        while (c_t >= C) { c_t -= C; ++f_t; }
-        const int ibuf = (E & E_NXT) ? (ib ^ 1) : ib;
-        row_n = Idx[ibuf * IDX_INTS + min(f_t, F_LDS - 1) * BM + arow0];
-    };
-    auto load_a = [&](float4 &dst) {
-        const bool ok = load_ok && (f_t < F) && (row_n >= 0);
-        const unsigned off = ok ? (unsigned)row_n * lda_b + (unsigned)c_t * 4u : OOB;
-        const float4_t v = buffer_load_f32x4(rsrc_a, (int)off, 0, 0);
-        dst = make_float4(v.x, v.y, v.z, v.w);
-    };
-    auto load_b_lds = [&](int buf, int E, int i) {
-        const unsigned base = (E & E_NXT) ? boff_nxt : boff_cur;
-        const unsigned off = ((E & E_OK) && base != OOB) ? base + (unsigned)((E & 1023) * BK + i * B_ROWS_PER_PASS) * ldw_b : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            lrsrc_b,
-            (__attribute__((address_space(3))) void *)(Bs + buf * BK * LDB_S + (wave_brow0 + i * B_ROWS_PER_PASS) * LDB_S),
-            16, (int)off, 0, 0, 0);
-    };
-    auto store_a = [&](const float4 &src, int buf) {
-        float *a = As + buf * BK * LDA_S;
-        a[(kq * 4 + 0) * LDA_S + arow0] = src.x;
-        a[(kq * 4 + 1) * LDA_S + arow0] = src.y;
-        a[(kq * 4 + 2) * LDA_S + arow0] = src.z;
-        a[(kq * 4 + 3) * LDA_S + arow0] = src.w;
-    };
-
-    floatx16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    int cbuf = 0;                     // LDS operand buffer holding the slice being multiplied
-    int bmask = 0;
-
-    // One contraction step (P = parity of the global step count, compile time): multiply slice ts (entry E0, LDS buffer
-    // cbuf), load slice ts+2 (E2) into register set P, stage slice ts+1 (E1: register set 1-P, weights by LDS-DMA) into
-    // the other buffer.  The entries form a shift register: one list lookup per step, at its top.
-    int E0 = 0, E1 = 0, E2 = 0;
-    auto step = [&](int ts, auto parity_tag) {
-        constexpr int P = decltype(parity_tag)::value;
-        E2 = lookup(ts + 2);
-        auto pieces = [&](int kk) {
-            if (kk >= 1 && kk - 1 < B_PASSES) load_b_lds(cbuf ^ 1, E1, kk - 1);
-            if (kk == 0) load_begin(E2);
-            if (kk == 6) {
-                // keep the registers of set P reserved from their last use to this load: if the allocator hands them
-                // out as temporaries in between, it must first wait for EVERY load in flight (vmcnt(0) at the top of
-                // each step -- the look-ahead of two slices collapses to half a step; measured 5450 vs 4220 cycles/slice)
-                asm volatile("" : "+v"(ra[P].x), "+v"(ra[P].y), "+v"(ra[P].z), "+v"(ra[P].w));
-                load_a(ra[P]);
-            }
-            if (kk == 10) store_a(ra[1 - P], cbuf ^ 1);
-            if (kk == BK / 2 - 1) {
-                constexpr int inflight = A_PASSES;
-                __builtin_amdgcn_s_waitcnt((inflight & 0xF) | ((inflight >> 4) << 14) | (0x7 << 4) | (0xF << 8));
-            }
-        };
-        const int f_lo = (E0 >> 10) & 15, two = (E0 >> 14) & 1;
-        const bool need = !blockskip || (((bmask >> f_lo) | (two ? (bmask >> (f_lo + 1)) : 0)) & 1);
-        if (!need) {
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) pieces(kk);
-        } else {
-            const float *a = As + cbuf * BK * LDA_S + wm * WTM + li;
-            const float *b = Bs + cbuf * BK * LDB_S + wn * WTN + li;
-            float av[2], bv[2];
-            av[0] = a[hi * LDA_S];
-            bv[0] = b[hi * LDB_S];
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                if (kk + 1 < BK / 2) {
-                    av[(kk + 1) & 1] = a[((kk + 1) * 2 + hi) * LDA_S];
-                    bv[(kk + 1) & 1] = b[((kk + 1) * 2 + hi) * LDB_S];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1], bv[kk & 1], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                pieces(kk);
-            }
-        }
-        __syncthreads();
-        cbuf ^= 1;
-        E0 = E1;
-        E1 = E2;
-    };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-
-#ifdef HPL_TIMING
-    long long tm_loop = 0, tm_stage = 0, tm_epi = 0, tm_slices = 0, tm_tiles = 0, tm_stage2 = 0;
-    const long long tm_start = __builtin_readcyclecounter(), tm_wstart = __builtin_amdgcn_s_memrealtime();
-#define PT(var, expr) do { const long long t0__ = __builtin_readcyclecounter(); expr; var += __builtin_readcyclecounter() - t0__; } while (0)
-#else
-#define PT(var, expr) do { expr; } while (0)
-#endif
-    // ================= start: the first two queue items, the first tile staged synchronously
-    if (t == 0) { qslot[0] = atomicAdd(head, 1); qslot[1] = atomicAdd(head, 1); }
-    __syncthreads();
-    cur = make_ctx(__builtin_amdgcn_readfirstlane(qslot[0]));
-    int q_next = __builtin_amdgcn_readfirstlane(qslot[1]);
-    __syncthreads();
-    PT(tm_stage, stage(cur, 0));
-    boff_cur = boff_of(cur);
-    bool primed = false;
-    int gstep = 0;
-    int pulled = -1;                  // thread 0: the queue item pulled during the current tile
-
-    while (cur.valid) {
-        nxt = make_ctx(q_next);
-        boff_nxt = boff_of(nxt);
-        link = false;
-        bool staged = false;
-        if (cur.nsl < 4) {                                   // short tile: stage the next one before the loop
-            PT(tm_stage, stage(nxt, ib ^ 1));
-            staged = true;
-            link = nxt.valid && cur.nsl >= 3 && nxt.nsl >= 3;
-        }
-        if (!primed) {                                       // fill the pipeline: slice 0 -> LDS, slice 1 -> registers
-            E0 = lookup(0);
-            E1 = lookup(1);
-#pragma unroll
-            for (int i = 0; i < B_PASSES; ++i) load_b_lds(cbuf, E0, i);
-            load_begin(E0);
-            load_a(ra[0]);
-            store_a(ra[0], cbuf);
-            load_begin(E1);
-            load_a(ra[1]);
-            {
-                constexpr int inflight = A_PASSES;
-                __builtin_amdgcn_s_waitcnt((inflight & 0xF) | ((inflight >> 4) << 14) | (0x7 << 4) | (0x0 << 8));
-            }
-            __syncthreads();
-            primed = true;
-            gstep = 0;
-        }
-        bmask = __builtin_amdgcn_readfirstlane(Idx[ib * IDX_INTS + F_LDS * BM + BM + 2 + wm]);
-
-#ifdef HPL_TIMING
-        const long long tl0 = __builtin_readcyclecounter();
-        tm_slices += cur.nsl; ++tm_tiles;
-#endif
-        // The first two steps, then the staging of the next tile (its look-ahead loads start two steps before this
-        // tile ends), then the steady loop: nothing but steps in it, unrolled by two on the parity of the global step
-        // count -- straight-line code, so that the compiler's waitcnt bookkeeping keeps the loads of slice t+2 in
-        // flight across the step boundary (a branchy loop body makes it drain vmcnt at every step).
-        int ts = 0;
-        {
-            const int head_end = min(2, cur.nsl);
-            while (ts < head_end) {
-                if (gstep & 1) step(ts, P1{}); else step(ts, P0{});
-                ++ts; ++gstep;
-            }
-        }
-        if (!staged) {
-            PT(tm_stage2, stage(nxt, ib ^ 1));
-            staged = true;
-            link = nxt.valid && nxt.nsl >= 3;
-        }
-        if (ts < cur.nsl && (gstep & 1)) { step(ts, P1{}); ++ts; ++gstep; }
-        while (ts + 1 < cur.nsl) {
-            step(ts, P0{});
-            step(ts + 1, P1{});
-            ts += 2; gstep += 2;
-        }
-        if (ts < cur.nsl) { step(ts, P0{}); ++ts; ++gstep; }
-
-#ifdef HPL_TIMING
-        const long long te0 = __builtin_readcyclecounter();
-        tm_loop += te0 - tl0;
-#endif
-        if (t == 0) pulled = atomicAdd(head, 1);             // the item after next; its round trip hides behind the epilogue
-        // ---- epilogue of this tile (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-        {
-            const int *Vs = Idx + ib * IDX_INTS + F_LDS * BM;
-            const int n = cur.tn * BN + wn * WTN + li;
-            if (n < p.N) {
-                const float bsv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = Vs[wm * WTM + (r & 3) + 8 * (r >> 2) + 4 * hi];
-                    if (m < 0) continue;
-                    float v = acc[r] + bsv;
-                    if (p.res) v += p.res[(m % p.res_mod) * p.ldres + n];
-                    if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
-                    p.Y[m * p.ldy + n] = v;
-                    if (p.Y2 && m < p.rows2) p.Y2[m * p.ldy2 + n] = v;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        }
-        if (t == 0) qslot[0] = pulled;
-        __syncthreads();
-        q_next = __builtin_amdgcn_readfirstlane(qslot[0]);
-        __syncthreads();                                     // qslot is rewritten at the end of the next tile
-        if (!link) primed = false;
-        cur = nxt;
-        boff_cur = boff_nxt;
-        ib ^= 1;
-        E0 &= ~E_NXT;                                        // the carried entries are the new tile's slices 0 and 1
-        E1 &= ~E_NXT;
-#ifdef HPL_TIMING
-        tm_epi += __builtin_readcyclecounter() - te0;
-#endif
-    }
-#ifdef HPL_TIMING
-    if (lane == 0 && blockIdx.x < HPL_TIMING_WGS) {
-        long long *o = g_timing + ((size_t)blockIdx.x * 8 + wave) * 8;
-        o[0] = tm_start; o[1] = tm_loop; o[2] = tm_stage + tm_stage2; o[3] = __builtin_readcyclecounter();
-        o[4] = tm_slices; o[5] = tm_epi; o[6] = tm_wstart;
-        o[7] = (__builtin_amdgcn_s_memrealtime() << 4) | (tm_tiles & 15);
-    }
-#endif
-    if (probe) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe),
-                  (unsigned long long)((long long)__builtin_readcyclecounter() - probe_c));
-        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 1,
-                  (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - probe_w));
-    }
-}
-
 }  // namespace
 
 int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
@@ -1155,36 +786,6 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
 }
 
 namespace {
-// 0 = one tile per workgroup (k_gconv; default), 1 = persistent workgroups for the big row-ordered launches,
-// 2 = persistent whenever the launch has a row order and tile tables (tests).  Measured (profiles/r02k_pers_timing.txt,
-// r02j): the persistent kernel hides the tile prologue (loop = 94 % of a workgroup's life instead of 90 %) but its
-// steady loop runs 4750 instead of ~4570 cycles per slice (more scalar state, SGPR spills), its workgroups still
-// finish up to one tile apart, and it does not yield CUs to the kernels of the other forward streams: 2.05 vs 1.96 ms
-// on bcn1_ alone, 208 vs 226 pairs/s in the pipelined benchmark.  Kept selectable, off by default.
-int g_persistent = -1;
-int persistent_mode() {
-    if (g_persistent < 0) g_persistent = getenv("HPL_PERSISTENT") ? atoi(getenv("HPL_PERSISTENT")) : 0;
-    return g_persistent;
-}
-
-// counters of the persistent launches: a ring of PERS_CTR_SLOTS sets per device; a launch zeroes its set on its stream
-bool launch_persistent(GParams &p, hipStream_t s) {
-    static int *ring[16] = {nullptr};
-    static unsigned next_slot[16] = {0};
-    static int cus[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
-    if (!ring[dev]) {
-        if (hipMalloc(reinterpret_cast<void **>(&ring[dev]), sizeof(int) * PERS_CTR_SLOTS * PERS_CTR_INTS) != hipSuccess) return false;
-        if (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] <= 0) cus[dev] = 256;
-    }
-    int *ctr = ring[dev] + (size_t)(next_slot[dev]++ % PERS_CTR_SLOTS) * PERS_CTR_INTS;
-    if (hipMemsetAsync(ctr, 0, sizeof(int) * PERS_CTR_INTS, s) != hipSuccess) return false;
-    const int grid = (2 * cus[dev]) / 8 * 8;              // two workgroups per CU, the same number on every queue
-    k_gconv_pers<64, 128, 2, 4><<<grid, 512, 0, s>>>(p, ctr);
-    return true;
-}
-
 template <int BM, int BN, int WGM, int WGN>
 void launch_cfg(GParams &p, bool avec, hipStream_t s) {
     p.tiles_m = (int)cdiv(p.M, BM);
@@ -1242,12 +843,6 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
         p.col_share = 8 / g;
         p.col_rows = p.col_share == 1 ? p.tiles_m : (int)cdiv(p.tiles_m, COL_CHUNK * p.col_share) * COL_CHUNK;
         grid = p.tiles_n * p.col_share * p.col_rows;
-    }
-    if constexpr (BM == 64 && BN == 128 && WGM == 2 && WGN == 4) {
-        const int pers = persistent_mode();
-        if (pers && avec && p.F > 1 && p.tile_idx && p.col_share > 0 && p.splits == 1 && !p.scat &&
-            (tiles >= 1024 || pers == 2) && launch_persistent(p, s))
-            return;
     }
     if constexpr (BM == 64 && BN == 128 && WGM == 2 && WGN == 4) {
         // three workgroups per CU (COMPACT LDS budget, 52.8 KB) for the tap-group passes of the big stencil launches: a
@@ -1424,17 +1019,11 @@ extern "C" int hpl_tile_index(const int32_t *nbr, int64_t nbr_stride, int F, int
     return HPL_OK;
 }
 
-extern "C" int hpl_set_persistent(int mode) {
-    HPL_REQUIRE(mode >= 0 && mode <= 2, "hpl_set_persistent: mode 0, 1 or 2");
-    const int old = persistent_mode();
-    g_persistent = mode;
-    return old;
-}
-
 extern "C" int hpl_gconv_forward_naive(const hpl_gconv_desc *d, hplStream stream) {
     GParams p;
     int rc = fill_params(d, p, "hpl_gconv_forward_naive");
     if (rc != HPL_OK) return rc;
+    HPL_REQUIRE(!d->post_Wt, "hpl_gconv_forward_naive: the reference kernel has no fused trailing conv (post_Wt)");
     if (p.M == 0) return HPL_OK;
     const int grid = (int)imin(cdiv(p.M * p.N, 256), 8192);
     k_gconv_naive<<<grid, 256, 0, to_stream(stream)>>>(p);

@@ -44,24 +44,15 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-// Diagnostic builds (tools/gpu/ablate.sh, -DHPL_ABLATE=n; results are WRONG, timing only): 1 = no global loads in the main
-// loop (gathered rows and weight fragments), 2 = no split + LDS stores of the gathered rows, 3 = both, 4 = no fragment reads
-#ifndef HPL_ABLATE
-#define HPL_ABLATE 0
-#endif
-// (5 = 3 + 4: matrix instructions, barriers and waits only; 6 = 5 without the half-step barriers)
-constexpr bool ABL_LOADS_A = HPL_ABLATE == 1 || HPL_ABLATE == 3 || HPL_ABLATE == 5 || HPL_ABLATE == 6 || HPL_ABLATE == 7;   // (7: gathered rows only)
-constexpr bool ABL_LOADS_B = HPL_ABLATE == 1 || HPL_ABLATE == 3 || HPL_ABLATE == 5 || HPL_ABLATE == 6 || HPL_ABLATE == 8;   // (8: weight fragments only)
-constexpr bool ABL_STORES = HPL_ABLATE == 2 || HPL_ABLATE == 3 || HPL_ABLATE == 5 || HPL_ABLATE == 6;
-constexpr bool ABL_FRAGS = HPL_ABLATE >= 4 && HPL_ABLATE <= 6;
-
 // Diagnostic build (-DHPL_PHASE_PROBE=1, tools/gpu/phase_probe.sh): every wave of the sampled workgroups accumulates the shader
 // cycles it spends in the four parts of a ping-pong half-step (memory phase up to its wait, first barrier, compute phase,
 // second barrier) into clock_probe[8 + 4 * wave row ..]; timing only (the stamps are scalar memory reads: they add waits)
 #ifndef HPL_PHASE_PROBE
 #define HPL_PHASE_PROBE 0
 #endif
-// Ping-pong schedule of the 8-wave tile (see k_gconv3): 1 = on
+// Ping-pong schedule of the 8-wave tile (see gconv3_body): 1 = on; -DHPL_PP=0 builds the one-barrier form for A/B runs
+// (measured variants that did not pay -- one barrier per half-step, the non-MFMA work in the memory phase, register caps --
+// are in DESIGN.md 4.1 and profiles/r03s_variants_ab.txt, r04b_split3_pp3_ab.txt, not in this file)
 #ifndef HPL_PP
 #define HPL_PP 1
 #endif
@@ -112,7 +103,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     // half-steps before it is read, i.e. >= 3 barriers before the first reader of either row; a stage's last reader (the
     // late row, one barrier behind) is still >= 1 barrier ahead of its next writer.
     constexpr bool PP = WGN == 4 && HPL_PP != 0;
-    constexpr bool PP1 = PP && HPL_PP == 2;      // one barrier per half-step (see the compute phase)
     static_assert(A_PASSES == 2 || A_PASSES == 4, "two halves of a slice per thread");
     // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NA * A_STAGE + NB * B_STAGE + ((F_LDS + 1) * BM + BM + 8) * 4 + KLIST * 2];
@@ -275,13 +265,12 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     };
     auto load_a_issue = [&](auto set_tag) {
         constexpr int SET = decltype(set_tag)::value;
-        if (ABL_LOADS_A) return;
         const int32x4_t rs = rsrc_a;                  // (asm operands inside a generic lambda must be its own locals)
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             float4_t &dst = ra[SET][i];
             // (an absent row's entry is 0x80000000: with the column offset still beyond the descriptor's range -> zeros)
-            const unsigned o = (unsigned)(HPL_ABLATE == 9 ? (a_rows[i] & 0x8000ffff) : a_rows[i]) + (unsigned)a_c[i] * 4u;      // (9: every gathered load hits the first 64 KB)
+            const unsigned o = (unsigned)a_rows[i] + (unsigned)a_c[i] * 4u;
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(o), "s"(rs) : "memory");
         }
     };
@@ -307,21 +296,11 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     const int kb_w = (t >> 1) & 1;
     auto store_a = [&](auto set_tag, int h, int st, int j) {
         constexpr int SET = decltype(set_tag)::value;
-        if (ABL_STORES) return;
         const float4_t v = h ? ra[SET][2 * j + 1] : ra[SET][2 * j];      // (h is a literal at every call site)
         const int row = arow0 + j * ROWS_PP;
         unsigned h0, m0_, l0, h1, m1, l1;
-        if (HPL_ABLATE == 12) {          // (12: the LDS stores without the conversion)
-            h0 = __builtin_bit_cast(unsigned, v.x); h1 = __builtin_bit_cast(unsigned, v.y); m0_ = __builtin_bit_cast(unsigned, v.z);
-            m1 = __builtin_bit_cast(unsigned, v.w); l0 = h0; l1 = h1;
-        } else {
-            split2(v.x, v.y, h0, m0_, l0);
-            split2(v.z, v.w, h1, m1, l1);
-        }
-        if (HPL_ABLATE == 11) {          // (11: the conversion without the LDS stores)
-            asm volatile("" :: "v"(h0), "v"(h1), "v"(m0_), "v"(m1), "v"(l0), "v"(l1));
-            return;
-        }
+        split2(v.x, v.y, h0, m0_, l0);
+        split2(v.z, v.w, h1, m1, l1);
         unsigned char *base = smem + st * A_STAGE + (kb_w * BM + a_slot(row, kb_w)) * 16 + (t & 1) * 8;
         *reinterpret_cast<u32x2 *>(base) = u32x2{h0, h1};
         *reinterpret_cast<u32x2 *>(base + 2 * BM * 16) = u32x2{m0_, m1};
@@ -331,8 +310,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     // weight fragments of half h of slice kt straight into stage st: wave (wm, wn) fetches k-block wm of the half for
     // the 64 columns of column block wn, one 1 KiB LDS-direct load per plane
     auto load_b = [&](int kt, int h, int st) {
-        if (ABL_LOADS_B) return;
-        const unsigned kbg = HPL_ABLATE == 10 ? (unsigned)(h * 2 + wm) : (unsigned)(kt * (BK / 8) + h * 2 + wm);      // (10: every weight load hits the first slice)
+        const unsigned kbg = (unsigned)(kt * (BK / 8) + h * 2 + wm);
         const unsigned off = kbg * ldw16 + b_colofs;      // (b_colofs = 0x80000000 for a column past the image: stays out of range)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
@@ -393,7 +371,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         wait_vm_lgkm0(S0{});
         asm volatile("s_barrier" ::: "memory");
 
-        if (PP && wm == 1 && HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");      // the second wave row runs one phase behind
+        if (PP && wm == 1) asm volatile("s_barrier" ::: "memory");      // the second wave row runs one phase behind
 
         int sta = 0, stb = 0;                        // stages of the half-step being multiplied (A ring, B ring)
         unsigned long long ph_t = HPL_PHASE_PROBE ? __builtin_readcyclecounter() : 0ull, ph_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
@@ -427,29 +405,21 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             constexpr int PB[6] = {0, 1, 0, 2, 0, 1};
             if constexpr (PP) {
                 // ---- memory phase: only what has to wait for the barrier -- the twelve fragment reads of this half-step.
-                if (ABL_FRAGS) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) { af[pl][i] = u32x4{(unsigned)sta, 1u, 2u, 3u}; bf[pl][i] = u32x4{4u, 5u, (unsigned)h, 7u}; }
-                } else {
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            af[pl][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i] + pl * 2 * BM * 16);
-                            bf[pl][i] = *reinterpret_cast<const u32x4 *>(sb + b_rofs + pl * 2 * BN * 16 + i * 32 * 16);
-                        }
-                }
+                    for (int i = 0; i < 2; ++i) {
+                        af[pl][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i] + pl * 2 * BM * 16);
+                        bf[pl][i] = *reinterpret_cast<const u32x4 *>(sb + b_rofs + pl * 2 * BN * 16 + i * 32 * 16);
+                    }
                 // the loads of the compute phase before last have landed (in flight: the last compute phase's); fragments here,
                 // the LDS stores of the last compute phase done
                 const unsigned long long ph_issue = HPL_PHASE_PROBE ? __builtin_readcyclecounter() : 0ull;      // (read behind the wait)
-                if constexpr (PP1) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): fragments here, last compute phase's LDS stores done
-                else wait_vm_lgkm0(inflight_tag);
+                wait_vm_lgkm0(inflight_tag);
                 if (HPL_PHASE_PROBE) ph_acc[4] += ph_issue - ph_t;
                 __builtin_amdgcn_sched_barrier(0);
                 stamp(0);
-                if (HPL_ABLATE != 6 && (!PP1 || wm == 0)) asm volatile("s_barrier" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
                 stamp(1);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- compute phase: the 24 MFMAs of the wave's 64 rows and, in their shadow, everything else of the half-step
@@ -463,14 +433,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 // With all three groups in the memory phase instead: 1190 / 790 (before the instruction trims); with the gathered
                 // loads and the stores there 617 us against 597 us for the launch: this split is the fastest of the four tried.
                 auto others = [&]() {
-#ifdef HPL_DUMMY_VALU      // diagnostic: what one more VALU instruction beside the MFMAs costs
-                    {
-                        int dummy = lane;
-#pragma unroll
-                        for (int k = 0; k < HPL_DUMMY_VALU; ++k) asm volatile("v_add_u32 %0, %0, %0" : "+v"(dummy));
-                        asm volatile("" :: "v"(dummy));
-                    }
-#endif
                     if constexpr (B) load_b(kt_b, hb_b, stb2);
                     // (the row indices of these loads were read from LDS one slice ago -- no wait on the LDS queue, which the
                     // other wave row's fragment reads fill, in front of the MFMAs behind this point; kt_l = the NEXT slice's entry)
@@ -506,33 +468,14 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 }
                 // (own LDS stores: waited for at the end of the next memory phase, one barrier before anybody reads them)
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (PP1) {
-                    // ONE barrier per half-step: the first wave row has it between its memory and compute phase, the second
-                    // (which entered one barrier late) behind its compute phase -- between two barriers the first row runs
-                    // compute(g), memory(g+1), the second memory(g), compute(g): the phases of a SIMD's two waves still
-                    // alternate, but a wave no longer idles at a barrier between ITS OWN phases.  The second row's loads and
-                    // LDS stores of this phase's predecessor must be visible one barrier earlier than the first row's:
-                    // in flight behind this wait = this compute phase's loads (second row) / this and the last one's (first).
-                    constexpr int TIGHT = (B ? B_CHUNKS_PER_WAVE : 0) + (L ? A_PASSES : 0), INFL = decltype(inflight_tag)::value;
-                    if constexpr (INFL == 0) wait_vm_lgkm0(std::integral_constant<int, 0>{});      // (tail: drain)
-                    else if (wm == 1) wait_vm_lgkm0(std::integral_constant<int, TIGHT>{});
-                    else wait_vm_lgkm0(std::integral_constant<int, TIGHT + INFL>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 stamp(2);
-                if (HPL_ABLATE != 6 && (!PP1 || wm == 1)) asm volatile("s_barrier" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
                 stamp(3);
                 __builtin_amdgcn_sched_barrier(0);
                 sta = sta == 2 ? 0 : sta + 1;
                 stb = stb == NB - 1 ? 0 : stb + 1;
                 return;
             }
-            if (ABL_FRAGS) {
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) { af[pl][i] = u32x4{(unsigned)sta, 1u, 2u, 3u}; bf[pl][i] = u32x4{4u, 5u, (unsigned)h, 7u}; }
-            } else
             if (need[0] || need[1]) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
@@ -581,7 +524,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             }
             // everything older than the last NB - 2 half-steps' loads has landed (loads complete in order); own LDS stores done
             wait_vm_lgkm0(inflight_tag);
-            if (HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
             sta = sta == 2 ? 0 : sta + 1;
             stb = stb == NB - 1 ? 0 : stb + 1;
         };
@@ -652,7 +595,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             if (sl + 1 < nsl) slice_tail(sl + 1, S1{});
             if constexpr (ASETS == 3) { if (sl + 2 < nsl) slice_tail(sl + 2, S2{}); }
         }
-        if (PP && wm == 0 && HPL_ABLATE != 6) asm volatile("s_barrier" ::: "memory");      // (the second wave row's last compute phase)
+        if (PP && wm == 0) asm volatile("s_barrier" ::: "memory");      // (the second wave row's last compute phase)
         if (HPL_PHASE_PROBE && p.clock_probe && (blockIdx.x & 15) == 0 && lane == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 8 + 4 * wm + k, ph_acc[k]);
@@ -675,7 +618,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
             p.res ? (void *)const_cast<float *>(p.res) : (void *)p.Y, (short)0, p.res ? 0x7fffffff : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(
-            p.Y2 ? (void *)p.Y2 : (void *)p.Y, (short)0, p.Y2 ? 0x7fffffff : 0, 0x00020000);
+            p.Y2 ? (void *)p.Y2 : (void *)p.Y, (short)0, (p.Y2 && p.splits <= 1) ? 0x7fffffff : 0, 0x00020000);   // (split-K partials never go to Y2: k_gconv_finish writes it)
         const unsigned ldy_b = (unsigned)(p.splits > 1 ? p.N : p.ldy) * 4u, ldr_b = (unsigned)p.ldres * 4u, ldy2_b = (unsigned)p.ldy2 * 4u;
         const bool plain = p.splits <= 1;
         const bool res_wrap = p.res && p.res_mod < p.M;      // (uniform)
@@ -757,19 +700,9 @@ __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
     gconv3_body<WGN, F_LDS, NB>(p);
 }
 
-// The 8-wave tile with a register budget (-DHPL_VGPR_CAP=n, in units of 2 registers on gfx950's unified file; 0 = none): the
-// tile keeps its CU to itself (142 KB of LDS), and with 2 x 240 of a SIMD's 512 registers taken no wave of another stream's
-// small kernels (lattice build, narrow layers) fits beside it; a cap leaves room for them.
-#ifndef HPL_VGPR_CAP
-#define HPL_VGPR_CAP 0
-#endif
-#if HPL_VGPR_CAP > 0
-#define HPL_VGPR_ATTR __attribute__((amdgpu_num_vgpr(HPL_VGPR_CAP)))
-#else
-#define HPL_VGPR_ATTR
-#endif
+// the 8-wave tile (128 x 256, ping-pong wave rows): one workgroup per CU
 template <int F_LDS, int NB>
-__global__ void __launch_bounds__(512, 2) HPL_VGPR_ATTR k_gconv3w(const GParams p) {
+__global__ void __launch_bounds__(512, 2) k_gconv3w(const GParams p) {
     gconv3_body<4, F_LDS, NB>(p);
 }
 

@@ -278,6 +278,8 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
     nbr None and reg_stride > 0: tap f of row m reads row f*reg_stride + m (no table: the displacement
     filter of the correlation layer, whose taps are the F blocks of H1 virtual vertices).
     out2 / rows2: rows m < rows2 of the result are also stored to the matrix (view) `out2`."""
+    if naive and post is not None:
+        raise _lib.HplError('the naive reference kernel has no fused trailing conv (post)')
     d = GConvDesc()
     d.A, d.lda, d.rows_a, a_cols = _mat(A, 'activation')
     if nbr is not None:
@@ -465,9 +467,11 @@ class WeightBank(object):
         job = self.jobs.get(key)
         k_rows, ldw = round_up(F * R, 32), round_up(Q, 4)
         if job is not None and not self.dirty and job[4] == weight._version and job[0] is weight:
-            return self.buf[job[2]:job[2] + job[3]].view(k_rows, ldw)
+            img = self.buf[job[2]:job[2] + job[3]].view(k_rows, ldw)
+            img._hpl_bank_job = job             # split3_of keeps the image's split planes with the job
+            return img
         if job is None:
-            self.jobs[key] = [weight, (R, Q, F, sr, sq, sf, base, mirror), None, k_rows * ldw, -1]
+            self.jobs[key] = [weight, (R, Q, F, sr, sq, sf, base, mirror), None, k_rows * ldw, -1, None]
             self.dirty = True
         fmap = _mirror_map(F, weight.device) if mirror else None
         return weight_relayout(weight, R, Q, F, sr, sq, sf, base=base, fmap=fmap)
@@ -550,14 +554,39 @@ def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, r
     return y
 
 
+def _split3_entry(Wt, version):
+    ev = torch.cuda.Event()
+    w3 = weight_split3(Wt)
+    ev.record()                       # behind k_weight_split3: a consumer on another stream waits for THIS, not for the re-layout
+    return [w3, version, ev, stream()]
+
+
+def _split3_wait(entry):
+    ev = entry[2]
+    if ev is not None and stream() != entry[3]:
+        if ev.query():
+            entry[2] = None           # seen complete once: visible to every later launch on any stream
+        else:
+            torch.cuda.current_stream().wait_event(ev)
+    return entry[0]
+
+
 def split3_of(Wt):
-    """The split image of a weight image, made once per image tensor (the image caches / banks hand out the same
-    tensor object until the parameter changes)."""
-    w3 = getattr(Wt, '_hpl_split3', None)
-    if w3 is None or w3[1] != Wt._version:
-        w3 = (weight_split3(Wt), Wt._version)
-        Wt._hpl_split3 = w3
-    return w3[0]
+    """The split image of a weight image, made once per image: images handed out by a WeightBank keep it with the bank's
+    job (the bank returns a fresh view of its buffer on every lookup, so an attribute on the view would never be found
+    again; valid while the job's parameter version is the one its last refresh saw), other images carry it as an
+    attribute keyed on their version.  Either way the entry holds the event recorded behind the split kernel: a forward
+    on another stream that finds the entry waits for the split, not just for the re-layout (_cached_relayout's event)."""
+    job = getattr(Wt, '_hpl_bank_job', None)
+    if job is not None:
+        ent = job[5]
+        if ent is None or ent[1] != job[4]:
+            ent = job[5] = _split3_entry(Wt, job[4])
+        return _split3_wait(ent)
+    ent = getattr(Wt, '_hpl_split3', None)
+    if ent is None or ent[1] != Wt._version:
+        ent = Wt._hpl_split3 = _split3_entry(Wt, Wt._version)
+    return _split3_wait(ent)
 
 
 class GConvFn(torch.autograd.Function):

@@ -164,7 +164,7 @@ def _conv_stack(P, x, mods, M, rows_sym, F, level, table, order, slope, out=None
             nxt = _conv_of(mods[i + 1])
             O2 = nxt.weight.shape[0]
             wide_first = i == 0 and table == TBL_BLUR0 and conv.in_channels >= GROUPS_MIN_CHANNELS      # (tap-group passes)
-            if O <= 64 and O % 2 == 0 and O2 <= 64 and not wide_first:
+            if O <= 64 and O % 2 == 0 and O2 <= 64 and not wide_first and (i > 0 or (F <= 15 and order != ORD_GROUPS)):
                 # conv + the 1x1 conv behind it as one launch (hpl_gconv_desc.post_*): the intermediate matrix never exists
                 post = (P.weight(nxt.weight, O, O2, 1, O, 0), P.bias(nxt.bias), O2, 1 if isinstance(mods[i + 1], _ConvReLU) else 0,
                         P.buf(rows_sym, O).c())          # (the intermediate matrix of the two-launch form: big levels)

@@ -255,13 +255,6 @@ int hpl_tile_index(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, con
  * (bnn_flow.py:189-202) and the displacement filter Conv2d((15,1))
  * (bnn_flow.py:205).  The gathered tensor is never materialised. */
 int hpl_gconv_forward(const hpl_gconv_desc *desc /* HOST */, hplStream stream);
-/* Tuning knob: how the big row-ordered launches (row_perm + tile tables, 64 x 128 tiles) are scheduled.  0 (default;
- * env HPL_PERSISTENT) = one tile per workgroup, heaviest tiles first; 1 = persistent workgroups pulling tiles from one
- * queue per XCD, the next tile's prologue overlapped with the current tile's main loop (measured slower, see
- * csrc/gconv.hip); 2 = persistent for every launch that can.  Results are identical in all modes.  Returns the
- * previous mode. */
-int hpl_set_persistent(int mode);
-
 /* same contract, one thread per output element, no MFMA: test/debug reference only */
 int hpl_gconv_forward_naive(const hpl_gconv_desc *desc /* HOST */, hplStream stream);
 

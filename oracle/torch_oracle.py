@@ -167,7 +167,7 @@ def lattice(gd, dtype=torch.float64):
             for d in gd]
 
 
-def hplflownet_forward(sd, pc1, pc2, gd, shallow=False, use_leaky=True, last_relu=False):
+def hplflownet_forward(sd, pc1, pc2, gd, shallow=False, use_leaky=True, last_relu=False, use_norm=True):
     """models/HPLFlowNet.py:238-430 / models/HPLFlowNet_shallow.py:171-311 from `sd` = parameters(...);
     pc1, pc2 (3, N) tensors, gd = lattice(...).  Returns the flow (3, N)."""
     def stack(x, prefix, n):
@@ -187,7 +187,7 @@ def hplflownet_forward(sd, pc1, pc2, gd, shallow=False, use_leaky=True, last_rel
             x = torch.cat([gd[L][which + '_el_minus_gr'], f], dim=0)
             res.append(bilateral_conv_forward(x, convs, None, gd[L][which + '_barycentric'],
                                               gd[L][which + '_lattice_offset'], gd[L][which + '_blur_neighbors'],
-                                              None, None, True, False, True, use_leaky, last_relu))
+                                              None, None, True, False, use_norm, use_leaky, last_relu))
         f1, f2 = res
         down1.append(f1)
         if L >= 2:
@@ -195,7 +195,7 @@ def hplflownet_forward(sd, pc1, pc2, gd, shallow=False, use_leaky=True, last_rel
             cc, bc = _corr_params(sd, 'corr%d' % j)
             c = bilateral_corr_forward(f1, f2, prev, gd[L]['pc1_barycentric'] if prev is not None else None,
                                        gd[L]['pc1_lattice_offset'] if prev is not None else None,
-                                       gd[L]['pc1_corr_indices'], gd[L]['pc2_corr_indices'], cc, bc, True, use_leaky,
+                                       gd[L]['pc1_corr_indices'], gd[L]['pc2_corr_indices'], cc, bc, use_norm, use_leaky,
                                        last_relu)
             if shallow:
                 if L + 1 < nlev:
@@ -215,7 +215,7 @@ def hplflownet_forward(sd, pc1, pc2, gd, shallow=False, use_leaky=True, last_rel
             parts.append(down1[L])
             x = torch.cat(parts, dim=0)
         up = bilateral_conv_forward(x, convs, bias, None, None, gd[L]['pc1_blur_neighbors'], gd[L]['pc1_barycentric'],
-                                    gd[L]['pc1_lattice_offset'], False, True, True, use_leaky, last_relu)
+                                    gd[L]['pc1_lattice_offset'], False, True, use_norm, use_leaky, last_relu)
     x = conv1d(up, sd['conv2.composed_module.0.weight'], sd['conv2.composed_module.0.bias'], True, use_leaky)
     x = conv1d(x, sd['conv3.composed_module.0.weight'], sd['conv3.composed_module.0.bias'], True, use_leaky)
     return conv1d(x, sd['conv4.weight'], sd['conv4.bias'], False)
@@ -226,10 +226,11 @@ def epe3d_loss(flow, sf):
     return torch.norm(flow - sf, p=2, dim=0).mean()
 
 
-def model_step(state_dict, pc1, pc2, sf, gd, shallow=False, dtype=torch.float64):
+def model_step(state_dict, pc1, pc2, sf, gd, shallow=False, dtype=torch.float64, use_leaky=True, use_norm=True):
     """Forward + backward of one pair: -> (flow (3, N) numpy, loss float, {param name: gradient numpy})."""
     sd = parameters(state_dict, dtype)
-    flow = hplflownet_forward(sd, _t(pc1, dtype), _t(pc2, dtype), lattice(gd, dtype), shallow=shallow)
+    flow = hplflownet_forward(sd, _t(pc1, dtype), _t(pc2, dtype), lattice(gd, dtype), shallow=shallow, use_leaky=use_leaky,
+                              use_norm=use_norm)
     loss = epe3d_loss(flow, _t(sf, dtype))
     loss.backward()
     grads = {k: v.grad.numpy() for k, v in sd.items() if v.grad is not None}

@@ -357,42 +357,6 @@ def test_tile_index_tables_and_gconv_with_them(ops):
                        ops.gconv_raw(A, nbr, M, C, F, Wt8, 24, row_perm=perm, tiles=(idx, mask)))
 
 
-@pytest.mark.parametrize('C,O,F,density', [(96, 160, 15, 0.45), (580, 256, 8, 0.4), (20, 130, 15, 0.3), (8, 200, 15, 0.1),
-                                           (324, 512, 7, 0.75)])
-def test_persistent_gconv_equals_one_tile_per_workgroup(ops, C, O, F, density):
-    """The persistent scheduling of the row-ordered launches (queues per XCD, next tile staged during the current one,
-    the slice stream continuing across tiles) gives bit-identical results, incl. tiles with one or two slices (small C,
-    sparse taps), tiles past M and a residual + activation epilogue."""
-    from hplflownet_amd import _lib
-    L = _lib.load()
-    rng = np.random.RandomState(C + O)
-    M = 30000 + C
-    nbr_np = rng.randint(0, M, (F, M)).astype(np.int32)
-    nbr_np[rng.rand(F, M) > density] = -1
-    nbr_np[0, : M // 2] = np.arange(M // 2)
-    nbr = torch.from_numpy(nbr_np).to(DEV)
-    perm = ops.tap_order(nbr)
-    tiles = ops.tile_index(nbr, perm)
-    A = torch.from_numpy(rng.randn(M, C).astype(np.float32)).to(DEV)
-    W = torch.from_numpy((rng.randn(O, C, F) / np.sqrt(C * F)).astype(np.float32)).to(DEV)
-    Wt = ops.weight_relayout(W, C, O, F, F, C * F, 1)
-    bias = torch.from_numpy(rng.randn(O).astype(np.float32)).to(DEV)
-    res = torch.from_numpy(rng.randn(M, O).astype(np.float32)).to(DEV)
-    outs = []
-    old = L.hpl_set_persistent(0)
-    try:
-        for mode in (0, 2):
-            L.hpl_set_persistent(mode)
-            outs.append(ops.gconv_raw(A, nbr, M, C, F, Wt, O, bias=bias, act=ops.ACT_LEAKY, res=res, row_perm=perm, tiles=tiles))
-            outs.append(ops.gconv_raw(A, nbr, M, C, F, Wt, O, row_perm=perm, tiles=tiles))
-        torch.cuda.synchronize()
-    finally:
-        L.hpl_set_persistent(old)
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
-    y_naive = ops.gconv_raw(A, nbr, M, C, F, Wt, O, naive=True)
-    assert torch.equal(outs[3], y_naive) if C % 32 == 0 or True else True
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize('M,C,O,F,density', [(53, 64, 32, 15, 0.5), (426, 260, 128, 15, 0.4), (1787, 64, 64, 1, 1.0),
                                               (4324, 580, 1024, 15, 0.95), (9433, 388, 256, 15, 0.45)])
