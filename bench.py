@@ -432,6 +432,8 @@ def main():
         # CPU thread pools (torch intra-op, BLAS) from claiming every core N times over
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
     from hplflownet_amd import parallel
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    pin = parallel.pin_host_threads(local_rank, local_world) if world > 1 else {'pinned': False}
     parallel.init_distributed(backend='nccl', device=dev)      # RCCL; inference uses it for barrier/max only
     if a.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
@@ -595,6 +597,7 @@ def main():
                 y = step(i)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        rank_elapsed = elapsed
         timers.enabled = False
         native_prof = None
         if plan is not None:
@@ -603,6 +606,9 @@ def main():
         parallel.barrier()
         elapsed = parallel.max_over_ranks(elapsed, device=dev)
         host_line = host_report(host, a.steps, threaded=native and not a.python_lattice and a.lattice_thread) if overlap else None      # (the regions below run the same loop: snapshot first)
+        # every rank's own step time and host busy time (rank 0 prints them: a slow rank, or a host that cannot feed 8 GPUs, shows here)
+        rank_stats = parallel.gather_floats([rank_elapsed * 1e3 / a.steps, (host_line or {}).get('busy_ms', 0.0),
+                                             float(pin.get('numa_node') if pin.get('numa_node') is not None else -1)], device=dev)
         # The contract times EXACTLY --steps steps; a short region (the driver passes 20: 60 ms) is at the mercy of one
         # scheduling hiccup, so a second region of >= 1 s of the same loop is timed right behind it and reported beside it
         steady = None
@@ -832,6 +838,11 @@ def main():
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,
                 'host_ms_per_step': host_line, 'steady': steady, 'forward_only': fwd_only,
+                'ranks': {'world': world, 'backend': (torch.distributed.get_backend() if world > 1 else None),
+                          'ranks_seen': len(rank_stats), 'ms_per_step_by_rank': [r[0] for r in rank_stats],
+                          'host_busy_ms_by_rank': [r[1] for r in rank_stats], 'numa_node_by_rank': [int(r[2]) for r in rank_stats],
+                          'host_threads_pinned': pin,
+                          'note': 'multi-rank runs over RCCL on > 1 GPU have not been possible on the builder\'s 1-GPU boxes: unmeasured until the driver\'s SCALE run'},
                 'pipelined_output_check': pipe_check, 'single_pair_latency_ms': latency,
                 'device_memory_mb': {'max_allocated': torch.cuda.max_memory_allocated(dev) / 2 ** 20,
                                      'reserved': torch.cuda.memory_reserved(dev) / 2 ** 20}}

@@ -37,6 +37,67 @@ def init_distributed(backend=None, device=None):
     return rank, world, local_rank
 
 
+def _cpulist(text):
+    cpus = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        cpus += list(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_node(device_index):
+    """NUMA node the GPU hangs off (sysfs of its PCI function), or None if the platform does not say."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def pin_host_threads(local_rank, local_world, device_index=None):
+    """Keep this rank's host threads (the forward-enqueue thread and the lattice producer thread) on the cores next to its
+    GPU: the cores of the GPU's NUMA node, divided among the ranks whose GPUs share that node; without NUMA information an
+    even split of the visible cores by local rank.  One rank needs two cores (bench.py reports its busy time per step);
+    what matters at 8 ranks is that no rank's threads migrate across sockets or pile up on another rank's cores.
+    Returns a dict describing what was done (for the bench line)."""
+    info = {'numa_node': None, 'cpus': None, 'pinned': False}
+    if not hasattr(os, 'sched_setaffinity') or os.environ.get('HPL_NO_PIN'):
+        return info
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        node = gpu_numa_node(local_rank if device_index is None else device_index) if torch.cuda.is_available() else None
+        cpus, share, slot = allowed, max(1, local_world), local_rank
+        if node is not None:
+            on_node = [c for c in _cpulist(open('/sys/devices/system/node/node%d/cpulist' % node).read()) if c in allowed]
+            if on_node:
+                # ranks on the same node: assume GPUs are spread evenly over the nodes (8 GPUs / 2 sockets on MI355X hosts)
+                nodes = len([d for d in os.listdir('/sys/devices/system/node') if d.startswith('node') and d[4:].isdigit()]) or 1
+                share = max(1, -(-local_world // nodes))
+                slot = local_rank % share
+                cpus = on_node
+        per = max(2, len(cpus) // share)
+        mine = cpus[slot * per:(slot + 1) * per] or cpus
+        os.sched_setaffinity(0, mine)
+        info.update(numa_node=node, cpus='%d-%d (%d)' % (mine[0], mine[-1], len(mine)), pinned=True)
+    except Exception as e:           # containers without sysfs / restricted affinity: report, never fail
+        info['error'] = str(e)
+    return info
+
+
+def gather_floats(values, device='cpu'):
+    """every rank's list of python floats -> [[rank 0's], [rank 1's], ...] on every rank"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [[float(v) for v in values]]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o.tolist()] for o in out]
+
+
 def sample_seeds(rank, world, per_rank, base=0):
     """Disjoint sample ids for this rank: rank r owns base + r, base + r + world, ... (the usual
     strided DistributedSampler split; pairs are independent, so any partition is valid)."""

@@ -73,7 +73,10 @@ def _worker(rank, world, port, out_dir):
     red()
     P.barrier()
     tmax = P.max_over_ranks(1.0 + rank)
-    torch.save({'seeds': seeds, 'grads': [p.grad.clone() for p in model.parameters()], 'same': same,
+    gathered = P.gather_floats([10.0 + rank, -1.0 * rank])
+    pin = P.pin_host_threads(rank, world)            # (no GPU here: an even split of the visible cores by local rank)
+    affinity = sorted(os.sched_getaffinity(0))
+    torch.save({'seeds': seeds, 'gathered': gathered, 'pin': pin, 'affinity': affinity, 'grads': [p.grad.clone() for p in model.parameters()], 'same': same,
                 'extra': extra.grad.clone(), 'launched': (launched_in_backward, second_launched, len(red.buckets)),
                 'grads2': grads2,
                 'params': [p.detach().clone() for p in model.parameters()], 'tmax': tmax},
@@ -88,6 +91,9 @@ def test_two_rank_gloo():
         res = [torch.load(os.path.join(d, 'r%d.pt' % r)) for r in range(world)]
     assert res[0]['seeds'] == [0, 2, 4] and res[1]['seeds'] == [1, 3, 5]            # disjoint shards
     assert res[0]['tmax'] == res[1]['tmax'] == 2.0                                   # slowest rank
+    assert res[0]['gathered'] == res[1]['gathered'] == [[10.0, 0.0], [11.0, -1.0]]   # per-rank stats of the bench line
+    if all(r['pin']['pinned'] for r in res):                                         # the two ranks' threads on disjoint cores
+        assert len(res[0]['affinity']) >= 1 and not (set(res[0]['affinity']) & set(res[1]['affinity']))
     for a, b in zip(res[0]['params'], res[1]['params']):
         assert torch.equal(a, b)                                                     # broadcast
     for a, b in zip(res[0]['grads'], res[1]['grads']):
@@ -104,3 +110,18 @@ def test_two_rank_gloo():
     loss.backward()
     for p, g in zip(model.parameters(), res[0]['grads']):
         assert torch.allclose(p.grad, g, atol=1e-6, rtol=1e-5)
+
+
+def test_cpulist_and_single_rank_helpers():
+    sys.path.insert(0, ROOT)
+    from hplflownet_amd import parallel as P
+    assert P._cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11] and P._cpulist('') == []
+    assert P.gather_floats([1.5, 2]) == [[1.5, 2.0]]
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        info = P.pin_host_threads(1, 4)
+        if info['pinned']:
+            now = sorted(os.sched_getaffinity(0))
+            assert set(now) <= set(before) and len(now) >= min(2, len(before))
+    finally:
+        os.sched_setaffinity(0, before)
