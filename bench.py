@@ -81,6 +81,7 @@ class KernelTimers(object):
         self.records = []
         self.enabled = False
         self.only = None           # set of class names to time (None = all); events cost host time
+        self.exec_fractions = False   # compute the executed / algorithmic ratio of every gathered launch (detail pass)
         self._orig = (ops.gconv_raw, ops.splat_raw, ops.slice_raw)
         timers = self
 
@@ -104,8 +105,8 @@ class KernelTimers(object):
         def exec_frac(nbr, C, F, perm, rows):
             """executed / algorithmic multiply-adds of a gathered launch: the kernels skip the MFMAs of a block of `rows` output
             rows for the 32-wide contraction slices whose taps none of its rows has (host mirror: needed_slice_fraction)"""
-            if nbr is None or F == 1 or C < 32:
-                return 1.0
+            if nbr is None or F == 1 or C < 32 or not timers.exec_fractions:
+                return 1.0            # (exec_fractions is on in the untimed per-launch detail pass only: the mirror syncs the device)
             key = (nbr.data_ptr(), C, F, perm.data_ptr() if perm is not None else 0, rows)
             if key not in ef_cache:
                 ef_cache[key] = needed_slice_fraction(types.SimpleNamespace(t=nbr, perm=perm), C, BM=rows)
@@ -313,7 +314,11 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
     main = torch.cuda.current_stream(dev)
     # as `bench.py --train`: the lattice of the next pair is built on a second stream while this pair trains; exactly one
     # build and one optimiser step per timed step
-    pipe = LatticePipeline(gen, lambda i: pairs[i % len(pairs)], 0, warmup + steps, depth=2, stream=side, for_training=True)
+    # the native (fused) builder on a producer thread: the tables of the training path (tap lists, symmetry verdicts) are added
+    # there too, off the thread that issues the ~900 launches of the step
+    nat = not os.environ.get('HPL_TRAIN_PY_LATTICE')
+    pipe = LatticePipeline(gen, lambda i: pairs[i % len(pairs)], 0, warmup + steps, depth=2, stream=side, for_training=True,
+                           native=nat, threaded=nat)
     keep = []
 
     def one():
@@ -522,9 +527,10 @@ def main():
         import collections
         from hplflownet_amd.lattice import LatticePipeline
 
+        nat_lat = (native or a.train) and not a.python_lattice      # (training: native lattice, Python autograd forward)
         pipe = None if fixed is not None else LatticePipeline(
             gen, lambda i: pairs[i % a.pool], first, count, depth=a.lattice_depth, stream=side, for_training=a.train,
-            native=native and not a.python_lattice, threaded=native and not a.python_lattice and a.lattice_thread)
+            native=nat_lat, threaded=nat_lat and a.lattice_thread)
         done_ev = torch.cuda.Event()
         done_ev.record()
         nxt = [first]
@@ -605,7 +611,7 @@ def main():
             native_prof = plan.profile_read()
         parallel.barrier()
         elapsed = parallel.max_over_ranks(elapsed, device=dev)
-        host_line = host_report(host, a.steps, threaded=native and not a.python_lattice and a.lattice_thread) if overlap else None      # (the regions below run the same loop: snapshot first)
+        host_line = host_report(host, a.steps, threaded=(native or a.train) and not a.python_lattice and a.lattice_thread) if overlap else None      # (the regions below run the same loop: snapshot first)
         # every rank's own step time and host busy time (rank 0 prints them: a slow rank, or a host that cannot feed 8 GPUs, shows here)
         rank_stats = parallel.gather_floats([rank_elapsed * 1e3 / a.steps, (host_line or {}).get('busy_ms', 0.0),
                                              float(pin.get('numa_node') if pin.get('numa_node') is not None else -1)], device=dev)
@@ -679,6 +685,7 @@ def main():
     timers.records = []
     timers.only = None
     timers.enabled = True
+    timers.exec_fractions = True
     clk = torch.zeros(4, dtype=torch.int64, device=dev)
     ops.CLOCK_PROBE = clk                    # the wide row-ordered launches stamp their first workgroup's clocks
     model.native_forward = False             # launch by launch, an event pair around each
@@ -688,6 +695,7 @@ def main():
     torch.cuda.synchronize()
     model.native_forward = native
     timers.enabled = False
+    timers.exec_fractions = False
     ops.CLOCK_PROBE = None
     cyc, ticks = clk.tolist()[:2]
     clock_ghz = cyc / float(ticks) * 0.1 if ticks > 0 else None

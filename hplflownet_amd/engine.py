@@ -142,8 +142,11 @@ class Trainer(object):
         the lattices of the next `depth` samples are under construction on the side stream while the
         current one is consumed, and the host never blocks on their vertex-count read-backs."""
         main = torch.cuda.current_stream(self.device)
+        # the native (fused) builder drives both; in training it also adds the tables of the backward (tap lists, symmetry
+        # verdicts) -- on a producer thread, off the thread that issues the step's launches
         pipe = LatticePipeline(self.gen, lambda k: data[order[k]], 0, len(order), depth=depth, stream=self._side,
-                               for_training=training, native=not training)      # inference: native builder + native forward
+                               for_training=training, native=self.gen.native_supported(),
+                               threaded=training and self.gen.native_supported())
         keep = collections.deque()
         for _ in range(len(order)):
             (_, sample), lat, ev = pipe.get()

@@ -54,6 +54,14 @@ class GenerateDataUnsymmetric(object):
             self._native = NativeBuilder(self)
         return self._native
 
+    def native_supported(self):
+        """True if csrc/lattice_builder.hip can build this configuration (radius-1 stencils, <= 8 levels)."""
+        try:
+            self.native_builder()
+            return True
+        except _lib.HplError:
+            return False
+
     def build_native(self, pc1, pc2):
         """The same lattice from the native builder (one arena, one C call per level half): -> NativeLattice."""
         return NativeLatticeBuild(self, pc1, pc2).finish()
