@@ -700,6 +700,27 @@ def main():
     cyc, ticks = clk.tolist()[:2]
     clock_ghz = cyc / float(ticks) * 0.1 if ticks > 0 else None
     kernels = timers.summary(detail_steps)
+    # The HBM-bound gathers move 10-60 MB per launch: at 8 TB/s that is 2-8 us, the order of what ANY dependent launch costs
+    # on this GPU.  Beside the fraction of the 8 TB/s peak, the line therefore carries what a plain device-to-device copy of
+    # the SAME number of bytes per launch reaches, timed the same way (HIP events around one launch, best of 30).
+    for nm, d in kernels.items():
+        if d.get('bound') != 'hbm' or not d.get('launches_per_step'):
+            continue
+        nbytes = int(d['mbytes_per_step'] * 1e6 / d['launches_per_step'])
+        src = torch.empty(max(16, nbytes // 2), dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        best = None
+        for _ in range(30):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst.copy_(src)
+            e1.record()
+            e1.synchronize()
+            t_ = e0.elapsed_time(e1) * 1e3
+            best = t_ if best is None else min(best, t_)
+        d['copy_of_same_bytes'] = {'bytes_per_launch': nbytes, 'us': best, 'GB/s': nbytes / (best * 1e-6) / 1e9,
+                                   'kernel_vs_copy': (nbytes / (best * 1e-6)) and d['achieved'] / (nbytes / (best * 1e-6) / 1e9)}
+        del src, dst
     if rank == 0:
         split3 = bool(ops.SPLIT3) and full
         lat0 = gen.build(*pairs[0])

@@ -148,17 +148,20 @@ class Trainer(object):
                                for_training=training, native=self.gen.native_supported(),
                                threaded=training and self.gen.native_supported())
         keep = collections.deque()
-        for _ in range(len(order)):
-            (_, sample), lat, ev = pipe.get()
-            main.wait_event(ev)
-            yield sample, lat
-            fin = torch.cuda.Event()
-            fin.record(main)
-            keep.append((lat, sample, fin))         # side-stream memory stays alive until its consumer is done
-            while len(keep) > 2:
-                keep.popleft()[2].synchronize()
-        for _, _, fin in keep:
-            fin.synchronize()
+        try:
+            for _ in range(len(order)):
+                (_, sample), lat, ev = pipe.get()
+                main.wait_event(ev)
+                yield sample, lat
+                fin = torch.cuda.Event()
+                fin.record(main)
+                keep.append((lat, sample, fin))         # side-stream memory stays alive until its consumer is done
+                while len(keep) > 2:
+                    keep.popleft()[2].synchronize()
+        finally:
+            pipe.close()                                # (a consumer that stops early must not leave the producer thread behind)
+            for _, _, fin in keep:
+                fin.synchronize()
 
     # ------------------------------------------------------------------ loops
     def train_epoch(self, data, order=None):

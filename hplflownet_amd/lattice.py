@@ -242,21 +242,39 @@ class LatticePipeline(object):
         # main.py:85-92).  The native builder spends its time inside C calls, which ctypes makes with the GIL released, so
         # the consumer's forward enqueue (also one C call) overlaps it on a second core.
         self._thread = self._queue = None
+        self._stop = False
         if threaded and count > 0:
             import queue
             import threading
             self._queue = queue.Queue(maxsize=self.depth)
             dev = torch.cuda.current_device()
 
+            def put(item):
+                while not self._stop:               # (a consumer that went away must not leave this thread blocked forever)
+                    try:
+                        self._queue.put(item, timeout=0.2)
+                        return True
+                    except queue.Full:
+                        pass
+                return False
+
             def produce():
                 try:
                     torch.cuda.set_device(dev)
                     for _ in range(count):
-                        self._queue.put(self._get())
+                        if self._stop or not put(self._get()):
+                            return
                 except BaseException as e:          # noqa: B902 -- handed to the consumer
-                    self._queue.put(e)
+                    put(e)
             self._thread = threading.Thread(target=produce, name='hpl-lattice', daemon=True)
             self._thread.start()
+
+    def close(self):
+        """Stop the producer thread (if any) and wait for it: call when the consumer abandons the pipeline early."""
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=5.0)
+            self._thread = None
 
     def _top_up(self):
         while len(self._inflight) < self.depth and self._next < self._end:

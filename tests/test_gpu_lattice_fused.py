@@ -177,3 +177,21 @@ def test_rebuild_is_deterministic(monkeypatch):
         b = gen.build_native(t1, t2)
         torch.cuda.synchronize()
         assert_same_lattice(a, b, 'rebuild')
+
+
+def test_abandoned_pipeline_stops_its_producer(monkeypatch):
+    from hplflownet_amd.lattice import LatticePipeline
+    gen = make_gen(5, True, monkeypatch)
+    pairs = []
+    for s_ in range(6):
+        p1, p2, _ = synthetic_pair(500, 70 + s_)
+        pairs.append((dev(p1), dev(p2)))
+    side = torch.cuda.Stream()
+    pipe = LatticePipeline(gen, lambda i: pairs[i], 0, len(pairs), depth=2, stream=side, native=True, threaded=True)
+    (i, _), lat, ev = pipe.get()
+    assert i == 0
+    th = pipe._thread
+    assert th is not None and th.is_alive()          # blocked: the queue is full, four pairs are still to come
+    pipe.close()
+    assert not th.is_alive()
+    torch.cuda.synchronize()
