@@ -38,12 +38,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=200)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--native', action='store_true', help='the native builder (fused driver, staged fallback on overflow) instead of the Python stage driver')
     a = ap.parse_args()
     rng = np.random.RandomState(a.seed)
     maps = [SCALES_FILTER_MAP, SCALES_FILTER_MAP[:5], [[4., 1, -1, -1], [1.5, 1, 1, 1], [0.7, 1, 1, 1], [0.2, 1, 1, 1]]]
     kinds = ['frustum', 'surface', 'cluster', 'dup', 'line', 'far', 'tiny']
     t0 = time.time()
     bad = 0
+    gens = {}
     for case in range(a.cases):
         kind = kinds[case % len(kinds)]
         big = case % 25 == 24
@@ -51,8 +53,13 @@ def main():
         n2 = max(1, int(n1 * rng.uniform(0.5, 1.2)))
         sfm = maps[case % len(maps)]
         p1, p2 = cloud(rng, n1, kind), cloud(rng, n2, kind)
-        gen = H.GenerateDataUnsymmetric(types.SimpleNamespace(dim=3, scales_filter_map=sfm), device='cuda')
-        _, _, _, lat = gen([p1, p2, np.zeros_like(p1)])
+        gen = gens.setdefault(id(sfm), H.GenerateDataUnsymmetric(types.SimpleNamespace(dim=3, scales_filter_map=sfm), device='cuda'))
+        if a.native:         # one builder per scale map: the vertex bounds adapt over the cases (and overflow now and then)
+            t1, t2 = (torch.from_numpy(np.ascontiguousarray(p.T)).cuda() for p in (p1, p2))
+            lat = gen.build_native(t1, t2)
+            torch.cuda.synchronize()
+        else:
+            _, _, _, lat = gen([p1, p2, np.zeros_like(p1)])
         gd = LO.generate_data(p1, p2, sfm)
         for l, (x, y) in enumerate(zip(H.to_reference_format(lat), gd)):
             for k in y:
@@ -62,6 +69,8 @@ def main():
                     print('MISMATCH case %d kind %s n=(%d,%d) level %d key %s' % (case, kind, n1, n2, l, k))
         if case % 20 == 19:
             print('case %d ok so far (%d mismatches) %.0f s' % (case + 1, bad, time.time() - t0), flush=True)
+    if a.native:
+        print('native builders: fused %s, staged fallbacks %s' % ([g.native_builder().fused for g in gens.values()], [g.native_builder().fallbacks for g in gens.values()]))
     print('DONE %d cases, %d mismatching tables, %.0f s' % (a.cases, bad, time.time() - t0))
     return 1 if bad else 0
 
