@@ -45,13 +45,19 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s 
 def split3_takes(M, N, C, F, scat=False):
     """Mirror of hpl_gc::launch_split3 (csrc/gconv3.hip): which launches run on the bf16 MFMA with split operands."""
     from hplflownet_amd import ops
-    if not (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N >= 256 and F <= 15 and
-            M >= int(os.environ.get('HPL_SPLIT3_MIN_ROWS', 8192))):
+    env = lambda k, d: int(os.environ.get(k, d))
+    if not (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N >= 256 and F <= 15 and M >= env('HPL_SPLIT3_FLOOR_ROWS', 2048)):
         return False
-    if F == 1 or M >= int(os.environ.get('HPL_SPLIT3_MIN_ROWS_STENCIL', 16384)):
-        return True
-    # mid-size stencils: only split over K into one round of workgroups (partial tiles in the split-K workspace)
     tiles = -(-M // 128) * -(-N // 256)
+    fills = tiles >= env('HPL_SPLIT3_FILL_TILES', 128)
+    min_rows = env('HPL_SPLIT3_MIN_ROWS', 8192)
+    if F == 1:
+        return M >= min_rows or fills
+    if M >= env('HPL_SPLIT3_MIN_ROWS_STENCIL', 16384) or fills:
+        return True
+    if M < min_rows:
+        return False
+    # mid-size stencils: only split over K into one round of workgroups (partial tiles in the split-K workspace)
     splitk = min(8, 256 // max(1, tiles), (-(-F * C // 32)) // 16)
     return (os.environ.get('HPL_SPLIT3_MID_SPLITK', '1') != '0' and splitk >= 2 and N % 256 == 0 and M * N <= (8 << 20) and
             splitk * M * N * 4 <= (256 << 20))
@@ -365,8 +371,8 @@ def source_stamp():
     h = hashlib.sha256()
     for f in ('gconv.hip', 'gconv3.hip', 'gconv_common.h', 'executor.hip', 'row_order.hip'):
         h.update(open(os.path.join(ROOT, 'hplflownet_amd', 'csrc', f), 'rb').read())
-    for k in ('HPL_MATH', 'HPL_SPLIT3_BN', 'HPL_TAP_GROUPS', 'HPL_TILE', 'HPL_WG3', 'HPL_SPLIT3_MIN_ROWS', 'HPL_SPLIT3_MIN_ROWS_STENCIL',
-              'HPL_SPLIT3_NB', 'HPL_SPLIT3_BN256_PCT', 'HPL_SPLIT3_MID_SPLITK', 'HPL_ROW_ORDER', 'HPL_FUSE_NARROW', 'HPL_SPLIT3_EPILOGUE',
+    for k in ('HPL_MATH', 'HPL_SPLIT3_BN', 'HPL_TAP_GROUPS', 'HPL_TILE', 'HPL_WG3', 'HPL_SPLIT3_MIN_ROWS', 'HPL_SPLIT3_MIN_ROWS_STENCIL', 'HPL_SPLIT3_FILL_TILES', 'HPL_SPLIT3_FLOOR_ROWS',
+              'HPL_SPLIT3_NB', 'HPL_SPLIT3_BN256_PCT', 'HPL_PERM_MIN_ROWS', 'HPL_SPLIT3_MID_SPLITK', 'HPL_ROW_ORDER', 'HPL_FUSE_NARROW', 'HPL_SPLIT3_EPILOGUE',
               'HPL_GCONV_EPILOGUE'):
         h.update(('%s=%s;' % (k, os.environ.get(k, ''))).encode())
     return h.hexdigest()

@@ -81,7 +81,8 @@ class LatticeSpec(ctypes.Structure):
     """Mirror of `hpl_lattice_spec`."""
     _fields_ = [('n_levels', c_i32), ('scale', c_f32 * 8), ('bcn_radius', c_i32 * 8), ('corr_filter_radius', c_i32 * 8),
                 ('corr_corr_radius', c_i32 * 8), ('next_divisor', c_f32 * 8), ('wide_up', c_i32 * 8), ('n_groups', c_i32),
-                ('group_cut', c_i32 * 5), ('groups_min_sparsity', c_f32), ('perm_min_rows', c_i64), ('group_tile_bm', c_i32),
+                ('group_cut', c_i32 * 5), ('groups_min_sparsity', c_f32), ('perm_min_rows', c_i64), ('groups_min_rows', c_i64),
+                ('group_tile_bm', c_i32),
                 ('fused', c_i32)]
 
 

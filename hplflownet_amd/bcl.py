@@ -109,7 +109,7 @@ class NbrTable(object):
 
     #: smaller tables are not reordered: on the coarse levels > 90 % of the taps are present (measured:
     #: level 2 of the N=8192 frustum skips < 3 % of the slices), the sort costs more than it saves
-    PERM_MIN_ROWS = 16384
+    PERM_MIN_ROWS = int(os.environ.get('HPL_PERM_MIN_ROWS', '16384'))
 
     def __init__(self, t):
         self.t = t
@@ -141,6 +141,9 @@ class NbrTable(object):
     #: levels with at least this many lattice vertices per input point get the passes (level 0: 3.2, level 1:
     #: 1.34 -- bcn1_ and bcn2_; measured end to end 2.0 -> 1.2: 212.5 -> 218.5 pairs/s)
     GROUPS_MIN_SPARSITY = float(os.environ.get('HPL_GROUPS_MIN_SPARSITY', '1.2'))
+    #: ... and at least this many rows: the passes run on the split-operand kernel's 128 x 256 tiles, which take a launch that
+    #: fills half the CUs in one round (csrc/gconv3.hip fill_tiles) -- clouds of 2 048 points: 384 -> 717 pairs/s
+    GROUPS_MIN_ROWS = int(os.environ.get('HPL_GROUPS_MIN_ROWS', '4096'))
 
     def groups(self):
         """[(f0, f1, perm)] for TAP_GROUPS groups of consecutive taps, each with its own row order
@@ -149,7 +152,7 @@ class NbrTable(object):
             F, M = self.t.shape
             G = self.TAP_GROUPS
             sparse = self.vertices_per_point is None or self.vertices_per_point >= self.GROUPS_MIN_SPARSITY
-            if G <= 1 or not sparse or not (1 < F <= 15 and M >= self.PERM_MIN_ROWS):
+            if G <= 1 or not sparse or not (1 < F <= 15 and M >= self.GROUPS_MIN_ROWS):
                 self._groups = None
             else:
                 cuts = [round(i * F / G) for i in range(G + 1)]

@@ -773,13 +773,21 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // single-pass stencils of the mid-size levels (bcn3_: 9 433 rows x 15 taps x 388 channels) run faster on the fp32 kernel's
     // 64 x 64 tiles (0.31 vs 0.45 ms: a 128-row tile unites many more tap masks); dense launches gain from 8 192 rows on
     static const int min_rows_stencil = getenv("HPL_SPLIT3_MIN_ROWS_STENCIL") ? atoi(getenv("HPL_SPLIT3_MIN_ROWS_STENCIL")) : 16384;
-    if (p.M < min_rows || p.N < 256) return false;
-    // Stencils below min_rows_stencil rows leave most CUs without a tile (bcn3_: 74 row tiles x 1 column tile): they run here
+    // ... unless the launch still fills most of the GPU with 128 x 256 tiles in ONE round (small clouds: at N = 2 048 points the
+    // two wide Up convs are 51 x 4 and 68 x 2 tiles -- on the fp32 kernel they were 1.18 + 0.59 ms of a 3.7 ms forward)
+    static const int fill_tiles = getenv("HPL_SPLIT3_FILL_TILES") ? atoi(getenv("HPL_SPLIT3_FILL_TILES")) : 128;
+    static const int floor_rows = getenv("HPL_SPLIT3_FLOOR_ROWS") ? atoi(getenv("HPL_SPLIT3_FLOOR_ROWS")) : 2048;
+    if (p.N < 256 || p.M < floor_rows) return false;
+    const int64_t tiles256 = cdiv(p.M, BM3) * cdiv(p.N, 256);
+    const bool fills = tiles256 >= fill_tiles;
+    if (p.F == 1 && p.M < min_rows && !fills) return false;
+    // Stencils below min_rows_stencil rows that leave most CUs without a tile (bcn3_: 74 row tiles x 1 column tile): they run here
     // only split over K into enough workgroups for one round (partial tiles in the caller's workspace), else on the fp32 kernel
     int splitk = 1;
-    if (p.F > 1 && p.M < min_rows_stencil) {
+    if (p.F > 1 && p.M < min_rows_stencil && !fills) {
         static const int mid_split = getenv("HPL_SPLIT3_MID_SPLITK") ? atoi(getenv("HPL_SPLIT3_MID_SPLITK")) : 1;
-        const int64_t tiles = cdiv(p.M, BM3) * cdiv(p.N, 256);
+        if (p.M < min_rows) return false;
+        const int64_t tiles = tiles256;
         const int nk_all = (p.K + BK - 1) / BK;
         splitk = (int)imin(imin(8, 256 / imax(1, tiles)), nk_all / 16);
         if (!mid_split || !p.ws || p.scat || splitk < 2 || (int64_t)splitk * p.M * p.N * 4 > p.ws_bytes || p.N % 256 > 0) return false;

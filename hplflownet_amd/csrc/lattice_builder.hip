@@ -184,10 +184,11 @@ int level_tail(hpl_lattice *b) {
             rc = order_of(b, blur, Hp, F, Hp, &t.blur_perm, &t.blur_perm_tidx, &t.blur_perm_tmask);
             if (rc) return rc;
         }
-        if (H0 >= sp.perm_min_rows) {
+        {
             const int wide = sp.wide_up[L];
+            const int64_t gmin = sp.groups_min_rows > 0 ? sp.groups_min_rows : sp.perm_min_rows;
             const bool sparse = (double)H0 / (double)n0 >= (double)sp.groups_min_sparsity;
-            const bool grouped = wide != 0 && sp.n_groups >= 2 && sparse;
+            const bool grouped = wide != 0 && sp.n_groups >= 2 && sparse && H0 >= gmin;
             if (grouped) {
                 t.n_up_groups = sp.n_groups;
                 for (int g = 0; g < sp.n_groups; ++g) {
@@ -199,7 +200,7 @@ int level_tail(hpl_lattice *b) {
                 }
             }
             // the single-pass order: needed unless the Up conv surely runs as groups; corr1 (same table) uses it too
-            if (!(grouped && wide == 1) || (cf != -1 && !corr1)) {
+            if (H0 >= sp.perm_min_rows && (!(grouped && wide == 1) || (cf != -1 && !corr1))) {
                 rc = order_of(b, blur, Hp, F, H0, &t.up_perm, &t.up_perm_tidx, &t.up_perm_tmask);
                 if (rc) return rc;
             }
@@ -247,7 +248,8 @@ int fused_finish(hpl_lattice *b) {
         if (has_corr) { t.corr1 = V.blur; t.corr1_stride = Hp; t.corr2 = V.corr2; }
         const int wide = sp.wide_up[L];
         const bool sparse = (double)H0 / (double)n0 >= (double)sp.groups_min_sparsity;
-        const bool grouped = H0 >= sp.perm_min_rows && wide != 0 && sp.n_groups >= 2 && sparse;
+        const int64_t gmin = sp.groups_min_rows > 0 ? sp.groups_min_rows : sp.perm_min_rows;
+        const bool grouped = H0 >= gmin && wide != 0 && sp.n_groups >= 2 && sparse;
         const bool single = H0 >= sp.perm_min_rows && (!(grouped && wide == 1) || has_corr);
         for (int q = 0; q < V.n_jobs; ++q) {
             const fused::SortJob &J = V.job[q];

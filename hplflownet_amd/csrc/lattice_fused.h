@@ -40,8 +40,9 @@ struct Level {
     float scale, prev_div;
     int32_t prev_vstride[2], vstride[2];
     int32_t has_blur, has_corr, wide, n_groups;
-    int32_t perm_min_rows;
+    int32_t perm_min_rows, groups_min_rows;
     float min_sparsity;
+    int32_t pad0_;
     const float *pc[2];           // level 0 only
     const int32_t *prev_vk[2];
     int32_t *hdr, *dims;

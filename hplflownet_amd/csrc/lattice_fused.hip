@@ -57,12 +57,11 @@ __device__ __forceinline__ int dcdiv(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ int job_rows(const Level &L, const SortJob &J) {
     const int H0 = L.dims[D_H0], H1 = L.dims[D_H1];
     if (J.role == 0) return (H0 + H1 >= L.perm_min_rows) ? H0 + H1 : 0;
-    if (H0 < L.perm_min_rows) return 0;
     const int n0 = npts(L, 0);
     const bool sparse = (double)H0 / (double)n0 >= (double)L.min_sparsity;
-    const bool grouped = L.wide != 0 && L.n_groups >= 2 && sparse;
+    const bool grouped = L.wide != 0 && L.n_groups >= 2 && sparse && H0 >= L.groups_min_rows;
     if (J.role >= 2) return grouped ? H0 : 0;
-    return (!(grouped && L.wide == 1) || L.has_corr) ? H0 : 0;
+    return (H0 >= L.perm_min_rows && (!(grouped && L.wide == 1) || L.has_corr)) ? H0 : 0;
 }
 
 // exclusive scan of one int per thread over the 256 threads of the workgroup (scr: 8 ints of LDS); *total = the sum
@@ -768,6 +767,7 @@ int64_t layout(const hpl_lattice_spec &sp, int64_t n0, int64_t n1, const int64_t
         L.wide = sp.wide_up[Li];
         L.n_groups = sp.n_groups;
         L.perm_min_rows = (int32_t)imin(sp.perm_min_rows, INT32_MAX);
+        L.groups_min_rows = (int32_t)imin(sp.groups_min_rows > 0 ? sp.groups_min_rows : sp.perm_min_rows, INT32_MAX);
         L.min_sparsity = sp.groups_min_sparsity;
         L.hdr = plan.d_dims;
         L.dims = plan.d_dims ? plan.d_dims + DIM_INTS * (1 + Li) : nullptr;
@@ -823,13 +823,10 @@ int64_t layout(const hpl_lattice_spec &sp, int64_t n0, int64_t n1, const int64_t
         };
         const int gbm = sp.group_tile_bm == 128 ? 128 : 64;
         if (Hbp >= sp.perm_min_rows) add_job(1, 0, 0, 15, 64, Hbp);
-        if (Hb[0] >= sp.perm_min_rows) {
-            const bool may_group = L.wide != 0 && sp.n_groups >= 2;
-            if (may_group)
-                for (int g = 0; g < sp.n_groups; ++g)
-                    add_job(2, 2 + g, sp.group_cut[g], sp.group_cut[g + 1] - sp.group_cut[g], gbm, Hb[0]);
-            add_job(2, 1, 0, 15, 64, Hb[0]);
-        }
+        if (L.wide != 0 && sp.n_groups >= 2 && Hb[0] >= L.groups_min_rows)
+            for (int g = 0; g < sp.n_groups; ++g)
+                add_job(2, 2 + g, sp.group_cut[g], sp.group_cut[g + 1] - sp.group_cut[g], gbm, Hb[0]);
+        if (Hb[0] >= sp.perm_min_rows) add_job(2, 1, 0, 15, 64, Hb[0]);
         L.n_jobs = nj;
         nb[0] = Hb[0]; nb[1] = Hb[1];
     }

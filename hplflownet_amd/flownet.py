@@ -172,6 +172,8 @@ class DeviceLattice(object):
                 lv.clouds.append(ops.CloudTables(bary, off, lv.H[ci]))
                 bl = t(nm + '_blur_neighbors')
                 lv.blur.append(NbrTable(ops.narrow(bl.reshape(-1, lv.H[ci]))) if bl.numel() > 1 else None)
+                if lv.blur[-1] is not None:      # the same sparsity rule as a device-built lattice (tap groups only where most slots are empty)
+                    lv.blur[-1].vertices_per_point = lv.H[ci] / float(max(1, bary.shape[1]))
                 lv.emg.append(t(nm + '_el_minus_gr').reshape(4, -1).float().t().contiguous())
             c1 = t('pc1_corr_indices')
             if c1.numel() > 1:

@@ -483,6 +483,7 @@ class NativeBuilder(object):
             sp.group_cut[i] = round(i * F / G)
         sp.groups_min_sparsity = NbrTable.GROUPS_MIN_SPARSITY
         sp.perm_min_rows = NbrTable.PERM_MIN_ROWS
+        sp.groups_min_rows = NbrTable.GROUPS_MIN_ROWS
         sp.group_tile_bm = ops.GROUP_TILE_BM
         # fused driver (csrc/lattice_fused.hip): the whole build enqueued by hpl_lattice_begin, one read-back per pair.
         # HPL_LATTICE_FUSED=0 keeps the staged driver (one read-back per level); specs it cannot build stay staged too.

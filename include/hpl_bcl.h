@@ -544,7 +544,8 @@ typedef struct hpl_lattice_spec {
     int32_t n_groups;                            /* tap groups (>= 2) and their cuts, e.g. {0, 8, 15} */
     int32_t group_cut[5];
     float groups_min_sparsity;                   /* groups only where H0 / n0 >= this */
-    int64_t perm_min_rows;                       /* row orders only for tables with at least this many rows */
+    int64_t perm_min_rows;                       /* single-pass row orders only for tables with at least this many rows */
+    int64_t groups_min_rows;                     /* tap-group row orders (wide, sparse levels) from this many cloud-1 vertices on (0 = perm_min_rows) */
     int32_t group_tile_bm;                       /* tile height of the tap-group tile tables: 64 or 128 (0 = 64) */
     int32_t fused;                               /* != 0: hpl_lattice_begin enqueues the whole build, the vertex counts stay on the
                                                     device and are read back once (csrc/lattice_fused.hip); radius-1 specs only */
