@@ -46,7 +46,7 @@ def split3_takes(M, N, C, F, scat=False):
     """Mirror of hpl_gc::launch_split3 (csrc/gconv3.hip): which launches run on the bf16 MFMA with split operands."""
     from hplflownet_amd import ops
     env = lambda k, d: int(os.environ.get(k, d))
-    if not (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N >= 256 and F <= 15 and M >= env('HPL_SPLIT3_FLOOR_ROWS', 2048)):
+    if not (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N >= 256 and F <= 15 and M >= env('HPL_SPLIT3_FLOOR_ROWS', 1024)):
         return False
     tiles = -(-M // 128) * -(-N // 256)
     fills = tiles >= env('HPL_SPLIT3_FILL_TILES', 128)
@@ -55,7 +55,7 @@ def split3_takes(M, N, C, F, scat=False):
         return M >= min_rows or fills
     if M >= env('HPL_SPLIT3_MIN_ROWS_STENCIL', 16384) or fills:
         return True
-    if M < min_rows:
+    if M < env('HPL_SPLIT3_MID_MIN_ROWS', 1024):
         return False
     # mid-size stencils: only split over K into one round of workgroups (partial tiles in the split-K workspace)
     splitk = min(8, 256 // max(1, tiles), (-(-F * C // 32)) // 16)
@@ -371,7 +371,7 @@ def source_stamp():
     h = hashlib.sha256()
     for f in ('gconv.hip', 'gconv3.hip', 'gconv_common.h', 'executor.hip', 'row_order.hip'):
         h.update(open(os.path.join(ROOT, 'hplflownet_amd', 'csrc', f), 'rb').read())
-    for k in ('HPL_MATH', 'HPL_SPLIT3_BN', 'HPL_TAP_GROUPS', 'HPL_TILE', 'HPL_WG3', 'HPL_SPLIT3_MIN_ROWS', 'HPL_SPLIT3_MIN_ROWS_STENCIL', 'HPL_SPLIT3_FILL_TILES', 'HPL_SPLIT3_FLOOR_ROWS',
+    for k in ('HPL_MATH', 'HPL_SPLIT3_BN', 'HPL_TAP_GROUPS', 'HPL_TILE', 'HPL_WG3', 'HPL_SPLIT3_MIN_ROWS', 'HPL_SPLIT3_MIN_ROWS_STENCIL', 'HPL_SPLIT3_FILL_TILES', 'HPL_SPLIT3_FLOOR_ROWS', 'HPL_SPLIT3_MID_MIN_ROWS',
               'HPL_SPLIT3_NB', 'HPL_SPLIT3_BN256_PCT', 'HPL_PERM_MIN_ROWS', 'HPL_SPLIT3_MID_SPLITK', 'HPL_ROW_ORDER', 'HPL_FUSE_NARROW', 'HPL_SPLIT3_EPILOGUE',
               'HPL_GCONV_EPILOGUE'):
         h.update(('%s=%s;' % (k, os.environ.get(k, ''))).encode())

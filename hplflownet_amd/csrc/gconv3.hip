@@ -776,7 +776,7 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // ... unless the launch still fills most of the GPU with 128 x 256 tiles in ONE round (small clouds: at N = 2 048 points the
     // two wide Up convs are 51 x 4 and 68 x 2 tiles -- on the fp32 kernel they were 1.18 + 0.59 ms of a 3.7 ms forward)
     static const int fill_tiles = getenv("HPL_SPLIT3_FILL_TILES") ? atoi(getenv("HPL_SPLIT3_FILL_TILES")) : 128;
-    static const int floor_rows = getenv("HPL_SPLIT3_FLOOR_ROWS") ? atoi(getenv("HPL_SPLIT3_FLOOR_ROWS")) : 2048;
+    static const int floor_rows = getenv("HPL_SPLIT3_FLOOR_ROWS") ? atoi(getenv("HPL_SPLIT3_FLOOR_ROWS")) : 1024;
     if (p.N < 256 || p.M < floor_rows) return false;
     const int64_t tiles256 = cdiv(p.M, BM3) * cdiv(p.N, 256);
     const bool fills = tiles256 >= fill_tiles;
@@ -786,7 +786,8 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     int splitk = 1;
     if (p.F > 1 && p.M < min_rows_stencil && !fills) {
         static const int mid_split = getenv("HPL_SPLIT3_MID_SPLITK") ? atoi(getenv("HPL_SPLIT3_MID_SPLITK")) : 1;
-        if (p.M < min_rows) return false;
+        static const int mid_min_rows = getenv("HPL_SPLIT3_MID_MIN_ROWS") ? atoi(getenv("HPL_SPLIT3_MID_MIN_ROWS")) : 1024;      // (round 4: from 8 192; N = 2 048 clouds +8 %, N = 8 192 unchanged)
+        if (p.M < mid_min_rows) return false;
         const int64_t tiles = tiles256;
         const int nk_all = (p.K + BK - 1) / BK;
         splitk = (int)imin(imin(8, 256 / imax(1, tiles)), nk_all / 16);
