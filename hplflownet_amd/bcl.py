@@ -142,8 +142,8 @@ class NbrTable(object):
     #: 1.34 -- bcn1_ and bcn2_; measured end to end 2.0 -> 1.2: 212.5 -> 218.5 pairs/s)
     GROUPS_MIN_SPARSITY = float(os.environ.get('HPL_GROUPS_MIN_SPARSITY', '1.2'))
     #: ... and at least this many rows: the passes run on the split-operand kernel's 128 x 256 tiles, which take a launch that
-    #: fills half the CUs in one round (csrc/gconv3.hip fill_tiles) -- clouds of 2 048 points: 384 -> 717 pairs/s
-    GROUPS_MIN_ROWS = int(os.environ.get('HPL_GROUPS_MIN_ROWS', '4096'))
+    #: fills half the CUs in one round or splits over K (csrc/gconv3.hip) -- clouds of 2 048 points: 384 -> 720 pairs/s, 1 024: 620 -> 930
+    GROUPS_MIN_ROWS = int(os.environ.get('HPL_GROUPS_MIN_ROWS', '2048'))
 
     def groups(self):
         """[(f0, f1, perm)] for TAP_GROUPS groups of consecutive taps, each with its own row order
