@@ -600,7 +600,8 @@ def main():
         plan = model.forward_plan() if native else None
         if plan is not None:
             from hplflownet_amd.plan import TAG_WIDE_BLUR
-            plan.profile(TAG_WIDE_BLUR)       # HIP events around the wide stencil convs, on the stream they run on
+            if not os.environ.get('HPL_BENCH_NO_INLOOP_EVENTS'):
+                plan.profile(TAG_WIDE_BLUR)       # HIP events around the wide stencil convs, on the stream they run on
         t0 = time.perf_counter()
         if overlap:
             y = run_pipelined(PREWARM + a.warmup, a.steps)
