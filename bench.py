@@ -585,7 +585,7 @@ def main():
     with torch.set_grad_enabled(a.train):
         # one-time costs (weight images, allocator pools of every stream, lazy module loads) are paid by
         # PREWARM untimed steps of our own, so that --warmup 0 still measures the steady state
-        PREWARM = 3
+        PREWARM = int(os.environ.get('HPL_BENCH_PREWARM', '3'))
         if overlap:
             run_pipelined(0, PREWARM + a.warmup)
         else:
