@@ -195,3 +195,36 @@ def test_abandoned_pipeline_stops_its_producer(monkeypatch):
     pipe.close()
     assert not th.is_alive()
     torch.cuda.synchronize()
+
+
+def test_builder_protocol_errors(monkeypatch):
+    """misuse of the hpl_lattice_* calls is reported, not executed: bounds while a build is in flight, a too small arena
+    (HPL_ENOMEM with the size the fused layout needs known up front), advance without a build"""
+    import ctypes
+    from hplflownet_amd import _lib
+    gen = make_gen(7, True, monkeypatch)
+    nb = gen.native_builder()
+    L = nb.lib
+    h = nb.acquire()
+    try:
+        d = ctypes.c_int(0)
+        assert L.hpl_lattice_advance(h, ctypes.byref(d)) != 0 and b'no build' in L.hpl_last_error()
+        pc1, pc2, _ = synthetic_pair(2000, 5)
+        t1, t2 = dev(pc1), dev(pc2)
+        need = int(L.hpl_lattice_arena_bytes(h, 2000, 2000))
+        assert need > 0
+        small = torch.empty(need // 2, dtype=torch.uint8, device=DEV)
+        assert L.hpl_lattice_begin(h, t1.data_ptr(), t2.data_ptr(), 2000, 2000, small.data_ptr(), small.numel(), _lib.stream()) == -4
+        arena = torch.empty(need + 4096, dtype=torch.uint8, device=DEV)
+        assert L.hpl_lattice_begin(h, t1.data_ptr(), t2.data_ptr(), 2000, 2000, arena.data_ptr(), arena.numel(), _lib.stream()) == 0
+        bounds = (ctypes.c_int64 * 8)(*([1 << 20] * 8))
+        assert L.hpl_lattice_set_bounds(h, bounds) != 0 and b'in progress' in L.hpl_last_error()
+        while not d.value:
+            assert L.hpl_lattice_advance(h, ctypes.byref(d)) == 0
+        assert L.hpl_lattice_set_bounds(h, bounds) == 0                   # finished: allowed again
+        st = (ctypes.c_int32 * 3)()
+        assert L.hpl_lattice_stats(h, st) == 0 and st[0] <= 60 and st[1] == 1
+        assert int(L.hpl_lattice_arena_bytes(h, 2000, 2000)) > need        # the bounds just set are larger than the defaults' cascade
+        torch.cuda.synchronize()
+    finally:
+        nb.release(h)
