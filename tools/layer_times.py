@@ -30,7 +30,7 @@ with torch.no_grad():
 print('forward total %.3f ms' % s0.elapsed_time(s1))
 tot = 0
 shapes = iter(shapes)
-for (name, fl, nb), s, e in timers.records:
+for (name, fl, nb, _ef), s, e in timers.records:
     us = 1e3 * s.elapsed_time(e); tot += us
     shp = ('M=%-6d N=%-5d C=%-4d F=%-2d' % next(shapes)) if fl else ''
     print('%-18s %9.1f us  %-34s %s' % (name, us, shp, ('%.1f GF %.1f TF' % (fl / 1e9, fl / us / 1e6)) if fl else ('%.1f MB %.0f GB/s' % (nb / 1e6, nb / us / 1e3))))
