@@ -23,7 +23,9 @@ Printed JSON (rank 0, one line): the contract fields plus
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 import types
 
@@ -364,6 +366,27 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
     return out
 
 
+def smi_sample(index):
+    """One rocm-smi reading of GPU `index`: package power, its limit, shader clock (None where rocm-smi has no answer)."""
+    try:
+        out = subprocess.run(['rocm-smi', '-d', str(index), '--showpower', '--showmaxpower', '--showclocks', '--json'],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=10).stdout.decode()
+        card = next(iter(json.loads(out).values()))
+    except Exception:
+        return None
+    def num(pred):
+        for k, v in card.items():
+            if pred(k.lower()):
+                try:
+                    return float(str(v).strip('()').lower().replace('mhz', '').replace('w', ''))
+                except ValueError:
+                    return None
+        return None
+    return {'package_w': num(lambda k: 'package power' in k and 'max' not in k),
+            'limit_w': num(lambda k: 'max' in k and 'power' in k),
+            'sclk_mhz': num(lambda k: k.startswith('sclk clock speed'))}
+
+
 def source_stamp():
     """What a PMC profile under profiles/ must have been taken with to describe THIS run's kernels: the kernel sources
     and the switches that select kernels / tiles."""
@@ -648,6 +671,39 @@ def main():
             fwd_only = {'steps': n3, 'pairs_per_s': world * n3 / e3, 'ms_per_step': 1e3 * e3 / n3}
             del fixed
 
+        # what the board draws while the loop runs (rocm-smi on rank 0's GPU, sampled from a thread during >= 3 s of the same
+        # loop on every rank): the wide launches are bound by the clock the chip sustains under matrix load, DESIGN.md 4.8
+        power = None
+        if overlap and not a.train and not os.environ.get('HPL_BENCH_NO_POWER'):
+            per = max(elapsed / a.steps, 1e-4)
+            n4 = max(a.steps, int(3.5 / per))
+            samples, stop = [], threading.Event()
+            def _watch():
+                time.sleep(0.6)
+                while not stop.is_set() and len(samples) < 4:
+                    smp = smi_sample(local_rank)
+                    if smp is None:
+                        return
+                    samples.append(smp)
+            th = threading.Thread(target=_watch, daemon=True) if rank == 0 else None
+            sync_all()
+            t1 = time.perf_counter()
+            if th is not None:
+                th.start()
+            run_pipelined(PREWARM + a.warmup, n4)
+            torch.cuda.synchronize()
+            e4 = time.perf_counter() - t1
+            stop.set()
+            if th is not None:
+                th.join(timeout=15)
+            e4 = parallel.max_over_ranks(e4, device=dev)
+            busy = [x for x in samples if x.get('package_w')]
+            if busy:
+                med = lambda k: sorted(x[k] for x in busy if x.get(k) is not None)[len([x for x in busy if x.get(k) is not None]) // 2] if any(x.get(k) is not None for x in busy) else None
+                power = {'package_w': med('package_w'), 'limit_w': med('limit_w'), 'sclk_mhz': med('sclk_mhz'), 'samples': len(busy),
+                         'pairs_per_s': world * n4 / e4, 'steps': n4,
+                         'note': 'rocm-smi on rank 0, sampled while the same pipelined loop runs on every rank'}
+
     # the pipelined loop's last output against a plain single-stream forward of the same pair (inference)
     pipe_check = None
     if overlap and not a.train:
@@ -873,7 +929,7 @@ def main():
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,
-                'host_ms_per_step': host_line, 'steady': steady, 'forward_only': fwd_only,
+                'host_ms_per_step': host_line, 'steady': steady, 'forward_only': fwd_only, 'power': power,
                 'ranks': {'world': world, 'backend': (torch.distributed.get_backend() if world > 1 else None),
                           'ranks_seen': len(rank_stats), 'ms_per_step_by_rank': [r[0] for r in rank_stats],
                           'host_busy_ms_by_rank': [r[1] for r in rank_stats], 'numa_node_by_rank': [int(r[2]) for r in rank_stats],

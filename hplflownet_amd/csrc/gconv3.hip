@@ -50,6 +50,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef HPL_PHASE_PROBE
 #define HPL_PHASE_PROBE 0
 #endif
+#ifndef HPL_FAKE_BALANCE
+#define HPL_FAKE_BALANCE 0
+#endif
 // Ping-pong schedule of the 8-wave tile (see gconv3_body): 1 = on; -DHPL_PP=0 builds the one-barrier form for A/B runs
 // (measured variants that did not pay -- one barrier per half-step, the non-MFMA work in the memory phase, register caps --
 // are in DESIGN.md 4.1 and profiles/r03s_variants_ab.txt, r04b_split3_pp3_ab.txt, not in this file)
@@ -124,6 +127,11 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     const bool probe = p.clock_probe && (blockIdx.x & 63) == 0 && t == 0;
     long long probe_c = 0, probe_w = 0;
     if (probe) { probe_c = (long long)__builtin_readcyclecounter(); probe_w = (long long)__builtin_amdgcn_s_memrealtime(); }
+    // -DHPL_PHASE_PROBE=2 (tools/tile_probe.py): EVERY workgroup leaves 4 words at clock_probe[64 + 4 * blockIdx.x]: wall ticks
+    // (100 MHz) at entry and exit, shader cycles of the main loop, slices | HW_ID << 16 | XCC id << 48
+    const bool tprobe = HPL_PHASE_PROBE == 2 && p.clock_probe && t == 0;
+    long long tp_w0 = 0, tp_c0 = 0, tp_loop = 0;
+    if (tprobe) tp_w0 = (long long)__builtin_amdgcn_s_memrealtime();
 
     // ---- tile prologue: output rows, source rows of every (tap, tile row), tap masks
     if (p.tile_idx && p.tile_bm == BM) {
@@ -346,6 +354,40 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     };
 
     using S2 = std::integral_constant<int, 2>;
+#if HPL_FAKE_BALANCE
+    // Timing-only diagnostic (results are garbage): what the row-ordered launches would take if their work were spread evenly --
+    // the first 256 * k workgroups each run total / (256 * k) slices of their own list (cyclically), the others leave.
+    if (p.row_perm && p.col_share > 0 && p.tile_idx && p.splits <= 1 && WGN == 4) {
+        const int nt = p.tiles_m * p.tiles_n, n_active = (nt / 256) * 256;
+        if (n_active > 0) {
+            if ((int)blockIdx.x >= n_active) return;
+            __syncthreads();
+            if (t == 0) tapmask_s[7] = 0;
+            __syncthreads();
+            int mine = 0;
+            for (int tl = t; tl < p.tiles_m; tl += NT) {
+                const int mk = p.tile_mask[(int64_t)tl * 8];
+                for (int kt = 0; kt < nk; ++kt) {
+                    const int f_lo = (kt * BK) / p.C, f_hi = min((kt * BK + BK - 1) / p.C, p.F - 1);
+                    int bits = 0;
+                    for (int f = f_lo; f <= f_hi; ++f) bits |= 1 << f;
+                    mine += (mk & bits) != 0;
+                }
+            }
+            if (mine) atomicAdd(tapmask_s + 7, mine);
+            __syncthreads();
+            const int total = tapmask_s[7] * p.tiles_n;
+            const int want = min(KLIST, total / n_active);
+            if (nsl > 0) {
+                for (int i = nsl + t; i < want; i += NT) Ks[i] = Ks[(i - nsl) % nsl];
+                __syncthreads();
+                nsl = want;
+            }
+        }
+    }
+#endif
+    const int tp_nsl = nsl;
+    if (tprobe) tp_c0 = (long long)__builtin_readcyclecounter();
     if (nsl > 0) {
         // the slice list is read through a register: lane l holds entry ks_cb + l (refilled every 32 slices), an entry is a
         // v_readlane -- no LDS round trip (+ the in-order wait behind whatever else is queued there) in front of the half-steps
@@ -374,9 +416,9 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         if (PP && wm == 1) asm volatile("s_barrier" ::: "memory");      // the second wave row runs one phase behind
 
         int sta = 0, stb = 0;                        // stages of the half-step being multiplied (A ring, B ring)
-        unsigned long long ph_t = HPL_PHASE_PROBE ? __builtin_readcyclecounter() : 0ull, ph_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+        unsigned long long ph_t = HPL_PHASE_PROBE == 1 ? __builtin_readcyclecounter() : 0ull, ph_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
         auto stamp = [&](int k) {
-            if (!HPL_PHASE_PROBE) return;
+            if (HPL_PHASE_PROBE != 1) return;
             const unsigned long long now = __builtin_readcyclecounter();
             ph_acc[k] += now - ph_t;
             ph_t = now;
@@ -414,9 +456,9 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                     }
                 // the loads of the compute phase before last have landed (in flight: the last compute phase's); fragments here,
                 // the LDS stores of the last compute phase done
-                const unsigned long long ph_issue = HPL_PHASE_PROBE ? __builtin_readcyclecounter() : 0ull;      // (read behind the wait)
+                const unsigned long long ph_issue = HPL_PHASE_PROBE == 1 ? __builtin_readcyclecounter() : 0ull;      // (read behind the wait)
                 wait_vm_lgkm0(inflight_tag);
-                if (HPL_PHASE_PROBE) ph_acc[4] += ph_issue - ph_t;
+                if (HPL_PHASE_PROBE == 1) ph_acc[4] += ph_issue - ph_t;
                 __builtin_amdgcn_sched_barrier(0);
                 stamp(0);
                 asm volatile("s_barrier" ::: "memory");
@@ -596,7 +638,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             if constexpr (ASETS == 3) { if (sl + 2 < nsl) slice_tail(sl + 2, S2{}); }
         }
         if (PP && wm == 0) asm volatile("s_barrier" ::: "memory");      // (the second wave row's last compute phase)
-        if (HPL_PHASE_PROBE && p.clock_probe && (blockIdx.x & 15) == 0 && lane == 0) {
+        if (tprobe) tp_loop = (long long)__builtin_readcyclecounter() - tp_c0;
+        if (HPL_PHASE_PROBE == 1 && p.clock_probe && (blockIdx.x & 15) == 0 && lane == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 8 + 4 * wm + k, ph_acc[k]);
             atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 20 + wm, ph_acc[4]);
@@ -692,6 +735,14 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                   (unsigned long long)((long long)__builtin_readcyclecounter() - probe_c));
         atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 1,
                   (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - probe_w));
+    }
+    if (tprobe) {
+        long long *rec = p.clock_probe + 64 + 4 * (int64_t)blockIdx.x;
+        rec[0] = tp_w0;
+        rec[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        rec[2] = tp_loop;
+        rec[3] = (long long)tp_nsl | ((long long)(__builtin_amdgcn_s_getreg(4 | (31 << 11))) << 16) |
+                 ((long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 48);
     }
 }
 
