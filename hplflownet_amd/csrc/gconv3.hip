@@ -50,9 +50,6 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef HPL_PHASE_PROBE
 #define HPL_PHASE_PROBE 0
 #endif
-#ifndef HPL_FAKE_BALANCE
-#define HPL_FAKE_BALANCE 0
-#endif
 // Ping-pong schedule of the 8-wave tile (see gconv3_body): 1 = on; -DHPL_PP=0 builds the one-barrier form for A/B runs
 // (measured variants that did not pay -- one barrier per half-step, the non-MFMA work in the memory phase, register caps --
 // are in DESIGN.md 4.1 and profiles/r03s_variants_ab.txt, r04b_split3_pp3_ab.txt, not in this file)
@@ -354,38 +351,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     };
 
     using S2 = std::integral_constant<int, 2>;
-#if HPL_FAKE_BALANCE
-    // Timing-only diagnostic (results are garbage): what the row-ordered launches would take if their work were spread evenly --
-    // the first 256 * k workgroups each run total / (256 * k) slices of their own list (cyclically), the others leave.
-    if (p.row_perm && p.col_share > 0 && p.tile_idx && p.splits <= 1 && WGN == 4) {
-        const int nt = p.tiles_m * p.tiles_n, n_active = (nt / 256) * 256;
-        if (n_active > 0) {
-            if ((int)blockIdx.x >= n_active) return;
-            __syncthreads();
-            if (t == 0) tapmask_s[7] = 0;
-            __syncthreads();
-            int mine = 0;
-            for (int tl = t; tl < p.tiles_m; tl += NT) {
-                const int mk = p.tile_mask[(int64_t)tl * 8];
-                for (int kt = 0; kt < nk; ++kt) {
-                    const int f_lo = (kt * BK) / p.C, f_hi = min((kt * BK + BK - 1) / p.C, p.F - 1);
-                    int bits = 0;
-                    for (int f = f_lo; f <= f_hi; ++f) bits |= 1 << f;
-                    mine += (mk & bits) != 0;
-                }
-            }
-            if (mine) atomicAdd(tapmask_s + 7, mine);
-            __syncthreads();
-            const int total = tapmask_s[7] * p.tiles_n;
-            const int want = min(KLIST, total / n_active);
-            if (nsl > 0) {
-                for (int i = nsl + t; i < want; i += NT) Ks[i] = Ks[(i - nsl) % nsl];
-                __syncthreads();
-                nsl = want;
-            }
-        }
-    }
-#endif
     const int tp_nsl = nsl;
     if (tprobe) tp_c0 = (long long)__builtin_readcyclecounter();
     if (nsl > 0) {
