@@ -1064,35 +1064,92 @@ __global__ void k_weight_relayout(const float *__restrict__ W, int64_t base, int
 // One launch for many re-layouts (all conv weights of a model, both directions): job j owns
 // destination elements [prefix[j], prefix[j+1]) of one buffer; mirror = taps stored in the order
 // (F - f) % F (the mirrored-gather data gradient).
-__global__ void k_weight_relayout_batch(const hpl_relayout_job *__restrict__ jobs, int njobs,
-                                        const int64_t *__restrict__ prefix, float *__restrict__ dst) {
-    const int64_t total = prefix[njobs];
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) {
-        int lo = 0, hi = njobs - 1;               // last job with prefix[job] <= i
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (prefix[mid] <= i) lo = mid; else hi = mid - 1;
+//
+// Both are transposes with a 60-byte inner run (F = 15 taps), so a thread per element reads or writes 4 bytes of every 128-byte
+// line it touches (77 MB of weights took 380 us in, 63 launches of 7-120 us out, per training step).  A work unit is 16
+// (F <= 3: 64) consecutive r of one job: per chunk of 32 q its source -- for the two layouts the model has, runs of 16 * F (forward image:
+// sr == F) or 32 * F (data-gradient image: sq == F) contiguous floats -- goes through LDS, and every global access is a full line.
+constexpr int RL_TQ = 32, RL_FMAX = 15, RL_JOBS = 1024;
+constexpr int RL_LDMAX = 16 * RL_FMAX + 1;
+__host__ __device__ __forceinline__ int rl_tr(int F) { return F <= 3 ? 64 : 16; }      // r per unit: runs of >= 64 floats
+
+__device__ __forceinline__ int relayout_unit_job(const int *upre, int njobs, int u) {
+    int lo = 0, hi = njobs - 1;                          // last job with upre[job] <= u
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (upre[mid] <= u) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) k_weight_relayout_batch(const hpl_relayout_job *__restrict__ jobs, int njobs,
+                                                               const int64_t *__restrict__ prefix, float *__restrict__ dst) {
+    __shared__ float tile[RL_TQ * RL_LDMAX];
+    __shared__ int upre[RL_JOBS + 1];
+    const int t = threadIdx.x;
+    for (int j = t; j < njobs; j += 256)             // units of a job: r-blocks x chunks of 32 columns (exact in a float: < 2^24)
+        tile[j] = (float)(((jobs[j].R + rl_tr(jobs[j].F) - 1) / rl_tr(jobs[j].F)) * (int)((jobs[j].ldw + RL_TQ - 1) / RL_TQ));
+    __syncthreads();
+    for (int j = t; j <= njobs; j += 256) {
+        int acc = 0;
+        for (int i = 0; i < j; ++i) acc += (int)tile[i];
+        upre[j] = acc;
+    }
+    __syncthreads();
+    const int units = upre[njobs];
+    const int lane = t & 31, grp = t >> 5;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int j = relayout_unit_job(upre, njobs, u);
+        const hpl_relayout_job jb = jobs[j];
+        float *out = dst + prefix[j];
+        const int F = jb.F, R = jb.R, Q = jb.Q;
+        const int64_t ldw = jb.ldw;
+        const int TR = rl_tr(F), LD = TR * F + 1;              // (odd: the store reads one q per lane)
+        const int qchunks = (int)((ldw + RL_TQ - 1) / RL_TQ), ul = u - upre[j];
+        const int r0 = (ul / qchunks) * TR, nr = min(TR, R - r0), q0 = (ul % qchunks) * RL_TQ;
+        const bool mode_a = F <= RL_FMAX && jb.sf == 1 && jb.sr == F, mode_b = F <= RL_FMAX && jb.sf == 1 && jb.sq == F;
+        const bool staged = mode_a || mode_b;
+        {
+            const int nq = max(0, min(RL_TQ, Q - q0));
+            if (mode_a) {               // fixed q: (r, f) contiguous
+                const int run = nr * F;
+                for (int i = t; i < nq * run; i += 256) {
+                    const int qi = i / run, x = i - qi * run;
+                    tile[qi * LD + x] = jb.W[jb.base + (int64_t)r0 * F + x + (int64_t)(q0 + qi) * jb.sq];
+                }
+            } else if (mode_b) {        // fixed r: (q, f) contiguous
+                const int run = nq * F;
+                for (int i = t; i < nr * run; i += 256) {
+                    const int ri = i / run, x = i - ri * run, qi = x / F, f = x - qi * F;
+                    tile[qi * LD + ri * F + f] = jb.W[jb.base + (int64_t)(r0 + ri) * jb.sr + (int64_t)q0 * F + x];
+                }
+            }
+            if (staged) __syncthreads();
+            for (int row = grp; row < F * TR; row += 8) {
+                const int f = row / TR, ri = row - f * TR;
+                if (ri >= nr || q0 + lane >= ldw) continue;
+                const int fd = jb.mirror ? (F - f) % F : f;
+                float v = 0.f;
+                if (lane < nq)
+                    v = staged ? tile[lane * LD + ri * F + f]
+                               : jb.W[jb.base + (int64_t)(r0 + ri) * jb.sr + (int64_t)(q0 + lane) * jb.sq + (int64_t)f * jb.sf];
+                out[((int64_t)fd * R + r0 + ri) * ldw + q0 + lane] = v;
+            }
+            if (staged) __syncthreads();
         }
-        const hpl_relayout_job jb = jobs[lo];
-        const int64_t e = i - prefix[lo];
-        const int64_t k = e / jb.ldw;
-        const int q = (int)(e - k * jb.ldw);
-        float v = 0.f;
-        if (q < jb.Q && k < (int64_t)jb.F * jb.R) {
-            const int fdst = (int)(k / jb.R);
-            const int r = (int)(k - (int64_t)fdst * jb.R);
-            const int f = jb.mirror ? (jb.F - fdst) % jb.F : fdst;
-            v = jb.W[jb.base + r * jb.sr + q * jb.sq + f * jb.sf];
+        if (r0 + TR >= R) {          // the last r-block clears its columns of the rows that pad F * R to a multiple of 32
+            const int64_t k_used = (int64_t)F * R, k_rows = (k_used + 31) / 32 * 32;
+            for (int64_t k = k_used + grp; k < k_rows; k += 8)
+                if (q0 + lane < ldw) out[k * ldw + q0 + lane] = 0.f;
         }
-        dst[i] = v;
     }
 }
 
-__global__ void k_weight_unlayout(const float *__restrict__ Wt, int64_t ldw, int R, int Q, int F,
-                                  float *__restrict__ W, int64_t base, int64_t sr, int64_t sq, int64_t sf,
-                                  int accumulate) {
+// inverse: W[base + r*sr + q*sq + f*sf] (+)= Wt[(f*R + r)*ldw + q]; small weights (a few workgroups' worth: launch latency is all
+// there is) one element per thread, the others with the same staging (reads of Wt are rows of 32 q)
+__global__ void k_weight_unlayout_small(const float *__restrict__ Wt, int64_t ldw, int R, int Q, int F,
+                                        float *__restrict__ W, int64_t base, int64_t sr, int64_t sq, int64_t sf,
+                                        int accumulate) {
     const int64_t total = (int64_t)F * R * Q;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1102,8 +1159,51 @@ __global__ void k_weight_unlayout(const float *__restrict__ Wt, int64_t ldw, int
         const int f = (int)(k / R);
         const int r = (int)(k - (int64_t)f * R);
         const float v = Wt[k * ldw + q];
-        float *dst = W + base + r * sr + q * sq + f * sf;
-        *dst = accumulate ? *dst + v : v;
+        float *d = W + base + r * sr + q * sq + f * sf;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_weight_unlayout(const float *__restrict__ Wt, int64_t ldw, int R, int Q, int F,
+                                                         float *__restrict__ W, int64_t base, int64_t sr, int64_t sq, int64_t sf,
+                                                         int accumulate) {
+    __shared__ float tile[RL_TQ * RL_LDMAX];
+    const int t = threadIdx.x, lane = t & 31, grp = t >> 5;
+    const bool mode_a = F <= RL_FMAX && sf == 1 && sr == F, mode_b = F <= RL_FMAX && sf == 1 && sq == F;
+    const bool staged = mode_a || mode_b;
+    const int TR = rl_tr(F), LD = TR * F + 1;
+    const int units = (R + TR - 1) / TR, qchunks = (Q + RL_TQ - 1) / RL_TQ;
+    for (int64_t w = blockIdx.x; w < (int64_t)units * qchunks; w += gridDim.x) {
+        const int r0 = (int)(w / qchunks) * TR, q0 = (int)(w % qchunks) * RL_TQ;
+        const int nr = min(TR, R - r0), nq = min(RL_TQ, Q - q0);
+        for (int row = grp; row < F * TR; row += 8) {
+            const int f = row / TR, ri = row - f * TR;
+            if (ri >= nr || lane >= nq) continue;
+            const float v = Wt[((int64_t)f * R + r0 + ri) * ldw + q0 + lane];
+            if (staged) tile[lane * LD + ri * F + f] = v;
+            else {
+                float *d = W + base + (int64_t)(r0 + ri) * sr + (int64_t)(q0 + lane) * sq + (int64_t)f * sf;
+                *d = accumulate ? *d + v : v;
+            }
+        }
+        if (!staged) continue;
+        __syncthreads();
+        if (mode_a) {
+            const int run = nr * F;
+            for (int i = t; i < nq * run; i += 256) {
+                const int qi = i / run, x = i - qi * run;
+                float *d = W + base + (int64_t)r0 * F + x + (int64_t)(q0 + qi) * sq;
+                *d = accumulate ? *d + tile[qi * LD + x] : tile[qi * LD + x];
+            }
+        } else {
+            const int run = nq * F;
+            for (int i = t; i < nr * run; i += 256) {
+                const int ri = i / run, x = i - ri * run, qi = x / F, f = x - qi * F;
+                float *d = W + base + (int64_t)(r0 + ri) * sr + (int64_t)q0 * F + x;
+                *d = accumulate ? *d + tile[qi * LD + ri * F + f] : tile[qi * LD + ri * F + f];
+            }
+        }
+        __syncthreads();
     }
 }
 }  // namespace
@@ -1122,7 +1222,8 @@ extern "C" int hpl_weight_relayout(const float *W, int64_t base, int R, int Q, i
 extern "C" int hpl_weight_relayout_batch(const hpl_relayout_job *jobs, int njobs, const int64_t *prefix,
                                          int64_t total, float *dst, hplStream stream) {
     HPL_REQUIRE(jobs && prefix && dst && njobs > 0 && total > 0, "hpl_weight_relayout_batch: bad arguments");
-    const int grid = (int)imin(cdiv(total, 256), 16384);
+    HPL_REQUIRE(njobs <= RL_JOBS, "hpl_weight_relayout_batch: at most 1024 jobs per call");
+    const int grid = (int)imin(cdiv(total, 2048), 8192);       // (a unit is <= 64 r x 3 taps or 16 r x 15 taps, x 32 columns)
     k_weight_relayout_batch<<<grid, 256, 0, to_stream(stream)>>>(jobs, njobs, prefix, dst);
     HPL_CHECK_LAUNCH("hpl_weight_relayout_batch");
     return HPL_OK;
@@ -1132,7 +1233,13 @@ extern "C" int hpl_weight_unlayout(const float *Wt, int64_t ldw, int R, int Q, i
                                    int64_t base, int64_t sr, int64_t sq, int64_t sf, int accumulate,
                                    hplStream stream) {
     HPL_REQUIRE(W && Wt && R > 0 && Q > 0 && F > 0 && ldw >= Q, "hpl_weight_unlayout: bad arguments");
-    const int grid = (int)imin(cdiv((int64_t)F * R * Q, 256), 8192);
+    if ((int64_t)F * R * Q < (int64_t)(1 << 19)) {
+        const int g1 = (int)imin(cdiv((int64_t)F * R * Q, 256), 8192);
+        k_weight_unlayout_small<<<g1, 256, 0, to_stream(stream)>>>(Wt, ldw, R, Q, F, W, base, sr, sq, sf, accumulate);
+        HPL_CHECK_LAUNCH("hpl_weight_unlayout");
+        return HPL_OK;
+    }
+    const int grid = (int)imin(cdiv(R, rl_tr(F)) * cdiv(Q, RL_TQ), 8192);
     k_weight_unlayout<<<grid, 256, 0, to_stream(stream)>>>(Wt, ldw, R, Q, F, W, base, sr, sq, sf, accumulate);
     HPL_CHECK_LAUNCH("hpl_weight_unlayout");
     return HPL_OK;

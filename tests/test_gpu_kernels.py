@@ -214,6 +214,48 @@ def test_weight_relayout_roundtrip(ops):
     assert np.array_equal(back.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('O,Ctot,F,c0,C', [(24, 40, 15, 8, 20), (130, 68, 15, 0, 68), (64, 3, 1, 0, 3), (513, 260, 1, 4, 250),
+                                           (33, 70, 15, 1, 69), (100, 100, 7, 0, 100), (5, 9, 27, 2, 6)])
+def test_weight_bank_and_unlayout_every_layout(ops, O, Ctot, F, c0, C):
+    """The LDS-staged batch re-layout (forward image, mirrored data-gradient image, any strides) against the per-element
+    kernel of hpl_weight_relayout, and the staged un-layout (plain + accumulate) against numpy -- bit for bit."""
+    from hplflownet_amd import _lib
+    rng = np.random.RandomState(O * 31 + C)
+    W = dev(rng.randn(O, Ctot, F).astype(np.float32))
+    W2 = dev(rng.randn(O + 3, Ctot, F).astype(np.float32))
+    bank = ops.WeightBank()
+    reqs = [(W, C, O, F, F, Ctot * F, 1, c0 * F, False), (W, O, C, F, Ctot * F, F, 1, c0 * F, True),
+            (W2, C, O + 3, F, F, Ctot * F, 1, c0 * F, False), (W2, O + 3, C, F, Ctot * F, F, 1, c0 * F, False),
+            (W, C, O, F, F, Ctot * F, 1, c0 * F, True)]
+    if F > 1:
+        reqs.append((W, O, F, C, Ctot * F, 1, F, c0 * F, False))          # neither layout: the generic path
+    for w, R, Q, Fk, sr, sq, sf, base, mirror in reqs:
+        bank.get(w, R, Q, Fk, sr, sq, sf, base, mirror)
+    bank.refresh()
+    for w, R, Q, Fk, sr, sq, sf, base, mirror in reqs:
+        img = bank.get(w, R, Q, Fk, sr, sq, sf, base, mirror)
+        assert getattr(img, '_hpl_bank_job', None) is not None          # served from the bank
+        fmap = dev(((Fk - np.arange(Fk)) % Fk).astype(np.int32)) if mirror else None
+        want = ops.weight_relayout(w, R, Q, Fk, sr, sq, sf, base=base, fmap=fmap)
+        assert torch.equal(img, want), (R, Q, Fk, sr, sq, sf, mirror)
+    Wt = ops.weight_relayout(W, C, O, F, F, Ctot * F, 1, base=c0 * F)
+    back = torch.full((O, Ctot, F), 2.0, device=DEV)
+    for acc in (0, 1):
+        _lib.check(_lib.load().hpl_weight_unlayout(Wt.data_ptr(), Wt.shape[1], C, O, F, back.data_ptr(), c0 * F, F,
+                                                   Ctot * F, 1, acc, _lib.stream()), 'unlayout')
+        want = np.full((O, Ctot, F), 2.0, np.float32)
+        want[:, c0:c0 + C] = W.cpu().numpy()[:, c0:c0 + C] * (1 + acc)
+        assert np.array_equal(back.cpu().numpy(), want)
+    # the data-gradient layout as destination (q contiguous in W)
+    WtT = ops.weight_relayout(W, O, C, F, Ctot * F, F, 1, base=c0 * F)
+    back = torch.zeros(O, Ctot, F, device=DEV)
+    _lib.check(_lib.load().hpl_weight_unlayout(WtT.data_ptr(), WtT.shape[1], O, C, F, back.data_ptr(), c0 * F, Ctot * F, F, 1, 0,
+                                               _lib.stream()), 'unlayout')
+    want = np.zeros((O, Ctot, F), np.float32)
+    want[:, c0:c0 + C] = W.cpu().numpy()[:, c0:c0 + C]
+    assert np.array_equal(back.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize('M,rows,C,F,O', [(3000, 3000, 68, 15, 64), (5000, 5000, 32, 1, 200), (900, 900, 3, 1, 32),
                                           (40000, 40000, 36, 15, 32)])
 def test_wgrad_colsum_leaky(ops, M, rows, C, F, O):
