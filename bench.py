@@ -418,6 +418,53 @@ def host_report(host, steps, threaded=False):
     return d
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks of this same command line, one per visible
+    GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torchrun would set them, rendezvous on 127.0.0.1 at a free port), pass
+    rank 0's stdout through (the ONE JSON line) and return the first non-zero exit code.  Fewer than N visible GPUs is an
+    error, not a smaller job -- except under HPL_BENCH_SHARE_GPU=1, the functional test of this path on a 1-GPU box (all
+    ranks on device 0, gloo instead of RCCL, which refuses two ranks on one device)."""
+    import socket
+    share = os.environ.get('HPL_BENCH_SHARE_GPU') == '1'
+    visible = torch.cuda.device_count()
+    if visible < n and not share:
+        print('bench.py --gpus %d: only %d GPU(s) visible; refusing to run a smaller job under that name' % (n, visible), file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    if share:
+        base['HPL_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK='0' if share else str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        import time as _t
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:              # a dead rank leaves the others in a collective: end the job
+                        q.terminate()
+            _t.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                        # (exactly the processes started above)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -454,6 +501,9 @@ def main():
                     help='time a training step (fwd + bwd + gradient all-reduce + Adam) instead of inference')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # a bare `python bench.py --gpus N` (no torchrun environment): this process becomes the launcher of N ranks
+        raise SystemExit(spawn_ranks(a.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -469,8 +519,8 @@ def main():
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
     pin = parallel.pin_host_threads(local_rank, local_world) if world > 1 else {'pinned': False}
     parallel.init_distributed(backend='nccl', device=dev)      # RCCL; inference uses it for barrier/max only
-    if a.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
+    if a.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: the line would report the wrong job size' % (a.gpus, world))
 
     import hplflownet_amd as H
     from hplflownet_amd import ops
@@ -953,6 +1003,9 @@ def main():
                              'max_abs_flow_diff': float(np.abs(flow_gpu - flow_cpu).max()),
                              'note': 'random-init weights: parity number, not accuracy'}
             line['speedup_vs_cpu_baseline'] = line['value'] / base['value']
+        if line['ranks']['ranks_seen'] != line['n_gpus'] or line['n_gpus'] != a.gpus:
+            raise SystemExit('bench.py: %d of %d ranks reported (--gpus %d): not printing a line for a job of another size'
+                             % (line['ranks']['ranks_seen'], line['n_gpus'], a.gpus))
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -80,3 +80,27 @@ def test_eight_ranks_dry_run_on_one_gpu():
     out0, _ = _run_two_ranks(['--train', '--steps', '3', '--warmup', '1', '--points', '1024'], timeout=600, world=8)
     d = json.loads([ln for ln in out0.strip().splitlines() if ln.startswith('{')][0])
     assert d['n_gpus'] == 8 and d['value'] > 0 and 'train' in d['config']['workload'].lower()
+
+
+@pytest.mark.gpu
+def test_self_spawned_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with NO torchrun environment: bench.py launches its two ranks itself (free rendezvous port,
+    rank 0's stdout passed through).  HPL_BENCH_SHARE_GPU=1 puts both on cuda:0 over gloo (RCCL refuses that); without it the
+    launcher refuses a box with fewer GPUs than ranks (tests/test_parallel_cpu.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['HPL_BENCH_SHARE_GPU'] = '1'
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--points', '1024',
+                        '--no-cpu-baseline', '--no-train-probe'], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks']['ranks_seen'] == 2 and d['ranks']['backend'] == 'gloo' and d['value'] > 0
+    env.pop('HPL_BENCH_SHARE_GPU')
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return                                                   # (a multi-GPU box can place the job: nothing to refuse)
+    q = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert q.returncode == 2 and 'visible' in q.stderr           # one GPU on this box: a 2-GPU job is refused, not shrunk

@@ -125,3 +125,50 @@ def test_cpulist_and_single_rank_helpers():
             assert set(now) <= set(before) and len(now) >= min(2, len(before))
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_bucket_order_of_the_full_model_is_rank_independent():
+    """The failure mode that only shows over RCCL: ranks issuing their bucket all-reduces in different orders.  For the
+    FULL model (150 state entries, 19.3 M parameters): the bucket partition is a pure function of the parameter list
+    (two independently built models agree name by name, whatever the values), every parameter is in exactly one bucket,
+    buckets follow the reverse registration order, and -- whatever order the gradient hooks fire in on a rank -- bucket
+    b's collective is never launched before bucket b-1's."""
+    import random
+    import types
+    sys.path.insert(0, ROOT)
+    from hplflownet_amd import parallel as P
+    from hplflownet_amd.flownet import HPLFlowNet
+    from hplflownet_amd.synthetic import SCALES_FILTER_MAP
+    args = types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP, evaluate=False, use_leaky=True, bcn_use_bias=True,
+                                 bcn_use_norm=True, last_relu=False, DEVICE='cpu')
+    layouts = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        model = HPLFlowNet(args)
+        names = {id(p): n for n, p in model.named_parameters()}
+        red = P.GradAllReducer(model.parameters())
+        layouts.append([[(names[id(p)], tuple(p.shape)) for p in b] for b in red.buckets])
+    assert layouts[0] == layouts[1]
+    flat = [n for b in layouts[0] for n, _ in b]
+    assert len(flat) == len(set(flat)) == len(list(model.named_parameters()))
+    assert flat == [n for n, _ in reversed(list(model.named_parameters()))]
+    assert len(layouts[0]) >= 3 and all(sum(torch.Size(s).numel() for _, s in b) * 4 <= (32 << 20) or len(b) == 1 for b in layouts[0])
+    # hooks in a scrambled order (another rank's autograd may finish its leaves differently): launches stay in index order
+    launched = []
+    red._active = lambda: True
+    red._launch = lambda b: (launched.append(b), setattr(red, '_next', b + 1))
+    order = list(red.params)
+    random.Random(5).shuffle(order)
+    for p in order:
+        red._on_grad(p)
+    assert launched == list(range(len(red.buckets)))
+
+
+def test_bench_refuses_a_job_it_cannot_place():
+    """`python bench.py --gpus N` without a torchrun environment spawns its own ranks -- and with fewer than N visible GPUs
+    (none here) it must fail loudly instead of reporting a one-rank job as N GPUs."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'HPL_BENCH_SHARE_GPU')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 2 and 'visible' in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
