@@ -62,7 +62,8 @@ class Op(ctypes.Structure):
                 ('res_mod_sym', c_i32), ('level', c_i32), ('table', c_i32), ('order', c_i32), ('F', c_i32), ('C', c_i32),
                 ('N', c_i32), ('weight', c_i32), ('bias', c_i32), ('act', c_i32), ('slope', c_f32), ('use_norm', c_i32),
                 ('reg_stride_sym', c_i32), ('ext', c_i32), ('cond', c_i32), ('cond_level', c_i32), ('out2', Ref),
-                ('rows2_sym', c_i32), ('post_weight', c_i32), ('post_bias', c_i32), ('post_N', c_i32), ('post_act', c_i32), ('post_mid', Ref)]
+                ('rows2_sym', c_i32), ('post_weight', c_i32), ('post_bias', c_i32), ('post_N', c_i32), ('post_act', c_i32), ('post_mid', Ref),
+                ('b', Ref), ('flags', c_i32), ('aux', c_i32)]
 
 
 class LevelTables(ctypes.Structure):
@@ -74,7 +75,8 @@ class LevelTables(ctypes.Structure):
                 ('corr1_perm', c_vp), ('corr2', c_vp), ('tile_bm', c_i32), ('group_tile_bm', c_i32),
                 ('blur_perm_tidx', c_vp), ('blur_perm_tmask', c_vp), ('up_perm_tidx', c_vp), ('up_perm_tmask', c_vp),
                 ('up_group_tidx', c_vp * 4), ('up_group_tmask', c_vp * 4), ('corr1_perm_tidx', c_vp),
-                ('corr1_perm_tmask', c_vp)]
+                ('corr1_perm_tmask', c_vp), ('bary1', c_vp), ('off1', c_vp), ('up_tap_m', c_vp), ('up_tap_row', c_vp),
+                ('up_tap_ptr', c_vp), ('up_tap_max', c_i64)]
 
 
 class LatticeSpec(ctypes.Structure):
@@ -99,6 +101,12 @@ _SIGNATURES = {
                                           c_vp, c_vp]),
     'hpl_splat': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'hpl_slice': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'hpl_splat_add': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'hpl_slice_add': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'hpl_weight_unlayout_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp, c_vp]),
+    'hpl_psum': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, ctypes.c_int, c_vp, c_i64, ctypes.c_int, c_vp]),
+    'hpl_regroup': (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, ctypes.c_int, c_vp, c_i64, ctypes.c_int, c_vp]),
+    'hpl_epe3d': (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'hpl_weight_relayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i64, c_i64,
                                            c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
     'hpl_weight_relayout_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp, c_vp]),
@@ -146,6 +154,9 @@ _SIGNATURES = {
     'hpl_plan_destroy': (None, [c_vp]),
     'hpl_plan_workspace_bytes': (c_i64, [c_vp, ctypes.POINTER(LevelTables), ctypes.c_int]),
     'hpl_plan_run': (ctypes.c_int, [c_vp, ctypes.POINTER(LevelTables), ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'hpl_plan_run_range': (ctypes.c_int, [c_vp, ctypes.POINTER(LevelTables), ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                          c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'hpl_plan_set_unlayout': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64), ctypes.c_int]),
     'hpl_plan_profile': (ctypes.c_int, [c_vp, ctypes.c_int]),
     'hpl_plan_clock_probe': (ctypes.c_int, [c_vp, c_vp]),
     'hpl_plan_profile_read': (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(c_f32)]),

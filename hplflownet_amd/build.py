@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhplbcl.so')
-SOURCES = ['index_ops.hip', 'row_order.hip', 'splat_slice.hip', 'gconv.hip', 'gconv3.hip', 'wgrad3.hip', 'lattice.hip', 'lattice_fused.hip', 'executor.hip', 'lattice_builder.hip']
+SOURCES = ['index_ops.hip', 'row_order.hip', 'splat_slice.hip', 'train_ops.hip', 'gconv.hip', 'gconv3.hip', 'wgrad3.hip', 'lattice.hip', 'lattice_fused.hip', 'executor.hip', 'lattice_builder.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
          '-ffp-contract=off',   # every fused multiply-add in the kernels is an explicit fmaf
          '-Wall', '-Wno-unused-function']

@@ -14,6 +14,11 @@ void set_error(const char *fmt, ...);
 // out[n] += sum_m X[m*ld + n] (index_ops.hip); `out` is NOT zeroed
 void colsum_accumulate(const float *X, int64_t ld, int64_t M, int N, float *out, hipStream_t s);
 
+// strided helpers of the training executor (train_ops.hip)
+int zero_cols(float *dst, int64_t ldd, int64_t rows, int cols, hipStream_t s);
+int add_cols(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t rows, int cols, hipStream_t s);
+int vcopy(const float *src, float *dst, int n, hipStream_t s);
+
 inline hipStream_t to_stream(hplStream s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

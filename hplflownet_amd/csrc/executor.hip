@@ -88,6 +88,14 @@ struct hpl_plan {
     size_t pool_used = 0;
     std::vector<float *> base;              // per run: buffer base pointers
     std::vector<int64_t> rows;              // per run: buffer row counts
+    // training: un-layout buckets of the weight-gradient images (hpl_plan_set_unlayout), fence events of the side stream
+    const hpl_relayout_job *ul_jobs = nullptr;
+    const int64_t *ul_prefix = nullptr;
+    const float *ul_src = nullptr;
+    std::vector<int32_t> ul_first;
+    std::vector<int64_t> ul_offset;
+    std::vector<hipEvent_t> fence;
+    size_t fence_used = 0;
 };
 
 namespace {
@@ -129,6 +137,38 @@ struct Runner {
     float *splitk;
     hipStream_t s;
     hplStream hs;
+    const float *sf = nullptr;              // training: target flow (3, n0) and the loss scalar of HPL_OP_EPE3D
+    float *loss = nullptr;
+    hipStream_t main_s = nullptr, side_s = nullptr;
+    bool side_busy = false;                 // side-stream work the main stream has not waited for yet
+
+    hipEvent_t fence_event() {
+        if (pl.fence_used == pl.fence.size()) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            pl.fence.push_back(e);
+        }
+        return pl.fence[pl.fence_used++];
+    }
+    // the side stream starts behind everything enqueued on the main stream so far
+    int to_side() {
+        hipEvent_t e = fence_event();
+        HPL_REQUIRE(e, "hpl_plan_run_range: hipEventCreate failed");
+        if (hipEventRecord(e, main_s) != hipSuccess || hipStreamWaitEvent(side_s, e, 0) != hipSuccess) { set_error("hpl_plan_run_range: fence"); return HPL_EHIP; }
+        s = side_s; hs = reinterpret_cast<hplStream>(side_s);
+        side_busy = true;
+        return HPL_OK;
+    }
+    void to_main() { s = main_s; hs = reinterpret_cast<hplStream>(main_s); }
+    // the main stream waits for the side stream's work
+    int join() {
+        if (!side_busy) return HPL_OK;
+        hipEvent_t e = fence_event();
+        HPL_REQUIRE(e, "hpl_plan_run_range: hipEventCreate failed");
+        if (hipEventRecord(e, side_s) != hipSuccess || hipStreamWaitEvent(main_s, e, 0) != hipSuccess) { set_error("hpl_plan_run_range: join"); return HPL_EHIP; }
+        side_busy = false;
+        return HPL_OK;
+    }
 
     int view(const hpl_ref &r, View &v, const char *what) const {
         if (r.buf == HPL_BUF_OUT) {
@@ -226,8 +266,12 @@ struct Runner {
         }
         HPL_REQUIRE(!paired || (op.post_weight < (int)pl.weights.size() && op.post_bias < (int)pl.biases.size() && op.post_N > 0),
                     "hpl_plan_run: fused trailing conv refers to weight %d / bias %d", op.post_weight, op.post_bias);
-        HPL_REQUIRE(A.cols >= op.C && Y.cols >= (paired ? op.post_N : op.N) && Y.rows >= M, "hpl_plan_run: gconv shapes (C=%d of %d, N=%d of %d)",
+        const bool accum = (op.flags & HPL_FLAG_ACCUM) != 0, scatter = (op.flags & HPL_FLAG_SCATTER) != 0;
+        HPL_REQUIRE(!(accum && has_res) && !(scatter && (paired || has_out2 || ngroups >= 2 || !t.corr2 || op.aux <= 0 || op.N % op.aux)),
+                    "hpl_plan_run: accumulate / scatter flags on an op they do not fit");
+        HPL_REQUIRE(A.cols >= op.C && (scatter || (Y.cols >= (paired ? op.post_N : op.N) && Y.rows >= M)), "hpl_plan_run: gconv shapes (C=%d of %d, N=%d of %d)",
                     op.C, A.cols, op.N, Y.cols);
+        HPL_REQUIRE(!scatter || (Y.cols >= op.aux && Y.rows >= t.H1), "hpl_plan_run: scatter target too small");
         const bool prof = pl.profile_tag >= 0 && op.tag == pl.profile_tag;
         auto pass = [&](int f0, int F, const int32_t *row_perm, bool first, bool last, const int32_t *ti,
                         const int32_t *tm) -> int {
@@ -249,6 +293,7 @@ struct Runner {
             d.bias = (first && op.bias >= 0) ? pl.biases[op.bias] : nullptr;
             if (first) {
                 if (has_res) { d.res = R.p; d.ldres = R.ld; d.res_mod = op.res_mod_sym >= 0 ? sym[op.res_mod_sym] : R.rows; }
+                else if (accum && !scatter) { d.res = Y.p; d.ldres = Y.ld; d.res_mod = M; }
             } else {
                 d.res = Y.p; d.ldres = Y.ld; d.res_mod = M;
             }
@@ -269,6 +314,8 @@ struct Runner {
                 d.wt3_plane_stride = w.wt3_plane_stride;
             }
             if (prof) d.clock_probe = pl.clock_probe;
+            if (scatter) { d.scat = t.corr2; d.scat_stride = 15 * t.H0; d.scat_c = op.aux; }
+            else
             if (M * op.N <= SPLITK_ELEMS) { d.ws = splitk; d.ws_bytes = SPLITK_WS_BYTES; }
             bracket(prof, false);
             const int r = hpl_gconv_forward(&d, hs);
@@ -324,7 +371,8 @@ struct Runner {
                             A.cols >= op.C && A.rows >= (op.table == HPL_TBL_CSR_PAIR ? t.n0 + t.n1 : t.n0),
                         "hpl_plan_run: splat shapes at level %d", op.level);
             bracket(prof, false);
-            rc = hpl_splat(A.p, A.ld, op.C, t.csr_ptr, t.csr_pt, t.csr_w, op.use_norm ? t.csr_norm : nullptr, H, Y.p, Y.ld, hs);
+            rc = ((op.flags & HPL_FLAG_ACCUM) ? hpl_splat_add : hpl_splat)(A.p, A.ld, op.C, t.csr_ptr, t.csr_pt, t.csr_w,
+                                                                         op.use_norm ? t.csr_norm : nullptr, H, Y.p, Y.ld, hs);
             bracket(prof, true);
             return rc;
         }
@@ -359,6 +407,7 @@ struct Runner {
             }
             HPL_REQUIRE(Y.rows >= rows && Y.cols >= op.C, "hpl_plan_run: copy output too small");
             if (rows == 0) return HPL_OK;
+            if (op.flags & HPL_FLAG_ACCUM) return add_cols(src, lds, Y.p, Y.ld, rows, op.C, s);
             if (op.C % 4 == 0 && lds % 4 == 0 && Y.ld % 4 == 0 && aligned16(src) && aligned16(Y.p)) {
                 const int grid = (int)imin(cdiv(rows * (op.C / 4), 256), 4096);
                 k_copy_cols4<<<grid, 256, 0, s>>>(reinterpret_cast<const float4 *>(src), lds / 4,
@@ -375,6 +424,92 @@ struct Runner {
             const int64_t n = symv(sym, op.m_sym);
             HPL_REQUIRE((op.ext == 0 || op.ext == 1) && Y.rows >= n && Y.cols >= 3, "hpl_plan_run: load");
             return hpl_transpose(pc[op.ext], n, Y.p, Y.ld, 3, n, hs);
+        }
+        case HPL_OP_WGRAD: {
+            View B;
+            if ((rc = view(op.a, A, "wgrad input")) || (rc = view(op.b, B, "wgrad output gradient"))) return rc;
+            HPL_REQUIRE(op.level >= 0 && op.level < n_levels, "hpl_plan_run: wgrad at level %d", op.level);
+            HPL_REQUIRE(op.weight >= 0 && op.weight < (int)pl.weights.size() && op.bias < (int)pl.biases.size(), "hpl_plan_run: wgrad image %d", op.weight);
+            const hpl_level_tables &t = lv[op.level];
+            const int64_t M = symv(sym, op.m_sym);
+            const int32_t *nbr = nullptr;
+            int64_t stride = 0, reg = 0;
+            switch (op.table) {
+            case HPL_TBL_NONE: break;
+            case HPL_TBL_BLUR_PAIR: case HPL_TBL_BLUR0: nbr = t.blur; stride = t.blur_stride; break;
+            case HPL_TBL_CORR1: nbr = t.corr1; stride = t.corr1_stride; break;
+            case HPL_TBL_CORR2: nbr = t.corr2; stride = 15 * t.H0; break;
+            case HPL_TBL_REGULAR: reg = symv(sym, op.reg_stride_sym); break;
+            default: HPL_REQUIRE(false, "hpl_plan_run: wgrad with table kind %d", op.table);
+            }
+            HPL_REQUIRE(op.table == HPL_TBL_NONE || op.table == HPL_TBL_REGULAR || nbr, "hpl_plan_run: level %d lacks table %d", op.level, op.table);
+            HPL_REQUIRE(A.cols >= op.C && B.cols >= op.N && B.rows >= M, "hpl_plan_run: wgrad shapes");
+            const hpl_weight &g = pl.weights[op.weight];
+            const bool taps = (op.flags & HPL_FLAG_TAPS) && op.table == HPL_TBL_BLUR0 && t.up_tap_m && t.up_tap_row && t.up_tap_ptr;
+            return hpl_gconv_wgrad(A.p, A.ld, A.rows, nbr, stride, reg, M, op.C, op.F, B.p, B.ld, op.N, const_cast<float *>(g.Wt), g.ldw,
+                                   taps ? t.up_tap_m : nullptr, taps ? t.up_tap_row : nullptr, taps ? t.up_tap_ptr : nullptr,
+                                   taps ? t.up_tap_max : 0, op.bias >= 0 ? const_cast<float *>(pl.biases[op.bias]) : nullptr, hs);
+        }
+        case HPL_OP_LEAKY_BWD: {
+            View B;
+            if ((rc = view(op.a, A, "leaky_bwd dY")) || (rc = view(op.b, B, "leaky_bwd Y")) || (rc = view(op.out, Y, "leaky_bwd dX"))) return rc;
+            const int64_t M = symv(sym, op.m_sym);
+            HPL_REQUIRE(A.rows >= M && B.rows >= M && Y.rows >= M && A.cols >= op.N && B.cols >= op.N && Y.cols >= op.N, "hpl_plan_run: leaky_bwd shapes");
+            return hpl_leaky_bwd(A.p, A.ld, B.p, B.ld, op.slope, Y.p, Y.ld, M, op.N, hs);
+        }
+        case HPL_OP_COLSUM: {
+            if ((rc = view(op.a, A, "colsum input"))) return rc;
+            const int64_t M = symv(sym, op.m_sym);
+            HPL_REQUIRE(op.bias >= 0 && op.bias < (int)pl.biases.size() && A.rows >= M && A.cols >= op.C, "hpl_plan_run: colsum");
+            return hpl_colsum(A.p, A.ld, M, op.C, const_cast<float *>(pl.biases[op.bias]), hs);
+        }
+        case HPL_OP_SPLAT_BWD: {
+            if ((rc = view(op.a, A, "splat_bwd input")) || (rc = view(op.out, Y, "splat_bwd output"))) return rc;
+            HPL_REQUIRE(op.level >= 0 && op.level < n_levels && (op.table == HPL_TBL_CSR_PAIR || op.table == HPL_TBL_CSR_C0),
+                        "hpl_plan_run: splat_bwd at level %d table %d", op.level, op.table);
+            const hpl_level_tables &t = lv[op.level];
+            const bool pair = op.table == HPL_TBL_CSR_PAIR;
+            HPL_REQUIRE(A.cols >= op.C && Y.cols >= op.C && A.rows >= (pair ? t.H0 + t.H1 : t.H0) && Y.rows >= (pair ? t.n0 + t.n1 : t.n0),
+                        "hpl_plan_run: splat_bwd shapes at level %d", op.level);
+            HPL_REQUIRE(!pair || (t.bary1 && t.off1), "hpl_plan_run: the lattice of a training step must carry cloud 2's barycentric tables");
+            auto fn = (op.flags & HPL_FLAG_ACCUM) ? hpl_slice_add : hpl_slice;
+            rc = fn(A.p, A.ld, op.C, t.bary0, t.off0, t.n0, op.use_norm ? t.csr_norm : nullptr, nullptr, Y.p, Y.ld, hs);
+            if (rc || !pair) return rc;
+            return fn(A.p + t.H0 * A.ld, A.ld, op.C, t.bary1, t.off1, t.n1, op.use_norm ? t.csr_norm + t.H0 : nullptr, nullptr,
+                      Y.p + t.n0 * Y.ld, Y.ld, hs);
+        }
+        case HPL_OP_PSUM: {
+            if ((rc = view(op.a, A, "psum input")) || (rc = view(op.out, Y, "psum output"))) return rc;
+            const int64_t mod = symv(sym, op.m_sym);
+            HPL_REQUIRE(mod > 0 && op.F > 0 && A.rows >= mod * op.F && Y.rows >= mod && A.cols >= op.N && Y.cols >= op.N, "hpl_plan_run: psum shapes");
+            return hpl_psum(A.p, A.ld, mod * op.F, mod, op.N, Y.p, Y.ld, (op.flags & HPL_FLAG_ACCUM) ? 1 : 0, hs);
+        }
+        case HPL_OP_REGROUP: {
+            if ((rc = view(op.a, A, "regroup input")) || (rc = view(op.out, Y, "regroup output"))) return rc;
+            const int64_t M = symv(sym, op.m_sym);
+            HPL_REQUIRE(A.rows >= M && A.cols >= op.F * op.C && Y.rows >= M * op.F && Y.cols >= op.C, "hpl_plan_run: regroup shapes");
+            return hpl_regroup(A.p, A.ld, M, op.F, op.C, Y.p, Y.ld, (op.flags & HPL_FLAG_ACCUM) ? 1 : 0, hs);
+        }
+        case HPL_OP_ZERO: {
+            if ((rc = view(op.out, Y, "zero output"))) return rc;
+            return zero_cols(Y.p, Y.ld, op.m_sym >= 0 ? symv(sym, op.m_sym) : Y.rows, Y.cols, s);
+        }
+        case HPL_OP_EPE3D: {
+            if ((rc = view(op.out, Y, "epe3d gradient"))) return rc;
+            HPL_REQUIRE(sf && loss, "hpl_plan_run_range: the program holds a loss op but no target flow / loss pointer was given");
+            HPL_REQUIRE(Y.ld == 3 && Y.rows >= sym[HPL_SYM_N0], "hpl_plan_run: the loss gradient is a dense [N0][3] matrix");
+            return hpl_epe3d(out, sf, sym[HPL_SYM_N0], Y.p, loss, hs);
+        }
+        case HPL_OP_VCOPY:
+            HPL_REQUIRE(op.weight >= 0 && op.weight < (int)pl.biases.size() && op.bias >= 0 && op.bias < (int)pl.biases.size() && op.N > 0,
+                        "hpl_plan_run: vcopy");
+            return vcopy(pl.biases[op.weight], const_cast<float *>(pl.biases[op.bias]), op.N, s);
+        case HPL_OP_UNLAYOUT: {
+            HPL_REQUIRE(pl.ul_jobs && op.aux >= 0 && op.aux + 1 < (int)pl.ul_first.size(), "hpl_plan_run: un-layout bucket %d (hpl_plan_set_unlayout)", op.aux);
+            const int first = pl.ul_first[op.aux], n = pl.ul_first[op.aux + 1] - first;
+            if (n <= 0) return HPL_OK;
+            return hpl_weight_unlayout_batch(pl.ul_jobs + first, n, pl.ul_prefix + first, pl.ul_offset[op.aux + 1] - pl.ul_offset[op.aux],
+                                             pl.ul_src + pl.ul_offset[op.aux], hs);
         }
         default: HPL_REQUIRE(false, "hpl_plan_run: unknown op kind %d", op.kind);
         }
@@ -423,6 +558,7 @@ extern "C" hpl_plan *hpl_plan_create(const hpl_op *ops, int n_ops, const hpl_buf
 extern "C" void hpl_plan_destroy(hpl_plan *plan) {
     if (!plan) return;
     for (hipEvent_t e : plan->pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : plan->fence) (void)hipEventDestroy(e);
     delete plan;
 }
 
@@ -436,7 +572,26 @@ extern "C" int64_t hpl_plan_workspace_bytes(const hpl_plan *plan, const hpl_leve
 
 extern "C" int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels, int n_levels, const float *pc1,
                             const float *pc2, float *out, void *workspace, int64_t workspace_bytes, hplStream stream) {
+    HPL_REQUIRE(plan, "hpl_plan_run: null argument");
+    return hpl_plan_run_range(plan, levels, n_levels, pc1, pc2, nullptr, out, nullptr, workspace, workspace_bytes, stream, nullptr, 0,
+                              (int)plan->ops.size(), 1);
+}
+
+extern "C" int hpl_plan_set_unlayout(hpl_plan *plan, const hpl_relayout_job *jobs, const int64_t *prefix, const float *src,
+                                     const int32_t *bucket_first, const int64_t *bucket_offset, int n_buckets) {
+    HPL_REQUIRE(plan && jobs && prefix && src && bucket_first && bucket_offset && n_buckets > 0, "hpl_plan_set_unlayout: bad arguments");
+    plan->ul_jobs = jobs; plan->ul_prefix = prefix; plan->ul_src = src;
+    plan->ul_first.assign(bucket_first, bucket_first + n_buckets + 1);
+    plan->ul_offset.assign(bucket_offset, bucket_offset + n_buckets + 1);
+    return HPL_OK;
+}
+
+extern "C" int hpl_plan_run_range(hpl_plan *plan, const hpl_level_tables *levels, int n_levels, const float *pc1, const float *pc2,
+                                  const float *sf, float *out, float *loss, void *workspace, int64_t workspace_bytes, hplStream stream,
+                                  hplStream side_stream, int op_begin, int op_end, int join) {
     HPL_REQUIRE(plan && pc1 && pc2 && out && workspace, "hpl_plan_run: null argument");
+    HPL_REQUIRE(op_begin >= 0 && op_begin <= op_end && op_end <= (int)plan->ops.size(), "hpl_plan_run_range: ops [%d, %d) of %d", op_begin,
+                op_end, (int)plan->ops.size());
     int64_t sym[MAX_SYMS];
     int rc = resolve_syms(levels, n_levels, sym);
     if (rc) return rc;
@@ -455,6 +610,10 @@ extern "C" int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels, int 
     HPL_REQUIRE(w <= end, "hpl_plan_run: workspace of %lld bytes is too small (hpl_plan_workspace_bytes: %lld)",
                 (long long)workspace_bytes, (long long)hpl_plan_workspace_bytes(plan, levels, n_levels));
     Runner r{*plan, levels, n_levels, sym, {pc1, pc2}, out, splitk, to_stream(stream), stream};
+    r.sf = sf; r.loss = loss;
+    r.main_s = to_stream(stream);
+    r.side_s = side_stream ? to_stream(side_stream) : nullptr;
+    plan->fence_used = 0;
     auto active = [&](const hpl_op &op, bool &run) -> int {
         run = true;
         if (op.cond != HPL_COND_ALWAYS) {
@@ -469,7 +628,7 @@ extern "C" int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels, int 
     // else writes those columns: plan->hoist_emg)
     static const int batch_emg = getenv("HPL_EMG_BATCH") ? atoi(getenv("HPL_EMG_BATCH")) : 1;
     const bool hoist = batch_emg && plan->hoist_emg;
-    if (hoist) {
+    if (hoist && op_begin == 0) {
         EmgJobs jobs;
         jobs.n = 0;
         int64_t most = 0;
@@ -502,15 +661,22 @@ extern "C" int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels, int 
         flush();
         HPL_CHECK_LAUNCH("hpl_plan_run (emg copies)");
     }
-    for (const hpl_op &op : plan->ops) {
+    for (int i = op_begin; i < op_end; ++i) {
+        const hpl_op &op = plan->ops[i];
         if (hoist && is_emg(op)) continue;
         bool run;
         if ((rc = active(op, run))) return rc;
         if (!run) continue;
+        const bool side = r.side_s && (op.flags & HPL_FLAG_SIDE);
+        if (side) { if ((rc = r.to_side())) return rc; }
+        else if (op.kind == HPL_OP_UNLAYOUT && (rc = r.join())) return rc;       // (it reads what the side-stream wgrads wrote)
         rc = r.run_op(op);
+        if (side) r.to_main();
         if (rc) return rc;
     }
-    return HPL_OK;
+    if (!join) return HPL_OK;
+    r.side_busy = r.side_s != nullptr;         // (earlier ranges of the same step may have left work there)
+    return r.join();
 }
 
 extern "C" int hpl_plan_profile(hpl_plan *plan, int tag) {

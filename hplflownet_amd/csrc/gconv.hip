@@ -1073,6 +1073,13 @@ constexpr int RL_TQ = 32, RL_FMAX = 15, RL_JOBS = 1024;
 constexpr int RL_LDMAX = 16 * RL_FMAX + 1;
 __host__ __device__ __forceinline__ int rl_tr(int F) { return F <= 3 ? 64 : 16; }      // r per unit: runs of >= 64 floats
 
+// units of a job: r-blocks x chunks of 32 columns; "taps as column blocks" images (mirror == 2): blocks of 8 rows x 32 columns
+__device__ __forceinline__ int rl_units(const hpl_relayout_job &jb) {
+    const int qchunks = (int)((jb.ldw + RL_TQ - 1) / RL_TQ);
+    if (jb.mirror == 2) return ((jb.R + 31) / 32 * 32 / 8) * qchunks;
+    return ((jb.R + rl_tr(jb.F) - 1) / rl_tr(jb.F)) * qchunks;
+}
+
 __device__ __forceinline__ int relayout_unit_job(const int *upre, int njobs, int u) {
     int lo = 0, hi = njobs - 1;                          // last job with upre[job] <= u
     while (lo < hi) {
@@ -1088,7 +1095,7 @@ __global__ void __launch_bounds__(256) k_weight_relayout_batch(const hpl_relayou
     __shared__ int upre[RL_JOBS + 1];
     const int t = threadIdx.x;
     for (int j = t; j < njobs; j += 256)             // units of a job: r-blocks x chunks of 32 columns (exact in a float: < 2^24)
-        tile[j] = (float)(((jobs[j].R + rl_tr(jobs[j].F) - 1) / rl_tr(jobs[j].F)) * (int)((jobs[j].ldw + RL_TQ - 1) / RL_TQ));
+        tile[j] = (float)rl_units(jobs[j]);
     __syncthreads();
     for (int j = t; j <= njobs; j += 256) {
         int acc = 0;
@@ -1106,6 +1113,14 @@ __global__ void __launch_bounds__(256) k_weight_relayout_batch(const hpl_relayou
         const int64_t ldw = jb.ldw;
         const int TR = rl_tr(F), LD = TR * F + 1;              // (odd: the store reads one q per lane)
         const int qchunks = (int)((ldw + RL_TQ - 1) / RL_TQ), ul = u - upre[j];
+        if (jb.mirror == 2) {       // element (r, f*Q + q) = W[base + r*sr + q*sq + f*sf]; rows past R / columns past F*Q are zero
+            const int r = (ul / qchunks) * 8 + grp, col = (ul % qchunks) * RL_TQ + lane;
+            if (col < ldw) {
+                const int f = col / Q, q = col - f * Q;
+                out[(int64_t)r * ldw + col] = (r < R && f < F) ? jb.W[jb.base + (int64_t)r * jb.sr + (int64_t)q * jb.sq + (int64_t)f * jb.sf] : 0.f;
+            }
+            continue;
+        }
         const int r0 = (ul / qchunks) * TR, nr = min(TR, R - r0), q0 = (ul % qchunks) * RL_TQ;
         const bool mode_a = F <= RL_FMAX && jb.sf == 1 && jb.sr == F, mode_b = F <= RL_FMAX && jb.sf == 1 && jb.sq == F;
         const bool staged = mode_a || mode_b;
@@ -1206,7 +1221,80 @@ __global__ void __launch_bounds__(256) k_weight_unlayout(const float *__restrict
         __syncthreads();
     }
 }
+
+// The inverse of k_weight_relayout_batch for the weight gradients of a training step: job j's image [k_rows][ldw] at
+// src + prefix[j] -> jb.W[base + r*sr + q*sq + f*sf] (jb.W is the gradient tensor, in the parameter's layout).  Same units,
+// same staging (rows of 32 q are read as full lines, the parameter side is written in runs of 16 * F or 32 * F floats).
+__global__ void __launch_bounds__(256) k_weight_unlayout_batch(const hpl_relayout_job *__restrict__ jobs, int njobs,
+                                                               const int64_t *__restrict__ prefix, const float *__restrict__ src) {
+    __shared__ float tile[RL_TQ * RL_LDMAX];
+    __shared__ int upre[RL_JOBS + 1];
+    const int t = threadIdx.x;
+    for (int j = t; j < njobs; j += 256) tile[j] = (float)rl_units(jobs[j]);
+    __syncthreads();
+    for (int j = t; j <= njobs; j += 256) {
+        int acc = 0;
+        for (int i = 0; i < j; ++i) acc += (int)tile[i];
+        upre[j] = acc;
+    }
+    __syncthreads();
+    const int units = upre[njobs];
+    const int lane = t & 31, grp = t >> 5;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int j = relayout_unit_job(upre, njobs, u);
+        const hpl_relayout_job jb = jobs[j];
+        const float *in = src + (prefix[j] - prefix[0]);
+        float *W = const_cast<float *>(jb.W);
+        const int F = jb.F, R = jb.R, Q = jb.Q;
+        const int64_t ldw = jb.ldw;
+        const int TR = rl_tr(F), LD = TR * F + 1;
+        const int qchunks = (int)((ldw + RL_TQ - 1) / RL_TQ), ul = u - upre[j];
+        if (jb.mirror == 2) {
+            const int r = (ul / qchunks) * 8 + grp, col = (ul % qchunks) * RL_TQ + lane;
+            const int f = col / Q, q = col - f * Q;
+            if (r < R && f < F) W[jb.base + (int64_t)r * jb.sr + (int64_t)q * jb.sq + (int64_t)f * jb.sf] = in[(int64_t)r * ldw + col];
+            continue;
+        }
+        const int r0 = (ul / qchunks) * TR, nr = min(TR, R - r0), q0 = (ul % qchunks) * RL_TQ;
+        const int nq = max(0, min(RL_TQ, Q - q0));
+        const bool mode_a = F <= RL_FMAX && jb.sf == 1 && jb.sr == F, mode_b = F <= RL_FMAX && jb.sf == 1 && jb.sq == F;
+        const bool staged = mode_a || mode_b;
+        for (int row = grp; row < F * TR; row += 8) {
+            const int f = row / TR, ri = row - f * TR;
+            if (ri >= nr || lane >= nq) continue;
+            const float v = in[((int64_t)f * R + r0 + ri) * ldw + q0 + lane];
+            if (staged) tile[lane * LD + ri * F + f] = v;
+            else W[jb.base + (int64_t)(r0 + ri) * jb.sr + (int64_t)(q0 + lane) * jb.sq + (int64_t)f * jb.sf] = v;
+        }
+        if (!staged) continue;
+        __syncthreads();
+        if (mode_a) {
+            const int run = nr * F;
+            for (int i = t; i < nq * run; i += 256) {
+                const int qi = i / run, x = i - qi * run;
+                W[jb.base + (int64_t)r0 * F + x + (int64_t)(q0 + qi) * jb.sq] = tile[qi * LD + x];
+            }
+        } else {
+            const int run = nq * F;
+            for (int i = t; i < nr * run; i += 256) {
+                const int ri = i / run, x = i - ri * run, qi = x / F, f = x - qi * F;
+                W[jb.base + (int64_t)(r0 + ri) * jb.sr + (int64_t)q0 * F + x] = tile[qi * LD + ri * F + f];
+            }
+        }
+        __syncthreads();
+    }
+}
 }  // namespace
+
+extern "C" int hpl_weight_unlayout_batch(const hpl_relayout_job *jobs, int njobs, const int64_t *prefix, int64_t total,
+                                         const float *src, hplStream stream) {
+    HPL_REQUIRE(jobs && prefix && src && njobs > 0 && total > 0, "hpl_weight_unlayout_batch: bad arguments");
+    HPL_REQUIRE(njobs <= RL_JOBS, "hpl_weight_unlayout_batch: at most 1024 jobs per call");
+    const int grid = (int)imin(cdiv(total, 2048), 8192);
+    k_weight_unlayout_batch<<<grid, 256, 0, to_stream(stream)>>>(jobs, njobs, prefix, src);
+    HPL_CHECK_LAUNCH("hpl_weight_unlayout_batch");
+    return HPL_OK;
+}
 
 extern "C" int hpl_weight_relayout(const float *W, int64_t base, int R, int Q, int F, int64_t sr,
                                    int64_t sq, int64_t sf, const int32_t *fmap, float *Wt,

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) k_splat(const float *__restrict__ feat, i
                                                const int32_t *__restrict__ csr_pt,
                                                const float *__restrict__ csr_w,
                                                const float *__restrict__ norm, uint32_t total,
-                                               float *__restrict__ out, int64_t ldo, int xcd) {
+                                               float *__restrict__ out, int64_t ldo, int xcd, int accumulate) {
     using ops = vec_ops<V>;
     constexpr int VW = sizeof(V) / 4;
     const uint32_t stride = gridDim.x * 256u;
@@ -99,7 +99,9 @@ __global__ void __launch_bounds__(256) k_splat(const float *__restrict__ feat, i
             const V x = *reinterpret_cast<const V *>(col + (int64_t)csr_pt[j] * ldf);
             ops::fma(acc, csr_w[j], x);
         }
-        *reinterpret_cast<V *>(out + (int64_t)v * ldo + (int64_t)cq * VW) = ops::scale(acc, sc);
+        V *dst = reinterpret_cast<V *>(out + (int64_t)v * ldo + (int64_t)cq * VW);
+        acc = ops::scale(acc, sc);
+        *dst = accumulate ? ops::add(*dst, acc) : acc;
     }
 }
 
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(256) k_slice(const float *__restrict__ Y, int6
                                                const int32_t *__restrict__ off, int64_t N,
                                                const float *__restrict__ vscale,
                                                const float *__restrict__ bias, uint32_t total,
-                                               float *__restrict__ out, int64_t ldo, int xcd) {
+                                               float *__restrict__ out, int64_t ldo, int xcd, int accumulate) {
     using ops = vec_ops<V>;
     constexpr int VW = sizeof(V) / 4;
     const uint32_t S = gridDim.x * 256u;
@@ -155,16 +157,17 @@ __global__ void __launch_bounds__(256) k_slice(const float *__restrict__ Y, int6
 #pragma unroll
             for (int r = 0; r < 4; ++r) ops::fma(acc, w[u][r], y[u][r]);
             if (bias) acc = ops::add(acc, *reinterpret_cast<const V *>(bias + (int64_t)cq[u] * VW));
-            *reinterpret_cast<V *>(out + (int64_t)n[u] * ldo + (int64_t)cq[u] * VW) = acc;
+            V *dst = reinterpret_cast<V *>(out + (int64_t)n[u] * ldo + (int64_t)cq[u] * VW);
+            *dst = accumulate ? ops::add(*dst, acc) : acc;
         }
     }
 }
 
 }  // namespace
 
-extern "C" int hpl_splat(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr,
-                         const int32_t *csr_pt, const float *csr_w, const float *norm, int64_t H,
-                         float *out, int64_t ldo, hplStream stream) {
+namespace {
+int splat_launch(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr, const int32_t *csr_pt, const float *csr_w,
+                 const float *norm, int64_t H, float *out, int64_t ldo, hplStream stream, int accumulate) {
     HPL_REQUIRE(feat && csr_ptr && csr_pt && csr_w && out, "hpl_splat: null pointer");
     HPL_REQUIRE(C > 0 && H >= 0 && ldf >= C && ldo >= C, "hpl_splat: bad sizes C=%d H=%lld ldf=%lld ldo=%lld", C,
                 (long long)H, (long long)ldf, (long long)ldo);
@@ -176,15 +179,25 @@ extern "C" int hpl_splat(const float *feat, int64_t ldf, int C, const int32_t *c
     const uint32_t total = (uint32_t)(H * cv);
     int chunk;
     const int grid = xcd_grid(imin(cdiv((int64_t)total, 256), 256 * 32), &chunk);
-    if (vec) k_splat<float4><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk);
-    else k_splat<float><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk);
+    if (vec) k_splat<float4><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate);
+    else k_splat<float><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate);
     HPL_CHECK_LAUNCH("hpl_splat");
     return HPL_OK;
 }
+}  // namespace
 
-extern "C" int hpl_slice(const float *Y, int64_t ldy, int C, const float *bary, const int32_t *off,
-                         int64_t N, const float *vscale, const float *bias, float *out, int64_t ldo,
-                         hplStream stream) {
+extern "C" int hpl_splat(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr, const int32_t *csr_pt,
+                         const float *csr_w, const float *norm, int64_t H, float *out, int64_t ldo, hplStream stream) {
+    return splat_launch(feat, ldf, C, csr_ptr, csr_pt, csr_w, norm, H, out, ldo, stream, 0);
+}
+extern "C" int hpl_splat_add(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr, const int32_t *csr_pt,
+                             const float *csr_w, const float *norm, int64_t H, float *out, int64_t ldo, hplStream stream) {
+    return splat_launch(feat, ldf, C, csr_ptr, csr_pt, csr_w, norm, H, out, ldo, stream, 1);
+}
+
+namespace {
+int slice_launch(const float *Y, int64_t ldy, int C, const float *bary, const int32_t *off, int64_t N, const float *vscale,
+                 const float *bias, float *out, int64_t ldo, hplStream stream, int accumulate) {
     HPL_REQUIRE(Y && bary && off && out, "hpl_slice: null pointer");
     HPL_REQUIRE(C > 0 && N >= 0 && ldy >= C && ldo >= C, "hpl_slice: bad sizes C=%d N=%lld ldy=%lld ldo=%lld", C,
                 (long long)N, (long long)ldy, (long long)ldo);
@@ -201,12 +214,22 @@ extern "C" int hpl_slice(const float *Y, int64_t ldy, int C, const float *bary, 
     if (vec) {
         constexpr int U = 2;
         const int grid = xcd_grid(cdiv((int64_t)total, 256 * U), &chunk);
-        k_slice<float4, U><<<grid, 256, 0, s>>>(Y, ldy, (uint32_t)cv, bary, off, N, vscale, bias, total, out, ldo, chunk);
+        k_slice<float4, U><<<grid, 256, 0, s>>>(Y, ldy, (uint32_t)cv, bary, off, N, vscale, bias, total, out, ldo, chunk, accumulate);
     } else {
         constexpr int U = 4;
         const int grid = xcd_grid(cdiv((int64_t)total, 256 * U), &chunk);
-        k_slice<float, U><<<grid, 256, 0, s>>>(Y, ldy, (uint32_t)cv, bary, off, N, vscale, bias, total, out, ldo, chunk);
+        k_slice<float, U><<<grid, 256, 0, s>>>(Y, ldy, (uint32_t)cv, bary, off, N, vscale, bias, total, out, ldo, chunk, accumulate);
     }
     HPL_CHECK_LAUNCH("hpl_slice");
     return HPL_OK;
+}
+}  // namespace
+
+extern "C" int hpl_slice(const float *Y, int64_t ldy, int C, const float *bary, const int32_t *off, int64_t N,
+                         const float *vscale, const float *bias, float *out, int64_t ldo, hplStream stream) {
+    return slice_launch(Y, ldy, C, bary, off, N, vscale, bias, out, ldo, stream, 0);
+}
+extern "C" int hpl_slice_add(const float *Y, int64_t ldy, int C, const float *bary, const int32_t *off, int64_t N,
+                             const float *vscale, const float *bias, float *out, int64_t ldo, hplStream stream) {
+    return slice_launch(Y, ldy, C, bary, off, N, vscale, bias, out, ldo, stream, 1);
 }

@@ -111,7 +111,8 @@ class SyntheticPairs(object):
 
 
 class Trainer(object):
-    def __init__(self, arch='HPLFlowNet', device='cuda', lr=1e-4, seed=0, distributed=False, rank=0, init='hash'):
+    def __init__(self, arch='HPLFlowNet', device='cuda', lr=1e-4, seed=0, distributed=False, rank=0, init='hash',
+                 native_step=None):
         cls, nsc = ARCHS[arch]
         self.rank = rank
         self.arch, self.device = arch, torch.device(device)
@@ -135,6 +136,38 @@ class Trainer(object):
         self.epoch = 0
         self.min_loss = None
         self._side = torch.cuda.Stream(device=self.device, priority=-1) if self.device.type == 'cuda' else None
+        # the training step as one native program (train_plan.TrainPlan: forward + loss + backward enqueued by a handful of C calls,
+        # gradients in one flat arena the all-reduce runs on); HPL_NATIVE_TRAIN=0 / native_step=False keep the autograd path
+        if native_step is None:
+            native_step = os.environ.get('HPL_NATIVE_TRAIN', '1') != '0'
+        self.native_step = bool(native_step) and self.device.type == 'cuda'
+        self.tplan = None
+        self.native_steps = 0
+
+    def train_step(self, pc1, pc2, sf, lat):
+        """One optimiser step on one pair (main.py:203-217) -> the loss (device tensor, not synchronised)."""
+        if self.native_step and self.tplan is None:
+            from .train_plan import TrainPlan
+            if self.reducer is None:
+                self.reducer = parallel.GradAllReducer(self.model.parameters(), overlap=False)
+            self.tplan = TrainPlan(self.model, reducer=self.reducer)
+        if self.tplan is not None:
+            r = self.tplan.step(pc1, pc2, sf, lat)
+            if r is not None:
+                self.tplan.finish()
+                self.opt.step()
+                self.native_steps += 1
+                return r[1][0].clone()
+            self.tplan.gflat.zero_()                 # a lattice the native backward refuses: autograd adds into the same arena
+        flow = self.model(pc1[None], pc2[None], lat)
+        loss = epe3d_loss(flow, sf[None])
+        if self.tplan is None:
+            self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer()
+        self.opt.step()
+        return loss.detach()
 
     # ------------------------------------------------------------------ lattice pipeline
     def _lattices(self, data, order, training, depth=2):
@@ -169,14 +202,7 @@ class Trainer(object):
         order = list(range(len(data))) if order is None else list(order)
         total = torch.zeros((), device=self.device)
         for (pc1, pc2, sf), lat in self._lattices(data, order, True):
-            flow = self.model(pc1[None], pc2[None], lat)
-            loss = epe3d_loss(flow, sf[None])
-            self.opt.zero_grad(set_to_none=True)
-            loss.backward()
-            if self.reducer is not None:
-                self.reducer()
-            self.opt.step()
-            total += loss.detach()
+            total += self.train_step(pc1, pc2, sf, lat)
         self.epoch += 1
         tot = parallel.sum_over_ranks([float(total), float(len(order))], device=self.device)
         return tot[0] / max(1.0, tot[1])             # mean loss over the global batch stream (all ranks)

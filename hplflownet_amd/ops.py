@@ -471,10 +471,21 @@ class WeightBank(object):
             img._hpl_bank_job = job             # split3_of keeps the image's split planes with the job
             return img
         if job is None:
-            self.jobs[key] = [weight, (R, Q, F, sr, sq, sf, base, mirror), None, k_rows * ldw, -1, None]
-            self.dirty = True
+            self.register(weight, R, Q, F, sr, sq, sf, base, mirror)
         fmap = _mirror_map(F, weight.device) if mirror else None
         return weight_relayout(weight, R, Q, F, sr, sq, sf, base=base, fmap=fmap)
+
+    def register(self, weight, R, Q, F, sr, sq, sf, base=0, mirror=0):
+        """Record an image without producing it (the native plans: every image exists after the next refresh()).
+        mirror 0 / 1: Wt[(f*R + r), q] (taps as stored / in the order (F - f) % F); mirror 2: taps as column blocks,
+        Wt[r, f*Q + q] (hpl_relayout_job).  -> the job (offset in job[2] after refresh, image shape (job[6], job[7]))."""
+        key = self._key(weight, R, Q, F, sr, sq, sf, base, mirror)
+        job = self.jobs.get(key)
+        if job is None:
+            k_rows, ldw = (round_up(R, 32), round_up(F * Q, 4)) if mirror == 2 else (round_up(F * R, 32), round_up(Q, 4))
+            job = self.jobs[key] = [weight, (R, Q, F, sr, sq, sf, base, mirror), None, k_rows * ldw, -1, None, k_rows, ldw]
+            self.dirty = True
+        return job
 
     def refresh(self):
         """One launch: every recorded image from the current parameter values."""
@@ -487,7 +498,8 @@ class WeightBank(object):
             for i, job in enumerate(self.jobs.values()):
                 w, (R, Q, F, sr, sq, sf, base, mirror) = job[0], job[1]
                 arr[i].W, arr[i].base, arr[i].sr, arr[i].sq, arr[i].sf = w.data_ptr(), base, sr, sq, sf
-                arr[i].R, arr[i].Q, arr[i].F, arr[i].mirror, arr[i].ldw = R, Q, F, int(mirror), round_up(Q, 4)
+                arr[i].R, arr[i].Q, arr[i].F, arr[i].mirror = R, Q, F, int(mirror)
+                arr[i].ldw = round_up(F * Q, 4) if int(mirror) == 2 else round_up(Q, 4)
                 job[2] = prefix[-1]
                 prefix.append(prefix[-1] + job[3])
             self.total = prefix[-1]

@@ -172,6 +172,32 @@ class GradAllReducer(object):
     def _active(self):
         return dist.is_initialized() and (dist.get_world_size() > 1 or self.single_rank)
 
+    # ---- gradients that already live in ONE flat arena in bucket order (train_plan.TrainPlan: the parameters' .grad are views of
+    # it): a bucket's collective runs on its slice, no packing or write-back copies
+    def adopt_flat(self, gflat, ranges):
+        assert len(ranges) == len(self.buckets)
+        self._flat = [gflat[a:b] for a, b in ranges]
+        self._views = [[p.grad for p in bucket] for bucket in self.buckets]
+        self._flat_launched = []
+
+    def launch_flat(self, b):
+        """Start the all-reduce of bucket b (its gradients are complete on the current stream).  Every rank runs the same
+        program, so every rank calls this in the same order."""
+        if not self._active():
+            return
+        self._work[b] = dist.all_reduce(self._flat[b], op=dist.ReduceOp.SUM, async_op=True)
+        self._flat_launched.append(b)
+
+    def finish_flat(self):
+        if not self._active():
+            return
+        world = dist.get_world_size()
+        for b in self._flat_launched:
+            self._work[b].wait()
+            self._flat[b].div_(world)
+            self._work[b] = None
+        self._flat_launched = []
+
     def _on_grad(self, p):
         if not self._active():
             return

@@ -74,6 +74,8 @@ def _op(*fields, **kw):
     o.rows2_sym = kw.get('rows2', SYM_ZERO)
     o.post_weight, o.post_bias, o.post_N, o.post_act = kw.get('post', (-1, -1, 0, 0))[:4]
     o.post_mid = kw['post'][4] if len(kw.get('post', ())) > 4 else _NONE
+    o.b = kw.get('b') or _NONE
+    o.flags, o.aux = kw.get('flags', 0), kw.get('aux', 0)
     return o
 
 
@@ -81,9 +83,11 @@ class _Program(object):
     def __init__(self, bank):
         self.ops, self.bufs, self.bank = [], [], bank
         self.cond = (0, 0)          # (HPL_COND_*, level) stamped on the ops emitted next
-        self.weights = []           # (weight param, R, Q, F, sr, sq, sf, base)
+        self.weights = []           # (weight param, R, Q, F, sr, sq, sf, base[, mirror]) bank images; ('grad', i) gradient images
         self.biases = []            # tensors (kept alive; combined biases are refreshed in place)
         self.combined = []          # (tensor, (param a, param b))
+        self.meta = []              # per op: what train_plan needs to write its gradient (None: no gradient flows through it)
+        self.wmeta = {}             # weight index -> (param, C, O, F, Ctot, c0)
 
     def buf(self, rows_sym, cols):
         self.bufs.append((rows_sym, cols))
@@ -92,8 +96,9 @@ class _Program(object):
     def weight(self, w, C, O, F, Ctot, c0):
         # the image ops._cached_relayout makes: Wt[(f*C + c), o] = W[o, c0 + c, f]
         key = (w, C, O, F, F, Ctot * F, 1, c0 * F)
-        self.bank.get(w.detach(), C, O, F, F, Ctot * F, 1, base=c0 * F)
+        self.bank.register(w.detach(), C, O, F, F, Ctot * F, 1, base=c0 * F)
         self.weights.append(key)
+        self.wmeta[len(self.weights) - 1] = (w, C, O, F, Ctot, c0)
         return len(self.weights) - 1
 
     def bias(self, b):
@@ -111,29 +116,45 @@ class _Program(object):
         return self.bias(t)
 
     def gconv(self, a, out, M, C, N, wid, bias=-1, act=0, slope=0.1, F=1, level=0, table=TBL_NONE, order=ORD_NONE,
-              res=None, res_mod=SYM_ZERO, reg_stride=SYM_ZERO, tag=TAG_OTHER, out2=None, rows2=SYM_ZERO, post=None):
+              res=None, res_mod=SYM_ZERO, reg_stride=SYM_ZERO, tag=TAG_OTHER, out2=None, rows2=SYM_ZERO, post=None, flags=0, aux=0):
         """out2 / rows2: the first `rows2` rows of the result are written to a second view as well (a layer output that
         feeds two concatenation buffers is stored by its producer, not copied)."""
         self.ops.append(_op(OP_GCONV, tag, a.c(), out.c(), res.c() if res is not None else _NONE, M, res_mod, level, table,
                             order, F, C, N, wid, bias, act, slope, 0, reg_stride, 0, *self.cond,
-                            out2=out2.c() if out2 is not None else None, rows2=rows2, post=post or (-1, -1, 0, 0)))
+                            out2=out2.c() if out2 is not None else None, rows2=rows2, post=post or (-1, -1, 0, 0),
+                            flags=flags, aux=aux))
+        self.meta.append(dict(kind='gconv', a=a, out=out, res=res, M=M, C=C, N=N, wid=wid, bias=bias, act=act, slope=slope, F=F,
+                              level=level, table=table, order=order, res_mod=res_mod, reg_stride=reg_stride, out2=out2,
+                              rows2=rows2, cond=self.cond, post=post, tag=tag))
 
-    def splat(self, a, out, level, table, H, C, use_norm):
+    def splat(self, a, out, level, table, H, C, use_norm, flags=0):
         self.ops.append(_op(OP_SPLAT, TAG_OTHER, a.c(), out.c(), _NONE, H, SYM_ZERO, level, table, 0, 1, C, C, -1, -1, 0, 0.0,
-                           int(bool(use_norm)), SYM_ZERO, 0, *self.cond))
+                           int(bool(use_norm)), SYM_ZERO, 0, *self.cond, flags=flags))
+        self.meta.append(dict(kind='splat', a=a, out=out, level=level, table=table, H=H, C=C, use_norm=use_norm, cond=self.cond))
 
     def slice(self, a, out, level, N, C, bias=-1):
         self.ops.append(_op(OP_SLICE, TAG_OTHER, a.c(), out.c(), _NONE, N, SYM_ZERO, level, TBL_CLOUD0, 0, 1, C, C, -1, bias, 0,
                            0.0, 0, SYM_ZERO, 0, *self.cond))
+        self.meta.append(dict(kind='slice', a=a, out=out, level=level, N=N, C=C, bias=bias, cond=self.cond))
 
-    def copy(self, a, out, rows, C, level=0):
+    def copy(self, a, out, rows, C, level=0, flags=0):
         """a None: el_minus_gr of `level` (both clouds, point-major)."""
         self.ops.append(_op(OP_COPY, TAG_OTHER, a.c() if a is not None else _NONE, out.c(), _NONE, rows, SYM_ZERO, level, 0, 0,
-                           1, C, C, -1, -1, 0, 0.0, 0, SYM_ZERO, 0, *self.cond))
+                           1, C, C, -1, -1, 0, 0.0, 0, SYM_ZERO, 0, *self.cond, flags=flags))
+        self.meta.append(None)
 
     def load(self, out, ext, rows):
         self.ops.append(_op(OP_LOAD, TAG_OTHER, _NONE, out.c(), _NONE, rows, SYM_ZERO, 0, 0, 0, 1, 3, 3, -1, -1, 0, 0.0, 0,
                            SYM_ZERO, ext, 0, 0))
+        self.meta.append(None)
+
+    def raw(self, kind, a=None, out=None, b=None, M=SYM_ZERO, level=0, table=TBL_NONE, order=ORD_NONE, F=1, C=0, N=0, weight=-1, bias=-1,
+            slope=0.0, use_norm=0, reg_stride=SYM_ZERO, flags=0, aux=0):
+        """An op of the backward program (train_plan): fields as hpl_op, cond = the current one."""
+        self.ops.append(_op(kind, TAG_OTHER, a.c() if a is not None else _NONE, out.c() if out is not None else _NONE, _NONE, M, SYM_ZERO,
+                            level, table, order, F, C, N, weight, bias, 0, slope, int(bool(use_norm)), reg_stride, 0, *self.cond,
+                            b=b.c() if b is not None else None, flags=flags, aux=aux))
+        self.meta.append(None)
 
 
 def _dense(P, x, conv, act, slope, M, out=None, rows_sym=None):
@@ -410,7 +431,7 @@ class ForwardPlan(object):
         self._images_ready = None       # event recorded behind the last write of the weight images / combined biases
         self._images_stream = None
         with torch.no_grad():
-            self.prog = build_program(model, self.bank)
+            self.prog = self._program(model)
             self.bank.refresh()
         self._mark_images_written()
         self._sig = self._signature()
@@ -421,21 +442,27 @@ class ForwardPlan(object):
         w_arr = (Weight * len(P.weights))()
         # weights of the wide tap-group convs also exist as split images (csrc/gconv3.hip: bf16 MFMA, fp32-exact operands)
         wide = set(o.weight for o in P.ops if o.kind == OP_GCONV and o.table in (TBL_NONE, TBL_BLUR_PAIR, TBL_BLUR0, TBL_CORR1, TBL_CORR2)
-                   and o.N >= ops.SPLIT3_MIN_N and o.C >= ops.SPLIT3_MIN_C) if ops.SPLIT3 else set()
+                   and not (o.flags & 2) and o.N >= ops.SPLIT3_MIN_N and o.C >= ops.SPLIT3_MIN_C) if ops.SPLIT3 else set()
         self._split3 = {}           # weight index -> (image view, split image)
+        done = {}                   # bank job -> split image (several weight indices may name one image)
         for i, key in enumerate(P.weights):
-            job = self.bank.jobs[self.bank._key(key[0], *key[1:], False)]
-            R, Q, F = key[1], key[2], key[3]
-            k_rows, ldw = ops.round_up(F * R, 32), ops.round_up(Q, 4)
+            if key[0] == 'grad':                 # gradient image of a training plan: (pointer, rows, ldw) from _grad_image
+                w_arr[i].Wt, w_arr[i].rows, w_arr[i].ldw = self._grad_image(key[1])
+                continue
+            mirror = key[8] if len(key) > 8 else 0
+            job = self.bank.jobs[self.bank._key(key[0], *key[1:8], mirror)]
+            k_rows, ldw = job[6], job[7]
             w_arr[i].Wt = self.bank.buf.data_ptr() + 4 * job[2]
             w_arr[i].ldw, w_arr[i].rows = ldw, k_rows
-            if i in wide:
-                img = self.bank.buf[job[2]:job[2] + k_rows * ldw].view(k_rows, ldw)
-                w3 = ops.weight_split3(img)
-                self._split3[i] = (img, w3)
+            if i in wide and mirror != 2:
+                if id(job) not in done:
+                    img = self.bank.buf[job[2]:job[2] + k_rows * ldw].view(k_rows, ldw)
+                    done[id(job)] = (img, ops.weight_split3(img))
+                    self._split3[i] = done[id(job)]
+                w3 = done[id(job)][1]
                 w_arr[i].Wt3, w_arr[i].wt3_plane_stride = w3.data_ptr(), w3.stride(0)
         self._mark_images_written()
-        b_arr = (ctypes.c_void_p * max(1, len(P.biases)))(*[b.data_ptr() for b in P.biases])
+        b_arr = (ctypes.c_void_p * max(1, len(P.biases)))(*[(b if isinstance(b, int) else b.data_ptr()) for b in P.biases])
         self.handle = L.hpl_plan_create(ops_arr, len(P.ops), bufs_arr, len(P.bufs), w_arr, len(P.weights), b_arr,
                                         len(P.biases))
         if not self.handle:
@@ -446,6 +473,9 @@ class ForwardPlan(object):
         self._slot = 0
         self.slots = int(os.environ.get('HPL_PLAN_SLOTS', '4'))      # forwards in flight before a workspace is reused (bench: 3 forward streams)
         self._fence = {}
+
+    def _program(self, model):
+        return build_program(model, self.bank)
 
     def __del__(self):
         try:

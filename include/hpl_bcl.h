@@ -101,6 +101,13 @@ int hpl_splat(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr, con
  * also the backward of hpl_splat w.r.t. feat (SparseSum.backward, bilateralNN.py:33-40). */
 int hpl_slice(const float *Y, int64_t ldy, int C, const float *bary, const int32_t *off, int64_t N,
               const float *vscale, const float *bias, float *out, int64_t ldo, hplStream stream);
+/* The same two kernels ADDING to what `out` holds: a feature matrix with several consumers collects their gradients
+ * (autograd's accumulation of models/HPLFlowNet.py's torch.cat / reuse of a tensor). */
+int hpl_splat_add(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr, const int32_t *csr_pt,
+                  const float *csr_w, const float *norm, int64_t H, float *out, int64_t ldo,
+                  hplStream stream);
+int hpl_slice_add(const float *Y, int64_t ldy, int C, const float *bary, const int32_t *off, int64_t N,
+                  const float *vscale, const float *bias, float *out, int64_t ldo, hplStream stream);
 
 /* ------------------------------------------------------------------------ *
  * Per-vertex dense contraction: gather-GEMM on fp32 MFMA
@@ -127,6 +134,16 @@ typedef struct hpl_relayout_job {
 } hpl_relayout_job;
 int hpl_weight_relayout_batch(const hpl_relayout_job *jobs /* DEVICE */, int njobs,
                               const int64_t *prefix /* DEVICE, njobs + 1 */, int64_t total, float *dst,
+                              hplStream stream);
+/* mirror == 2 ("taps as column blocks"): the image is [roundup(R, 32)][ldw >= F*Q] with element (r, f*Q + q) =
+ * W[base + r*sr + q*sq + f*sf] -- the operand of the scatter / regular data gradients of the correlation layer
+ * (models/bnn_flow.py:202-205 backward: G[m, (f, c)] = g[m] . W[:, c, f]). */
+/* The inverse of the batch call, for the weight gradients of a whole training step: job j reads its image
+ * [k_rows][ldw] at src + (prefix[j] - prefix[0]) and writes W[base + r*sr + q*sq + f*sf] = src_j[(f*R + r)*ldw + q]
+ * (mirror 0 or 2); W is then the job's gradient tensor in the parameter's own layout (main.py:214 loss.backward()).
+ * total = elements of all images (sizes the grid). */
+int hpl_weight_unlayout_batch(const hpl_relayout_job *jobs /* DEVICE */, int njobs,
+                              const int64_t *prefix /* DEVICE, njobs + 1 */, int64_t total, const float *src,
                               hplStream stream);
 
 /* Split weight image for the bf16-MFMA path: Wt [k_rows][ldw] fp32 (k_rows % 8 == 0) -> three planes p = 0 (hi),
@@ -291,6 +308,19 @@ int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStre
 /* dX = dY * (Y > 0 ? 1 : slope)   element-wise on [M][N] views (LeakyReLU backward) */
 int hpl_leaky_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, float slope,
                   float *dX, int64_t lddx, int64_t M, int N, hplStream stream);
+/* out[h, n] (+)= sum_j X[(j*mod + h)*ldx + n], j < rows / mod: the gradient of a residual that was broadcast over the
+ * rows / mod blocks of a result (the f-independent pc1 half of the patch correlation, models/bnn_flow.py:192). */
+int hpl_psum(const float *X, int64_t ldx, int64_t rows, int64_t mod, int N, float *out, int64_t ldo, int accumulate,
+             hplStream stream);
+/* out[(f*M + m)*ldo + c] (+)= G[m*ldg + f*C + c]: the data gradient of the displacement filter (whose tap f of vertex m
+ * reads row f*M + m, models/bnn_flow.py:205) from the plain GEMM G = g . W. */
+int hpl_regroup(const float *G, int64_t ldg, int64_t M, int F, int C, float *out, int64_t ldo, int accumulate,
+                hplStream stream);
+/* EPE3DLoss (models/epe3d_loss.py:9-10, main.py:213) and its gradient in one launch: pred [N][3] point-major (the
+ * flow hpl_plan_run writes), sf (3, N); *loss = mean_n ||pred_n - sf_n||_2 (one workgroup, fixed-order sum:
+ * deterministic), grad[n][c] = (pred - sf) / (N * ||.||) (0 where the norm is 0). */
+int hpl_epe3d(const float *pred, const float *sf, int64_t N, float *grad, float *loss, hplStream stream);
+
 /* Per-tap lists of present vertices: list_m[tap_ptr[f] .. tap_ptr[f+1]) = { m : nbr[f][m] >= 0 }
  * ascending, list_row = their source rows nbr[f][m]; both hold up to F*M entries, tap_ptr F+1
  * (DEVICE).  scratch: 2*F*ceil(M/1024) + 1100 int32.  Consumer: hpl_gconv_wgrad (exact skipping
@@ -398,6 +428,26 @@ int hpl_lattice_next_points(const int32_t *vkeys, int64_t vstride, int64_t H, fl
 #define HPL_OP_COPY 4         /* out[:, cols] = a[:, cols]   (the torch.cat calls of the reference forward) */
 #define HPL_OP_LOAD 5         /* out rows = transpose of an external (3, N) cloud (ext: 0 = pc1, 1 = pc2) */
 
+/* Training (hpl_plan_run_range): the backward of the same program as more operations of the same plan.  Each is the
+ * hand-written gradient of one forward op (what autograd derives for models/bilateralNN.py:151-238 and
+ * models/bnn_flow.py:119-208), written by hplflownet_amd/plan.py in reverse order. */
+#define HPL_OP_WGRAD 6        /* hpl_gconv_wgrad: a = the forward op's input, b = the gradient of its output; weight = index of
+                                 the gradient image, bias = index of the bias-gradient vector or -1 */
+#define HPL_OP_LEAKY_BWD 7    /* hpl_leaky_bwd: a = dY, b = Y, out = dX (may be a) */
+#define HPL_OP_COLSUM 8       /* hpl_colsum of a [m_sym][C] into bias vector `bias` */
+#define HPL_OP_SPLAT_BWD 9    /* gradient of HPL_OP_SPLAT: hpl_slice with the normaliser as vertex scale (pair CSR: one per cloud) */
+#define HPL_OP_PSUM 10        /* hpl_psum: a [F*m_sym][N] -> out [m_sym][N] */
+#define HPL_OP_REGROUP 11     /* hpl_regroup: a [m_sym][F*C] -> out [F*m_sym][C] */
+#define HPL_OP_ZERO 12        /* out = 0 */
+#define HPL_OP_EPE3D 13       /* hpl_epe3d on the run's flow / sf / loss; out = gradient [N0][3] */
+#define HPL_OP_VCOPY 14       /* bias vector `bias` = bias vector `weight` (N entries): a gradient shared by two parameters */
+#define HPL_OP_UNLAYOUT 15    /* hpl_weight_unlayout_batch of bucket `aux` (hpl_plan_set_unlayout) */
+
+#define HPL_FLAG_ACCUM 1      /* the op adds to what `out` holds (gconv: first pass with res = out) */
+#define HPL_FLAG_SCATTER 2    /* gconv: scatter epilogue through the level's corr2 table, aux = channels per tap (scat_c) */
+#define HPL_FLAG_TAPS 4       /* wgrad: sum over the per-tap vertex lists of the level's cloud-1 blur table (when the run has them) */
+#define HPL_FLAG_SIDE 8       /* the op is a leaf of the backward graph: it may run on the side stream of hpl_plan_run_range */
+
 #define HPL_TBL_NONE 0
 #define HPL_TBL_BLUR_PAIR 1   /* blur table of the stacked pair [15][H0+H1]          (Down convs) */
 #define HPL_TBL_BLUR0 2       /* its cloud-1 columns                                  (Up convs) */
@@ -467,6 +517,9 @@ typedef struct hpl_op {
     int32_t post_act;
     hpl_ref post_mid;         /*        where the first conv's result goes when the executor runs the two convs as two launches
                                         (rows above its fusion threshold: a separate dense launch is the faster form there) */
+    hpl_ref b;                /* second input of the backward ops (buf == -1: none) */
+    int32_t flags;            /* HPL_FLAG_* */
+    int32_t aux;
 } hpl_op;
 
 /* Kernel-ready tables of one lattice level of a pair (what hplflownet_amd.lattice builds on the device;
@@ -499,6 +552,12 @@ typedef struct hpl_level_tables {
     const int32_t *up_perm_tidx, *up_perm_tmask;
     const int32_t *up_group_tidx[4], *up_group_tmask[4];
     const int32_t *corr1_perm_tidx, *corr1_perm_tmask;
+    /* training only (zero otherwise): cloud 2's barycentric weights / offsets [4][n1] (the splat's gradient), and the per-tap
+     * vertex lists of the cloud-1 blur table (hpl_tap_lists; up_tap_max = its longest list or H0) */
+    const float *bary1;
+    const int32_t *off1;
+    const int32_t *up_tap_m, *up_tap_row, *up_tap_ptr;
+    int64_t up_tap_max;
 } hpl_level_tables;
 
 typedef struct hpl_plan hpl_plan;   /* not thread-safe: one thread runs a given plan at a time (any number of streams) */
@@ -513,6 +572,19 @@ int64_t hpl_plan_workspace_bytes(const hpl_plan *plan, const hpl_level_tables *l
  * on `stream`; `workspace` must not be reused before the run has finished on the device. */
 int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels /* HOST */, int n_levels, const float *pc1,
                  const float *pc2, float *out, void *workspace, int64_t workspace_bytes, hplStream stream);
+/* Ops [op_begin, op_end) of the plan only (same carving of the workspace in every call: a step may be issued in
+ * pieces, e.g. to start a gradient all-reduce between them).  sf (3, n0) and loss (DEVICE, one float) serve HPL_OP_EPE3D
+ * (NULL: such an op is an error); side_stream (or NULL): ops flagged HPL_FLAG_SIDE are enqueued there behind an event on
+ * `stream` (an un-layout flagged that way follows the weight gradients it reads on that stream); `stream` waits for them before
+ * an HPL_OP_UNLAYOUT that runs on it and, with join != 0, at the end of the range (always join in the LAST range of a step). */
+int hpl_plan_run_range(hpl_plan *plan, const hpl_level_tables *levels /* HOST */, int n_levels, const float *pc1,
+                       const float *pc2, const float *sf, float *out, float *loss, void *workspace,
+                       int64_t workspace_bytes, hplStream stream, hplStream side_stream, int op_begin, int op_end, int join);
+/* The un-layout jobs of HPL_OP_UNLAYOUT: bucket i = jobs [bucket_first[i], bucket_first[i+1]) of the DEVICE tables
+ * (hpl_weight_unlayout_batch); src = the gradient images (image of job j at src + prefix[j]). */
+int hpl_plan_set_unlayout(hpl_plan *plan, const hpl_relayout_job *jobs /* DEVICE */, const int64_t *prefix /* DEVICE */,
+                          const float *src, const int32_t *bucket_first /* HOST, n_buckets + 1 */,
+                          const int64_t *bucket_offset /* HOST, n_buckets + 1: prefix[bucket_first[i]] */, int n_buckets);
 /* Profiling: with tag >= 0 every following run brackets the ops of that tag with HIP events on the run's stream
  * (tag < 0: off).  hpl_plan_profile_read waits for the recorded events and returns the number of bracketed
  * launches, their total duration in ms, and resets the record. */

@@ -1,0 +1,88 @@
+"""GPU: the native training step (hplflownet_amd.train_plan: forward + EPE3D loss + backward as ONE program of csrc/executor.hip)
+against the autograd path over the same kernels (ops.GConvFn / SplatFn / SliceFn, itself pinned to the reference's gradients by
+tests/test_gpu_autograd.py, test_gpu_bench_size.py and fixture F5/F9): same flow, same loss, every parameter gradient entry by entry."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_, synthetic_pair
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _setup(arch, n, seed=0):
+    import hplflownet_amd as H
+    nl = 7 if arch == 'HPLFlowNet' else 5
+    a = types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP[:nl], evaluate=False, use_leaky=True, bcn_use_bias=True,
+                              bcn_use_norm=True, last_relu=False, DEVICE='cuda')
+    model = getattr(H, arch)(a)
+    fill_module_(model, 1.0, 'hash')
+    model = model.to(DEV).train()
+    gen = H.GenerateDataUnsymmetric(a, device=DEV, wide_up=model.lattice_hint())
+    pc1, pc2, sf = synthetic_pair(n, seed)
+    t = [torch.from_numpy(np.ascontiguousarray(x.T)).to(DEV) for x in (pc1, pc2, sf)]
+    return model, gen, t
+
+
+def _autograd_step(model, t, lat):
+    for p in model.parameters():
+        p.grad = None
+    flow = model(t[0][None], t[1][None], lat)
+    loss = torch.norm(flow - t[2][None], p=2, dim=1).mean()
+    loss.backward()
+    return flow.detach().clone(), float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize('arch,n,native_lat', [('HPLFlowNetShallow', 512, False), ('HPLFlowNet', 1024, True), ('HPLFlowNet', 4096, True)])
+def test_native_step_matches_autograd(arch, n, native_lat):
+    from hplflownet_amd.train_plan import TrainPlan
+    model, gen, t = _setup(arch, n)
+    lat = (gen.build_native(t[0], t[1]).device_lattice() if native_lat else gen.build(t[0], t[1])).prepare(True)
+    flow_a, loss_a, grads_a = _autograd_step(model, t, lat)
+    for side in (False, True):
+        plan = TrainPlan(model, side_stream=side)
+        r = plan.step(t[0], t[1], t[2], lat)
+        assert r is not None
+        plan.finish()
+        torch.cuda.synchronize()
+        flow_n, loss_n = r
+        assert float((flow_n - flow_a).abs().max()) <= 1e-5 * float(flow_a.abs().max())
+        assert abs(float(loss_n) - loss_a) <= 1e-5 * abs(loss_a)
+        worst = ('', 0.0)
+        for k, p in model.named_parameters():
+            ga, gn = grads_a[k], p.grad
+            assert gn.data_ptr() >= plan.gflat.data_ptr() and gn.shape == ga.shape          # still a view of the arena
+            err = float((gn - ga).abs().max()) / max(float(ga.abs().max()), 1e-20)
+            if err > worst[1]:
+                worst = (k, err)
+        # both paths sum the same products; they differ where sums are atomic (weight-gradient slabs, corr2 scatter)
+        assert worst[1] < 2e-4, worst
+        # a second step on the same plan (buffers reused, arenas re-zeroed): the same numbers
+        g1 = plan.gflat.clone()
+        plan.step(t[0], t[1], t[2], lat)
+        plan.finish()
+        torch.cuda.synchronize()
+        assert float((plan.gflat - g1).abs().max()) <= 2e-4 * float(g1.abs().max())
+        del plan
+
+
+def test_trainer_takes_the_native_step_and_matches_the_autograd_loop():
+    """engine.Trainer with and without the native step: three Adam steps on the same pair end at the same weights."""
+    import os
+    from hplflownet_amd import engine
+    pc1, pc2, sf = synthetic_pair(512, 0)
+    data = [tuple(torch.from_numpy(np.ascontiguousarray(a.T)).to(DEV) for a in (pc1, pc2, sf))]
+    runs = {}
+    for native in (True, False):
+        tr = engine.Trainer('HPLFlowNetShallow', DEV, lr=1e-4, init='hash', native_step=native)
+        losses = [tr.train_epoch(data) for _ in range(3)]
+        assert (tr.native_steps == 3) if native else (tr.native_steps == 0)
+        runs[native] = (losses, {k: p.detach().clone() for k, p in tr.model.named_parameters()})
+    for a, b in zip(runs[True][0], runs[False][0]):
+        assert abs(a - b) < 2e-3 * abs(b)
+    for k in runs[True][1]:
+        d = float((runs[True][1][k] - runs[False][1][k]).abs().max())
+        assert d <= 6.1e-4, (k, d)                       # (Adam moves an entry by <= lr per step whatever the gradient's size)
