@@ -107,6 +107,9 @@ _SIGNATURES = {
     'hpl_psum': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, ctypes.c_int, c_vp, c_i64, ctypes.c_int, c_vp]),
     'hpl_regroup': (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, ctypes.c_int, c_vp, c_i64, ctypes.c_int, c_vp]),
     'hpl_epe3d': (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'hpl_gather_sum': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_i64, c_i64,
+                                      ctypes.c_int, c_f32, c_vp, c_i64, c_vp]),
+    'hpl_table_invert': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, ctypes.c_int, c_i64, c_vp, c_vp]),
     'hpl_weight_relayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i64, c_i64,
                                            c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
     'hpl_weight_relayout_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp, c_vp]),

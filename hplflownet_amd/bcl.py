@@ -184,6 +184,13 @@ class NbrTable(object):
             self._taps = ops.tap_lists(self.t) if (1 < F <= 15 and M >= self.TAPS_MIN_ROWS) else None
         return self._taps
 
+    def inverse(self, H0, F, Hv):
+        """For the permuted pc2_corr_indices [K, F*H0] (values: pc2 vertices < Hv): int32 [F, K*Hv] with
+        inverse[f][v*K + k] = the virtual vertex f*H0 + h that gathers v through tap k (ops.table_invert), built once."""
+        if getattr(self, '_inv', None) is None:
+            self._inv = ops.table_invert(self.t, H0, F, Hv)
+        return self._inv
+
     @property
     def symmetric(self):
         if self._sym is None:
@@ -494,8 +501,12 @@ class BilateralCorrelationFlex(nn.Module):
             a = ops.gconv(ps, w0, None, corr1.t, H1, K, c0=0, C=P, res=a, res_mod=H1, bwd_mode=mode1, row_perm=perm1,
                           tiles=corr1.perm_tiles)
         # B-term over the F*H1 virtual vertices, + broadcast A-term + bias, LeakyReLU
-        p = ops.gconv(f2, w0, conv0.bias, corr2.t, F * H1, K, act=ACT_LEAKY, c0=P + C, C=C, res=a,
-                      res_mod=H1, bwd_mode='scatter', slope=sl)
+        if w0.shape[0] % 4 == 0 and K == 15 and F == 15:
+            # every pc2 vertex projected once per correlation tap, then a gather-sum of 32-float rows (ops.CorrPc2Fn)
+            p = ops.corr_pc2(f2, w0, conv0.bias, a, corr2, H1, F, K, P + C, C, sl)
+        else:
+            p = ops.gconv(f2, w0, conv0.bias, corr2.t, F * H1, K, act=ACT_LEAKY, c0=P + C, C=C, res=a,
+                          res_mod=H1, bwd_mode='scatter', slope=sl)
         for m in list(self.corr_conv)[1:]:
             p = ops.gconv(p, m.conv.weight, m.conv.bias, None, F * H1, 1, act=ACT_LEAKY, bwd_mode='dense',
                           slope=sl)

@@ -119,6 +119,7 @@ int resolve_syms(const hpl_level_tables *lv, int n_levels, int64_t *sym) {
         s[HPL_SYM_FH0] = 15 * lv[L].H0;
         s[HPL_SYM_IN0] = lv[L].n0;
         s[HPL_SYM_INP] = lv[L].n0 + lv[L].n1;
+        s[HPL_SYM_FH1] = 15 * lv[L].H1;
     }
     return HPL_OK;
 }
@@ -510,6 +511,35 @@ struct Runner {
             if (n <= 0) return HPL_OK;
             return hpl_weight_unlayout_batch(pl.ul_jobs + first, n, pl.ul_prefix + first, pl.ul_offset[op.aux + 1] - pl.ul_offset[op.aux],
                                              pl.ul_src + pl.ul_offset[op.aux], hs);
+        }
+        case HPL_OP_GSUM: {
+            View R;
+            if ((rc = view(op.a, A, "gather-sum input")) || (rc = view(op.out, Y, "gather-sum output"))) return rc;
+            HPL_REQUIRE(op.level >= 0 && op.level < n_levels && op.F >= 1 && op.N > 0, "hpl_plan_run: gather-sum at level %d", op.level);
+            const hpl_level_tables &t = lv[op.level];
+            const int64_t M = symv(sym, op.m_sym);
+            const bool has_res = op.res.buf != -1;
+            if (has_res && (rc = view(op.res, R, "gather-sum residual"))) return rc;
+            const float *bias = op.bias >= 0 ? pl.biases[op.bias] : nullptr;
+            if (op.flags & HPL_FLAG_INVERSE) {
+                View B;
+                if ((rc = view(op.b, B, "inverse table"))) return rc;
+                HPL_REQUIRE(B.ld == B.cols && B.rows * B.cols >= (int64_t)op.F * M && Y.ld == Y.cols && Y.rows * Y.cols >= M * op.N &&
+                                A.cols >= op.N && !has_res, "hpl_plan_run: gather-sum through an inverse table: shapes");
+                return hpl_gather_sum(A.p, A.ld, reinterpret_cast<const int32_t *>(B.p), M, M, op.F, op.N, 0, bias, nullptr, 0, 0, op.act,
+                                      op.slope, Y.p, op.N, hs);
+            }
+            HPL_REQUIRE(op.table == HPL_TBL_CORR2 && t.corr2 && M == 15 * t.H0 && A.cols >= op.F * op.N && A.rows >= t.H1 && Y.rows >= M &&
+                            Y.cols >= op.N, "hpl_plan_run: gather-sum shapes at level %d", op.level);
+            return hpl_gather_sum(A.p, A.ld, t.corr2, 15 * t.H0, M, op.F, op.N, op.N, bias, has_res ? R.p : nullptr, has_res ? R.ld : 0,
+                                  has_res ? (op.res_mod_sym >= 0 ? sym[op.res_mod_sym] : R.rows) : 0, op.act, op.slope, Y.p, Y.ld, hs);
+        }
+        case HPL_OP_INVERT: {
+            if ((rc = view(op.out, Y, "inverse table"))) return rc;
+            HPL_REQUIRE(op.level >= 0 && op.level < n_levels && lv[op.level].corr2, "hpl_plan_run: invert at level %d", op.level);
+            const hpl_level_tables &t = lv[op.level];
+            HPL_REQUIRE(Y.ld == Y.cols && Y.rows * Y.cols >= 225 * t.H1, "hpl_plan_run: inverse table buffer too small");
+            return hpl_table_invert(t.corr2, 15 * t.H0, 15, t.H0, 15, t.H1, reinterpret_cast<int32_t *>(Y.p), hs);
         }
         default: HPL_REQUIRE(false, "hpl_plan_run: unknown op kind %d", op.kind);
         }

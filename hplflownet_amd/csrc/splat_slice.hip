@@ -163,6 +163,57 @@ __global__ void __launch_bounds__(256) k_slice(const float *__restrict__ Y, int6
     }
 }
 
+
+// Patch correlation from per-tap projections (hpl_gather_sum): one lane per (row m, 4 output columns); the K gathered 16-byte words
+// of a lane are independent loads (the K indices of a row are read first), the NV lanes of a row read one contiguous run of
+// N floats of Z.  Nothing is reused between rows, so there is no LDS stage.
+template <int KMAX>
+__global__ void __launch_bounds__(256) k_gather_sum(const float *__restrict__ Z, int64_t ldz, const int32_t *__restrict__ nbr,
+                                                    int64_t nbr_stride, int64_t M, int K, int NV, int col_step, const float *__restrict__ bias,
+                                                    const float *__restrict__ res, int64_t ldres, int64_t res_mod, int act, float slope,
+                                                    float *__restrict__ Y, int64_t ldy) {
+    const int64_t total = M * NV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / NV;
+        const int c = (int)(i - m * NV) * 4;
+        int32_t v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) v[k] = k < K ? nbr[(int64_t)k * nbr_stride + m] : -1;
+        float4 x[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            x[k] = v[k] >= 0 ? *reinterpret_cast<const float4 *>(Z + (int64_t)v[k] * ldz + (int64_t)k * col_step + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { acc.x += x[k].x; acc.y += x[k].y; acc.z += x[k].z; acc.w += x[k].w; }
+        if (res) {
+            const float4 r = *reinterpret_cast<const float4 *>(res + (m % res_mod) * ldres + c);
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias + c);
+            acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+        }
+        if (act == HPL_ACT_LEAKY) {
+            acc.x = acc.x > 0.f ? acc.x : slope * acc.x; acc.y = acc.y > 0.f ? acc.y : slope * acc.y;
+            acc.z = acc.z > 0.f ? acc.z : slope * acc.z; acc.w = acc.w > 0.f ? acc.w : slope * acc.w;
+        }
+        *reinterpret_cast<float4 *>(Y + m * ldy + c) = acc;
+    }
+}
+
+// inverse of a [K][F*H0] table whose row blocks m / H0 = f are injective maps h -> v (the pc2 table of the patch correlation):
+// inv[f][v*K + k] = m for T[k][m] = v >= 0; inv pre-filled with -1 by the caller
+__global__ void __launch_bounds__(256) k_table_invert(const int32_t *__restrict__ T, int64_t stride, int K, int64_t M, int64_t H0,
+                                                      int64_t H1, int32_t *__restrict__ inv) {
+    const int64_t total = (int64_t)K * M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t k = i / M, m = i - k * M;
+        const int32_t v = T[k * stride + m];
+        if (v >= 0) inv[(m / H0) * ((int64_t)K * H1) + (int64_t)v * K + k] = (int32_t)m;
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -232,4 +283,32 @@ extern "C" int hpl_slice(const float *Y, int64_t ldy, int C, const float *bary, 
 extern "C" int hpl_slice_add(const float *Y, int64_t ldy, int C, const float *bary, const int32_t *off, int64_t N,
                              const float *vscale, const float *bias, float *out, int64_t ldo, hplStream stream) {
     return slice_launch(Y, ldy, C, bary, off, N, vscale, bias, out, ldo, stream, 1);
+}
+
+
+extern "C" int hpl_gather_sum(const float *Z, int64_t ldz, const int32_t *nbr, int64_t nbr_stride, int64_t M, int K, int N,
+                              int col_step, const float *bias, const float *res, int64_t ldres, int64_t res_mod, int act, float slope,
+                              float *Y, int64_t ldy, hplStream stream) {
+    HPL_REQUIRE(Z && nbr && Y, "hpl_gather_sum: null pointer");
+    HPL_REQUIRE(M >= 0 && K >= 1 && K <= 15 && N > 0 && N % 4 == 0 && col_step >= 0 && col_step % 4 == 0 && ldz >= (int64_t)(K - 1) * col_step + N &&
+                    ldz % 4 == 0 && ldy >= N && ldy % 4 == 0 && aligned16(Z) && aligned16(Y) && (!bias || aligned16(bias)) &&
+                    (!res || (aligned16(res) && ldres % 4 == 0 && ldres >= N && res_mod > 0)),
+                "hpl_gather_sum: bad sizes / alignment (M=%lld K=%d N=%d ldz=%lld)", (long long)M, K, N, (long long)ldz);
+    if (M == 0) return HPL_OK;
+    const int nv = N / 4;
+    const int grid = (int)imin(cdiv(M * nv, 256), 1 << 20);
+    k_gather_sum<15><<<grid, 256, 0, to_stream(stream)>>>(Z, ldz, nbr, nbr_stride, M, K, nv, col_step, bias, res, ldres, res ? res_mod : 1, act,
+                                                          slope, Y, ldy);
+    HPL_CHECK_LAUNCH("hpl_gather_sum");
+    return HPL_OK;
+}
+
+extern "C" int hpl_table_invert(const int32_t *T, int64_t stride, int K, int64_t H0, int F, int64_t H1, int32_t *inv, hplStream stream) {
+    HPL_REQUIRE(T && inv && K > 0 && F > 0 && H0 > 0 && H1 > 0 && stride >= (int64_t)F * H0, "hpl_table_invert: bad arguments");
+    hipStream_t s = to_stream(stream);
+    if (hipMemsetAsync(inv, 0xff, (size_t)F * K * H1 * 4, s) != hipSuccess) { set_error("hpl_table_invert: hipMemsetAsync failed"); return HPL_EHIP; }
+    const int64_t M = (int64_t)F * H0;
+    k_table_invert<<<(int)imin(cdiv((int64_t)K * M, 256), 1 << 16), 256, 0, s>>>(T, stride, K, M, H0, H1, inv);
+    HPL_CHECK_LAUNCH("hpl_table_invert");
+    return HPL_OK;
 }

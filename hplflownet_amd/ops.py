@@ -233,6 +233,25 @@ def slice_raw(Y, bary, off, N, vscale=None, bias=None, out=None):
     return out
 
 
+def gather_sum_raw(Z, nbr, M, K, N, col_step, bias=None, res=None, res_mod=0, act=ACT_NONE, slope=LEAKY_RATE, out=None):
+    """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_k Z[nbr[k, m], k*col_step + n])  (hpl_gather_sum)."""
+    Z = _cl(Z)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=Z.device)
+    check(_lib.load().hpl_gather_sum(ptr(Z), _ld(Z), ptr(nbr), nbr.stride(0), M, K, N, col_step, ptr(bias), ptr(res),
+                                     _ld(res) if res is not None else 0, res_mod, act, slope, ptr(out), _ld(out), stream()),
+          'hpl_gather_sum')
+    return out
+
+
+def table_invert(tbl, H0, F, H1):
+    """int32 [K, F*H0] table with values in [0, H1) -> int32 [F, K*H1] inverse (hpl_table_invert)."""
+    K = tbl.shape[0]
+    inv = torch.empty((F, K * H1), dtype=torch.int32, device=tbl.device)
+    check(_lib.load().hpl_table_invert(ptr(tbl), tbl.stride(0), K, H0, F, H1, ptr(inv), stream()), 'hpl_table_invert')
+    return inv
+
+
 def round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -687,6 +706,78 @@ class GConvFn(torch.autograd.Function):
             else:
                 gres = g
         return gA, gW, gb, None, None, None, None, None, None, gres, None, None, None, None, None, None, None, None
+
+
+def _cols_image(weight, C, O, F, Ctot, c0):
+    """[roundup(C, 32), roundup(F*O, 4)] image with element (c, f*O + o) = weight[o, c0 + c, f] ("taps as column blocks",
+    hpl_relayout_job.mirror == 2): from the training bank when it holds a fresh one, else made here."""
+    if BANK is not None:
+        job = BANK.register(weight, C, O, F, F, Ctot * F, 1, c0 * F, 2)
+        if not BANK.dirty and job[4] == weight._version and job[0] is weight:
+            return BANK.buf[job[2]:job[2] + job[3]].view(job[6], job[7])
+    img = torch.zeros((round_up(C, 32), round_up(F * O, 4)), dtype=torch.float32, device=weight.device)
+    img[:C, :F * O] = weight.detach().reshape(O, Ctot, F)[:, c0:c0 + C, :].permute(1, 2, 0).reshape(C, F * O)
+    return img
+
+
+class CorrPc2Fn(torch.autograd.Function):
+    """The pc2 half of the patch correlation (models/bnn_flow.py:195-202) over the F*H0 virtual vertices:
+    P[f*H0 + h] = act(bias + res[h] + sum_k W_k . f2[corr2[k][f*H0 + h]]), computed as a projection of every pc2 vertex per tap
+    (one dense GEMM) and a gather-sum (hpl_gather_sum); the backward gathers through the inverse table (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, f2, weight, bias, res, table, H0, F, K, c0, C, slope):
+        O = weight.shape[0]
+        Ctot = weight.numel() // (O * K)
+        Hv = f2.shape[0]
+        Z = gconv_raw(f2, None, Hv, C, 1, _cols_image(weight, C, O, K, Ctot, c0), K * O)
+        Y = gather_sum_raw(Z, table.t, F * H0, K, O, O, bias=bias, res=res, res_mod=H0, act=ACT_LEAKY, slope=slope)
+        ctx.table, ctx.cfg = table, (H0, F, K, c0, C, O, Ctot, Hv, slope)
+        ctx.save_for_backward(f2, weight, Y)
+        return Y
+
+    @staticmethod
+    def backward(ctx, g):
+        f2, weight, Y = ctx.saved_tensors
+        H0, F, K, c0, C, O, Ctot, Hv, slope = ctx.cfg
+        g = g if (g.dim() == 2 and g.stride(1) == 1) else g.contiguous()
+        g = leaky_bwd(g, Y, slope)
+        gres = g.view(F, H0, O).sum(dim=0) if ctx.needs_input_grad[3] else None
+        gb = colsum(g) if ctx.needs_input_grad[2] else None
+        gf2 = gW = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            inv = ctx.table.inverse(H0, F, Hv)
+            dZ = gather_sum_raw(g, inv, K * Hv, F, O, 0).view(Hv, K * O)
+            if ctx.needs_input_grad[0]:
+                WzT = _train_relayout(weight, O, C, K, Ctot * K, K, 1, base=c0 * K)          # [(k*O + o), c]
+                gf2 = gconv_raw(dZ, None, Hv, K * O, 1, WzT, C)
+            if ctx.needs_input_grad[1]:
+                dWz = wgrad_raw(f2, None, Hv, C, 1, dZ, K * O)
+                gW = torch.zeros_like(weight)
+                gW.view(O, Ctot, K)[:, c0:c0 + C, :] = dWz[:C, :K * O].view(C, K, O).permute(2, 0, 1)
+        return gf2, gW, gb, gres, None, None, None, None, None, None, None
+
+
+def corr_pc2(f2, weight, bias, res, table, H0, F, K, c0, C, slope):
+    """-> [F*H0, O]; `table`: bcl.NbrTable of the permuted pc2_corr_indices [K, F*H0]."""
+    if torch.is_grad_enabled() and (f2.requires_grad or weight.requires_grad or (res is not None and res.requires_grad)):
+        return CorrPc2Fn.apply(f2, weight, bias, res, table, H0, F, K, c0, C, slope)
+    O = weight.shape[0]
+    Ctot = weight.numel() // (O * K)
+    key = (id(weight), c0, C, 'cols')
+    hit = _WT_CACHE.get(key)
+    if hit is None or hit[2] != weight._version or hit[1] is not weight or hit[3] != weight.data_ptr():
+        img = _cols_image(weight, C, O, K, Ctot, c0)
+        ev = torch.cuda.Event()
+        ev.record()
+        hit = _WT_CACHE[key] = [img, weight, weight._version, weight.data_ptr(), ev, stream()]
+    elif hit[4] is not None and stream() != hit[5]:
+        if hit[4].query():
+            hit[4] = None
+        else:
+            torch.cuda.current_stream().wait_event(hit[4])
+    Z = gconv_raw(f2, None, f2.shape[0], C, 1, hit[0], K * O)
+    return gather_sum_raw(Z, table.t, F * H0, K, O, O, bias=bias, res=res, res_mod=H0, act=ACT_LEAKY, slope=slope)
 
 
 def gconv(A, weight, bias, nbr, M, F, act=ACT_NONE, c0=0, C=None, res=None, res_mod=0, bwd_mode='scatter',

@@ -25,10 +25,11 @@ from .bcl import GROUPS_MIN_CHANNELS, _ConvReLU, _conv_of, _slope
 from .flownet import DeviceLattice, PairBlur
 
 OP_GCONV, OP_SPLAT, OP_SLICE, OP_COPY, OP_LOAD = 1, 2, 3, 4, 5
+OP_GSUM, OP_INVERT = 16, 17
 TBL_NONE, TBL_BLUR_PAIR, TBL_BLUR0, TBL_CORR1, TBL_CORR2, TBL_REGULAR, TBL_CSR_PAIR, TBL_CSR_C0, TBL_CLOUD0 = range(9)
 ORD_NONE, ORD_PERM, ORD_GROUPS = 0, 1, 2
 SYM_ZERO, SYM_N0, SYM_N1, SYM_NP, SYM_LEVEL0 = -1, 0, 1, 2, 8
-S_H0, S_H1, S_HP, S_FH0, S_IN0, S_INP = range(6)
+S_H0, S_H1, S_HP, S_FH0, S_IN0, S_INP, S_FH1 = range(7)
 BUF_OUT = -2
 
 #: HPL_FUSE_NARROW=1: a narrow conv and the 1x1 conv behind it are one op (hpl_op.post_*), which the executor runs as ONE
@@ -101,6 +102,13 @@ class _Program(object):
         self.wmeta[len(self.weights) - 1] = (w, C, O, F, Ctot, c0)
         return len(self.weights) - 1
 
+    def weight_cols(self, w, C, O, F, Ctot, c0):
+        # "taps as column blocks": Wt[c, f*O + o] = W[o, c0 + c, f]  (the per-tap projection of the patch correlation)
+        self.bank.register(w.detach(), C, O, F, F, Ctot * F, 1, c0 * F, 2)
+        self.weights.append((w, C, O, F, F, Ctot * F, 1, c0 * F, 2))
+        self.wmeta[len(self.weights) - 1] = (w, C, O, F, Ctot, c0)
+        return len(self.weights) - 1
+
     def bias(self, b):
         if b is None:
             return -1
@@ -116,7 +124,8 @@ class _Program(object):
         return self.bias(t)
 
     def gconv(self, a, out, M, C, N, wid, bias=-1, act=0, slope=0.1, F=1, level=0, table=TBL_NONE, order=ORD_NONE,
-              res=None, res_mod=SYM_ZERO, reg_stride=SYM_ZERO, tag=TAG_OTHER, out2=None, rows2=SYM_ZERO, post=None, flags=0, aux=0):
+              res=None, res_mod=SYM_ZERO, reg_stride=SYM_ZERO, tag=TAG_OTHER, out2=None, rows2=SYM_ZERO, post=None, flags=0, aux=0,
+              wcols=False):
         """out2 / rows2: the first `rows2` rows of the result are written to a second view as well (a layer output that
         feeds two concatenation buffers is stored by its producer, not copied)."""
         self.ops.append(_op(OP_GCONV, tag, a.c(), out.c(), res.c() if res is not None else _NONE, M, res_mod, level, table,
@@ -125,7 +134,14 @@ class _Program(object):
                             flags=flags, aux=aux))
         self.meta.append(dict(kind='gconv', a=a, out=out, res=res, M=M, C=C, N=N, wid=wid, bias=bias, act=act, slope=slope, F=F,
                               level=level, table=table, order=order, res_mod=res_mod, reg_stride=reg_stride, out2=out2,
-                              rows2=rows2, cond=self.cond, post=post, tag=tag))
+                              rows2=rows2, cond=self.cond, post=post, tag=tag, wcols=wcols))
+
+    def gsum(self, a, out, M, K, N, level, bias=-1, act=0, slope=0.1, res=None, res_mod=SYM_ZERO):
+        """hpl_gather_sum through the level's pc2 correlation table: out[m] = act(bias + res[m % res_mod] + sum_k a[corr2[k][m], k*N:])."""
+        self.ops.append(_op(OP_GSUM, TAG_OTHER, a.c(), out.c(), res.c() if res is not None else _NONE, M, res_mod, level, TBL_CORR2,
+                            0, K, N, N, -1, bias, act, slope, 0, SYM_ZERO, 0, *self.cond))
+        self.meta.append(dict(kind='gsum', a=a, out=out, res=res, res_mod=res_mod, M=M, K=K, N=N, level=level, bias=bias, act=act,
+                              slope=slope, cond=self.cond))
 
     def splat(self, a, out, level, table, H, C, use_norm, flags=0):
         self.ops.append(_op(OP_SPLAT, TAG_OTHER, a.c(), out.c(), _NONE, H, SYM_ZERO, level, table, 0, 1, C, C, -1, -1, 0, 0.0,
@@ -341,8 +357,14 @@ def _corr(P, model, L, f1, f2, prev, sl, dst):
                 res=a, res_mod=H0, slope=0.1)
         a = a2
     p = P.buf(FH0, O)
-    P.gconv(f2r, p, FH0, C, O, P.weight(w0, C, O, K, Ctot, Pd + C), bias=P.bias(conv0.bias), act=1, slope=csl, F=K, level=L,
-            table=TBL_CORR2, res=a, res_mod=H0)
+    if O % 4 == 0 and K == 15 and F == 15:
+        # every pc2 vertex projected once per correlation tap (dense GEMM 64 -> K*O), then a gather-sum of O-float rows
+        z = P.buf(lsym(L, S_H1), K * O)
+        P.gconv(f2r, z, lsym(L, S_H1), C, K * O, P.weight_cols(w0, C, O, K, Ctot, Pd + C), wcols=True)
+        P.gsum(z, p, FH0, K, O, L, bias=P.bias(conv0.bias), act=1, slope=csl, res=a, res_mod=H0)
+    else:
+        P.gconv(f2r, p, FH0, C, O, P.weight(w0, C, O, K, Ctot, Pd + C), bias=P.bias(conv0.bias), act=1, slope=csl, F=K, level=L,
+                table=TBL_CORR2, res=a, res_mod=H0)
     for mm in list(m.corr_conv)[1:]:
         p = _dense(P, p, mm.conv, True, csl, FH0, rows_sym=FH0)
     width = m.num_output[-1]

@@ -23,13 +23,13 @@ import torch
 from . import _lib, ops
 from ._lib import LevelTables, RelayoutJob, check, ptr, stream
 from .bcl import _ConvReLU
-from .plan import (BUF_OUT, FUSE_NARROW, ForwardPlan, ORD_NONE, OP_GCONV, S_FH0, S_H0, S_H1, S_HP, S_IN0, S_INP, SYM_N0, SYM_N1,
+from .plan import (BUF_OUT, FUSE_NARROW, ForwardPlan, ORD_NONE, OP_GCONV, OP_GSUM, OP_INVERT, S_FH0, S_FH1, S_H0, S_H1, S_HP, S_IN0, S_INP, SYM_N0, SYM_N1,
                    SYM_NP, SYM_LEVEL0, SYM_ZERO, TBL_BLUR0, TBL_BLUR_PAIR, TBL_CORR1, TBL_CORR2, TBL_CSR_C0, TBL_CSR_PAIR, TBL_NONE,
                    TBL_REGULAR, _R, build_program, level_tables, lsym)
 
 OP_WGRAD, OP_LEAKY_BWD, OP_COLSUM, OP_SPLAT_BWD, OP_PSUM, OP_REGROUP, OP_ZERO, OP_EPE3D, OP_VCOPY, OP_UNLAYOUT = range(6, 16)
 OP_SPLAT, OP_COPY = 2, 4
-F_ACCUM, F_SCATTER, F_TAPS, F_SIDE = 1, 2, 4, 8
+F_ACCUM, F_SCATTER, F_TAPS, F_SIDE, F_INVERSE = 1, 2, 4, 8, 16
 
 
 class _Sim(object):
@@ -43,7 +43,7 @@ class _Sim(object):
         n0, n1 = 3, 4
         for L in range(nlev):
             h0, h1 = 5 + 2 * L, 6 + 2 * L
-            for k, v in ((S_H0, h0), (S_H1, h1), (S_HP, h0 + h1), (S_FH0, 15 * h0), (S_IN0, n0), (S_INP, n0 + n1)):
+            for k, v in ((S_H0, h0), (S_H1, h1), (S_HP, h0 + h1), (S_FH0, 15 * h0), (S_IN0, n0), (S_INP, n0 + n1), (S_FH1, 15 * h1)):
                 sym[lsym(L, k)] = v
             n0, n1 = h0, h1
         self.sym = sym
@@ -98,6 +98,7 @@ class _Backward(object):
         self.gimg = {}                 # forward weight key -> (weight index of the gradient image, (param, C, O, F, Ctot, c0))
         self.ready = {}                # parameter index -> index of the last op that writes its gradient
         self.gout = None
+        self.inv = {}                  # level -> buffer of the inverse pc2 correlation table
 
     # ---- references
     def G(self, r):
@@ -139,7 +140,56 @@ class _Backward(object):
             getattr(self, '_' + m['kind'])(m)
         P.cond = (0, 0)
 
+    def _grad_image(self, m, cols=False):
+        """weight index of the gradient image of the forward weight image m['wid'] (one per distinct image)."""
+        key = self.P.weights[m['wid']]
+        kid = (id(key[0]),) + tuple(key[1:])
+        if kid not in self.gimg:
+            self.P.weights.append(('grad', len(self.gimg)))
+            self.gimg[kid] = (len(self.P.weights) - 1, self.P.wmeta[m['wid']], cols)
+        return self.gimg[kid][0]
+
+    def _zproj(self, m):
+        """Z = f2 . [W_0 | ... | W_{K-1}] (plan._corr: the per-tap projection of the patch correlation): dense GEMM with the taps as
+        column blocks.  dW image [C][K*O] (un-laid with mirror = 2), d f2 = dZ . [(k, o) x c] image."""
+        P, sim, cond = self.P, self.sim, m['cond']
+        w, C, O, F, Ctot, c0 = P.wmeta[m['wid']]
+        M, a = m['M'], m['a']
+        g = self.G(m['out'])
+        assert sim.written(g, cond) and m['res'] is None and not m['act'] and m['bias'] < 0
+        P.raw(OP_WGRAD, a=a, b=g, M=M, level=m['level'], table=TBL_NONE, F=1, C=C, N=F * O, weight=self._grad_image(m, True), flags=F_SIDE)
+        self._touch(w)
+        ga = self.G(a)
+        wid = self._bank(w, O, C, F, Ctot * F, F, 1, c0 * F, 0)               # rows (k*O + o), columns c
+        P.gconv(g, ga, M, F * O, C, wid, flags=F_ACCUM if sim.claim(ga, cond) else 0)
+
+    def _gsum(self, m):
+        P, sim, cond = self.P, self.sim, m['cond']
+        M, K, N, L = m['M'], m['K'], m['N'], m['level']
+        g = self.G(m['out'])
+        assert sim.written(g, cond)
+        if m['act']:
+            P.raw(OP_LEAKY_BWD, a=g, b=m['out'], out=g, M=M, N=N, slope=m['slope'])
+        if m['res'] is not None:
+            gr = self.G(m['res'])
+            P.raw(OP_PSUM, a=g, out=gr, M=m['res_mod'], F=sim.periods(M, m['res_mod']), N=N, flags=F_ACCUM if sim.claim(gr, cond) else 0)
+        if m['bias'] >= 0:
+            b = P.biases[m['bias']]
+            P.raw(OP_COLSUM, a=g, M=M, C=N, bias=self._gvec(b), flags=F_SIDE)
+            self._touch(b)
+        # dZ[(v*K + k)] = sum_f g[inverse[f][v*K + k]]: the same gather-sum through the inverse table (built once per step and level)
+        inv = self.inv.get(L)
+        if inv is None:
+            inv = self.inv[L] = P.buf(lsym(L, S_H1), 15 * K)
+            P.raw(OP_INVERT, out=inv, level=L)
+        gz = self.G(m['a'])
+        assert not sim.claim(gz, cond)
+        P.raw(OP_GSUM, a=g, b=inv, out=gz, M=lsym(L, S_FH1), level=L, F=sim.periods(M, m['res_mod']) if m['res'] is not None else 15, C=N, N=N,
+              flags=F_INVERSE)
+
     def _gconv(self, m):
+        if m.get('wcols'):
+            return self._zproj(m)
         P, sim, cond = self.P, self.sim, m['cond']
         assert m['post'] is None, 'fused conv pairs (HPL_FUSE_NARROW) have no native backward'
         M, N, F = m['M'], m['N'], m['F']
@@ -164,17 +214,13 @@ class _Backward(object):
             else:
                 P.raw(OP_PSUM, a=g, out=gr, M=m['res_mod'], F=per, N=N, flags=acc)
         # weight (and bias) gradient: a leaf
-        key = P.weights[m['wid']]
-        kid = (id(key[0]),) + tuple(key[1:])
-        if kid not in self.gimg:
-            P.weights.append(('grad', len(self.gimg)))
-            self.gimg[kid] = (len(P.weights) - 1, (w, C, O, F, Ctot, c0))
+        gw = self._grad_image(m)
         bias_t = P.biases[m['bias']] if m['bias'] >= 0 else None
         pair = next((ab for t, ab in P.combined if t is bias_t), None) if bias_t is not None else None
         bparam = pair[0] if pair is not None else bias_t
         # (Issuing the wide layers' weight gradients later -- beside the launch-bound chain of the coarse levels instead of beside the
         # equally wide data gradients -- was measured: the small launches then queue behind the wide tiles for CU slots, 13.3 -> 14.0 ms.)
-        P.raw(OP_WGRAD, a=a, b=g, M=M, level=m['level'], table=m['table'], F=F, C=C, N=N, weight=self.gimg[kid][0],
+        P.raw(OP_WGRAD, a=a, b=g, M=M, level=m['level'], table=m['table'], F=F, C=C, N=N, weight=gw,
               bias=self._gvec(bparam) if bparam is not None else -1, reg_stride=m['reg_stride'],
               flags=F_SIDE | (F_TAPS if m['table'] == TBL_BLUR0 else 0))
         self._touch(w)
@@ -299,13 +345,13 @@ class TrainPlan(ForwardPlan):
         keys = sorted(B.gimg.values(), key=lambda v: self.bucket_order.index(self._bucket_of[id(v[1][0])]))
         self._gimg_keys = keys
         off, self._gimg_off = 0, {}
-        for widx, (w, C, O, F, Ctot, c0) in keys:
-            self._gimg_off[widx] = (off, ops.round_up(F * C, 32), ops.round_up(O, 4))
-            off += ops.round_up(F * C, 32) * ops.round_up(O, 4)
+        for widx, (w, C, O, F, Ctot, c0), cols in keys:
+            rows, ldw = (ops.round_up(C, 32), ops.round_up(F * O, 4)) if cols else (ops.round_up(F * C, 32), ops.round_up(O, 4))
+            self._gimg_off[widx] = (off, rows, ldw)
+            off += rows * ldw
         self.gimg = torch.zeros(max(1, off), dtype=torch.float32, device=self.gflat.device)
-        self._gimg_of_weight = {('grad', i): None for i in range(len(keys))}
         self._grad_widx = {}
-        for widx, _ in B.gimg.values():
+        for widx, _, _ in B.gimg.values():
             self._grad_widx[P.weights[widx][1]] = widx
         return P
 
@@ -318,7 +364,7 @@ class TrainPlan(ForwardPlan):
         arr = (RelayoutJob * max(1, len(keys)))()
         prefix, first, offs = [0], [0], [0]
         cur = 0
-        for j, (widx, (w, C, O, F, Ctot, c0)) in enumerate(keys):
+        for j, (widx, (w, C, O, F, Ctot, c0), cols) in enumerate(keys):
             bi = self.bucket_order.index(self._bucket_of[id(w)])
             while cur < bi:
                 first.append(j)
@@ -327,7 +373,7 @@ class TrainPlan(ForwardPlan):
             a = arr[j]
             a.W = self.gflat.data_ptr() + 4 * self._goff[id(w)]
             a.base, a.sr, a.sq, a.sf = c0 * F, F, Ctot * F, 1
-            a.R, a.Q, a.F, a.mirror, a.ldw = C, O, F, 0, ops.round_up(O, 4)
+            a.R, a.Q, a.F, a.mirror, a.ldw = C, O, F, (2 if cols else 0), self._gimg_off[widx][2]
             prefix.append(prefix[-1] + self._gimg_off[widx][1] * self._gimg_off[widx][2])
         nb = len(self.bucket_order)
         while len(first) < nb + 1:

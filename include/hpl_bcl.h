@@ -109,6 +109,23 @@ int hpl_splat_add(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr,
 int hpl_slice_add(const float *Y, int64_t ldy, int C, const float *bary, const int32_t *off, int64_t N,
                   const float *vscale, const float *bias, float *out, int64_t ldo, hplStream stream);
 
+/* Patch correlation from per-tap projections.  The pc2 half of the Conv3d((1,15,1)) of models/bnn_flow.py:195-202 gathers the
+ * same pc2 vertex row for up to 225 (filter tap, correlation tap) pairs and multiplies each copy by W_k; projecting every pc2
+ * vertex ONCE per correlation tap, Z[v, k*N + n] = sum_c f2[v, c] * W[n, c, k] (a small dense GEMM), leaves
+ *   Y[m, n] = act(bias[n] + res[(m % res_mod) * ldres + n] + sum_{k<K} Z[nbr[k][m] * ldz + k*col_step + n])    (nbr < 0: nothing)
+ * with col_step = N -- a gather of N-float rows instead of C-float rows and no 8.7-GFLOP contraction (N = 32, C = 64,
+ * M = 15 * H1).  N % 4 == 0, K <= 15, 16-byte aligned rows; taps are added in ascending k (deterministic).
+ * Its gradient w.r.t. Z is the same kernel through the INVERSE table (hpl_table_invert) with col_step = 0:
+ * dZ[(v*K + k)*N + n] = sum_f G[inv[f][v*K + k] * ldg + n] -- no atomics. */
+int hpl_gather_sum(const float *Z, int64_t ldz, const int32_t *nbr, int64_t nbr_stride, int64_t M, int K, int N, int col_step,
+                   const float *bias, const float *res, int64_t ldres, int64_t res_mod, int act, float slope, float *Y,
+                   int64_t ldy, hplStream stream);
+/* T [K][stride >= F*H0] with values in [0, H1) or -1 whose F blocks of H0 columns are injective (the permuted pc2_corr_indices:
+ * for a fixed (filter tap f, correlation tap k) the map h -> T2(key1_h + offset) is one to one -- also under the reference's
+ * unchecked key packing, which is linear in the key) -> inv int32 [F][K*H1]: inv[f][v*K + k] = f*H0 + h where
+ * T[k][f*H0 + h] = v, else -1. */
+int hpl_table_invert(const int32_t *T, int64_t stride, int K, int64_t H0, int F, int64_t H1, int32_t *inv, hplStream stream);
+
 /* ------------------------------------------------------------------------ *
  * Per-vertex dense contraction: gather-GEMM on fp32 MFMA
  * ------------------------------------------------------------------------ */
@@ -420,6 +437,7 @@ int hpl_lattice_next_points(const int32_t *vkeys, int64_t vstride, int64_t H, fl
 #define HPL_SYM_FH0 3         /* 15 * H0: virtual vertices of the patch correlation */
 #define HPL_SYM_IN0 4         /* input points of cloud 1 at level L (N0, or H0 of level L-1) */
 #define HPL_SYM_INP 5         /* input points of both clouds */
+#define HPL_SYM_FH1 6         /* 15 * H1: rows of the inverse pc2 correlation table per tap */
 #define HPL_MAX_LEVELS 8
 
 #define HPL_OP_GCONV 1        /* hpl_gconv_forward (incl. tap-group passes) */
@@ -442,10 +460,14 @@ int hpl_lattice_next_points(const int32_t *vkeys, int64_t vstride, int64_t H, fl
 #define HPL_OP_EPE3D 13       /* hpl_epe3d on the run's flow / sf / loss; out = gradient [N0][3] */
 #define HPL_OP_VCOPY 14       /* bias vector `bias` = bias vector `weight` (N entries): a gradient shared by two parameters */
 #define HPL_OP_UNLAYOUT 15    /* hpl_weight_unlayout_batch of bucket `aux` (hpl_plan_set_unlayout) */
+#define HPL_OP_GSUM 16        /* hpl_gather_sum: a = Z, out [m_sym][N], F = taps, table HPL_TBL_CORR2 (forward, col_step = N) or, with
+                                 HPL_FLAG_INVERSE, through the inverse table held (as int32) by buffer b (col_step = 0, out = dense rows of N) */
+#define HPL_OP_INVERT 17      /* hpl_table_invert of the level's corr2 table into buffer `out` (as int32 [15][15*H1]) */
 
 #define HPL_FLAG_ACCUM 1      /* the op adds to what `out` holds (gconv: first pass with res = out) */
 #define HPL_FLAG_SCATTER 2    /* gconv: scatter epilogue through the level's corr2 table, aux = channels per tap (scat_c) */
 #define HPL_FLAG_TAPS 4       /* wgrad: sum over the per-tap vertex lists of the level's cloud-1 blur table (when the run has them) */
+#define HPL_FLAG_INVERSE 16   /* HPL_OP_GSUM: see there */
 #define HPL_FLAG_SIDE 8       /* the op is a leaf of the backward graph: it may run on the side stream of hpl_plan_run_range */
 
 #define HPL_TBL_NONE 0
