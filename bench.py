@@ -313,9 +313,15 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
     model = getattr(H, arch)(targs)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(dev).train()
-    ops.enable_weight_bank(True)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    reducer = parallel.GradAllReducer(model.parameters())
+    native = os.environ.get('HPL_NATIVE_TRAIN', '1') != '0'          # one native program per step (train_plan.TrainPlan); 0: autograd
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    if native:
+        from hplflownet_amd.train_plan import TrainPlan
+        reducer = parallel.GradAllReducer(model.parameters(), overlap=False)
+        tplan = TrainPlan(model, reducer=reducer)
+    else:
+        ops.enable_weight_bank(True)
+        reducer = parallel.GradAllReducer(model.parameters())
     loss = None
     from hplflownet_amd.lattice import LatticePipeline
     side = torch.cuda.Stream(device=dev, priority=-1)
@@ -333,12 +339,21 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
         (i, _), lat, ev = pipe.get()
         main.wait_event(ev)
         p1, p2 = pairs[i % len(pairs)]
-        flow = model(p1[None], p2[None], lat)                     # (refreshes the weight bank: one batched re-layout per step)
-        ls = torch.norm(flow - sfs[i % len(pairs)][None], p=2, dim=1).mean()
-        opt.zero_grad(set_to_none=True)
-        ls.backward()
-        reducer()
-        opt.step()
+        r = tplan.step(p1, p2, sfs[i % len(pairs)], lat) if native else None
+        if r is not None:
+            tplan.finish()
+            opt.step()
+            ls = r[1]
+        else:
+            if native:
+                tplan.gflat.zero_()
+            flow = model(p1[None], p2[None], lat)                 # (refreshes the weight bank: one batched re-layout per step)
+            ls = torch.norm(flow - sfs[i % len(pairs)][None], p=2, dim=1).mean()
+            if not native:
+                opt.zero_grad(set_to_none=True)
+            ls.backward()
+            reducer()
+            opt.step()
         fin = torch.cuda.Event()
         fin.record(main)
         keep.append((lat, fin))                # side-stream allocations stay alive until the step that used them has RUN
@@ -355,12 +370,16 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
             loss = one()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / steps
-        out = {'ms_per_step': ms, 'steps': steps, 'warmup': warmup, 'pairs_per_s': 1e3 / ms, 'loss_last_step': float(loss.detach()),
+        out = {'ms_per_step': ms, 'steps': steps, 'warmup': warmup, 'pairs_per_s': 1e3 / ms, 'loss_last_step': float(loss.detach().reshape(-1)[0]),
+               'issue': ('one native program per step (train_plan.TrainPlan: %d forward + %d backward ops, weight gradients on a side '
+                         'stream)' % (tplan.n_fwd, len(tplan.prog.ops) - tplan.n_fwd)) if native else 'python autograd, launch by launch',
                'step': 'device lattice build (second stream, next pair) + forward + EPE3D loss + backward + gradient all-reduce '
                        '(world size 1 here) + Adam, one pair per GPU (BASELINE config 4)'}
     except Exception as e_:
         out = {'failed': str(e_)}
     ops.enable_weight_bank(False)
+    if native:
+        del tplan
     del model, opt, reducer
     torch.cuda.empty_cache()
     return out
@@ -560,17 +579,32 @@ def main():
         # BASELINE config 4: one pair per GPU, identical weights, mean loss over ranks ==
         # all-reduce(mean) of the gradients (77.2 MB fp32 over xGMI), Adam lr 1e-4 (main.py:138-140)
         model.train()
-        ops.enable_weight_bank(not os.environ.get('HPL_NO_BANK'))     # one batched weight re-layout per step
+        native_train = os.environ.get('HPL_NATIVE_TRAIN', '1') != '0'
         parallel.broadcast_parameters(model)
-        reducer = parallel.GradAllReducer(model.parameters())
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
         sfs = [torch.from_numpy(sf.T.copy()).to(dev) for _, _, sf in pairs_np]
+        if native_train:
+            # forward + loss + backward as ONE native program per step; gradients in a flat arena the bucketed all-reduce runs on
+            from hplflownet_amd.train_plan import TrainPlan
+            reducer = parallel.GradAllReducer(model.parameters(), overlap=False)
+            tplan = TrainPlan(model, reducer=reducer)
+        else:
+            ops.enable_weight_bank(not os.environ.get('HPL_NO_BANK'))     # one batched weight re-layout per step
+            reducer = parallel.GradAllReducer(model.parameters())
 
         def compute(i, lat):
             p1, p2 = pairs[i % a.pool]
+            r = tplan.step(p1, p2, sfs[i % a.pool], lat) if native_train else None
+            if r is not None:
+                tplan.finish()
+                opt.step()
+                return r[0]
+            if native_train:
+                tplan.gflat.zero_()
             flow = model(p1[None], p2[None], lat)
             loss = torch.norm(flow - sfs[i % a.pool][None], p=2, dim=1).mean()      # EPE3DLoss, main.py:213
-            opt.zero_grad(set_to_none=True)
+            if not native_train:
+                opt.zero_grad(set_to_none=True)
             loss.backward()
             reducer()
             opt.step()

@@ -8,6 +8,7 @@
 #include "common.h"
 #include <stdlib.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -16,7 +17,7 @@ using namespace hpl;
 namespace {
 
 constexpr int64_t SPLITK_ELEMS = 8 << 20;          // ops.py: split-K only for outputs of <= 8 M elements
-constexpr int64_t SPLITK_WS_BYTES = 256ll << 20;   // 64 M floats of partial tiles (the launch fits its split count)
+constexpr int64_t SPLITK_WS_BYTES = 64ll << 20;    // 16 M floats of partial tiles (a launch fits its split count to it)
 constexpr int MAX_SYMS = HPL_SYM_LEVEL0 + 8 * HPL_MAX_LEVELS;
 
 __global__ void k_copy_cols(const float *__restrict__ src, int64_t lds, float *__restrict__ dst, int64_t ldd,
@@ -96,6 +97,9 @@ struct hpl_plan {
     std::vector<int64_t> ul_offset;
     std::vector<hipEvent_t> fence;
     size_t fence_used = 0;
+    // workspace layout of the last run (a function of the plan and the row-count symbols): byte offset of every buffer
+    std::vector<int64_t> lay_sym, lay_off;
+    int64_t lay_total = 0;
 };
 
 namespace {
@@ -188,6 +192,7 @@ struct Runner {
                         r.col_off + r.cols <= pl.bufs[r.buf].cols,
                     "hpl_plan_run: %s outside buffer %d (%lld x %d): rows %lld + %lld, columns %d + %d", what, r.buf,
                     (long long)pl.rows[r.buf], pl.bufs[r.buf].cols, (long long)off, (long long)v.rows, r.col_off, r.cols);
+        HPL_REQUIRE(pl.base[r.buf], "hpl_plan_run: %s refers to buffer %d, which no active op of the program uses", what, r.buf);
         v.ld = pl.bufs[r.buf].cols;
         v.p = pl.base[r.buf] + off * v.ld + r.col_off;
         v.cols = r.cols;
@@ -592,12 +597,67 @@ extern "C" void hpl_plan_destroy(hpl_plan *plan) {
     delete plan;
 }
 
+namespace {
+// Workspace layout.  A matrix lives from the first op that touches it to the last one that does (ops whose per-pair condition is
+// false do not count; what a side-stream op reads stays until the end of the program; the hoisted el_minus_gr copies run first).
+// Matrices whose lives do not overlap share memory: lowest-offset first fit in order of first use.  Inference needs the live set
+// of its widest layer (~0.35 GB at N = 8 192 instead of the 1.05 GB of all matrices), a training step every forward matrix plus the
+// short-lived gradient matrices.  The split-K scratch sits in front (fixed offset).  Cached per set of row counts.
+int64_t plan_layout(hpl_plan &pl, const hpl_level_tables *lv, int n_levels, const int64_t *sym) {
+    if (pl.lay_sym.size() == (size_t)MAX_SYMS && std::equal(pl.lay_sym.begin(), pl.lay_sym.end(), sym)) return pl.lay_total;
+    const int nb = (int)pl.bufs.size(), nops = (int)pl.ops.size();
+    std::vector<int> first(nb, nops + 1), last(nb, -1);
+    auto touch = [&](const hpl_ref &r, int at, bool to_end) {
+        if (r.buf < 0 || r.buf >= nb) return;
+        first[r.buf] = std::min(first[r.buf], at);
+        last[r.buf] = std::max(last[r.buf], to_end ? nops : at);
+    };
+    for (int i = 0; i < nops; ++i) {
+        const hpl_op &op = pl.ops[i];
+        if (op.cond != HPL_COND_ALWAYS) {
+            if (op.cond_level < 0 || op.cond_level >= n_levels) continue;
+            const bool shrink = lv[op.cond_level].n0 < lv[op.cond_level].H0;
+            if ((op.cond == HPL_COND_SHRINK) != shrink) continue;
+        }
+        const bool emg = op.kind == HPL_OP_COPY && op.a.buf == -1 && pl.hoist_emg;
+        const bool side = (op.flags & HPL_FLAG_SIDE) != 0;
+        const int at = emg ? 0 : i;
+        touch(op.a, at, side); touch(op.b, at, side); touch(op.res, at, side);
+        touch(op.out, at, false); touch(op.out2, at, false); touch(op.post_mid, at, false);
+    }
+    std::vector<int> order;
+    for (int b = 0; b < nb; ++b) if (last[b] >= 0) order.push_back(b);
+    std::vector<int64_t> size(nb, 0);
+    for (int b : order) size[b] = buf_bytes(sym[pl.bufs[b].rows_sym], pl.bufs[b].cols);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return first[x] != first[y] ? first[x] < first[y] : size[x] > size[y]; });
+    pl.lay_off.assign(nb, -1);
+    int64_t total = SPLITK_WS_BYTES;
+    std::vector<std::pair<int64_t, int64_t>> busy;          // (offset, end) of placed matrices alive together with the candidate
+    std::vector<int> placed;
+    for (int b : order) {
+        busy.clear();
+        for (int q : placed)
+            if (first[q] <= last[b] && first[b] <= last[q] && size[q] > 0) busy.emplace_back(pl.lay_off[q], pl.lay_off[q] + size[q]);
+        std::sort(busy.begin(), busy.end());
+        int64_t at = SPLITK_WS_BYTES;
+        for (const auto &iv : busy) {
+            if (iv.first - at >= size[b]) break;
+            at = std::max(at, iv.second);
+        }
+        pl.lay_off[b] = at;
+        total = std::max(total, at + size[b]);
+        placed.push_back(b);
+    }
+    pl.lay_sym.assign(sym, sym + MAX_SYMS);
+    pl.lay_total = total + 256;
+    return pl.lay_total;
+}
+}  // namespace
+
 extern "C" int64_t hpl_plan_workspace_bytes(const hpl_plan *plan, const hpl_level_tables *levels, int n_levels) {
     int64_t sym[MAX_SYMS];
     if (!plan || resolve_syms(levels, n_levels, sym) != HPL_OK) return -1;
-    int64_t total = SPLITK_WS_BYTES + 256;
-    for (const hpl_buf &b : plan->bufs) total += buf_bytes(sym[b.rows_sym], b.cols);
-    return total;
+    return plan_layout(*const_cast<hpl_plan *>(plan), levels, n_levels, sym);
 }
 
 extern "C" int hpl_plan_run(hpl_plan *plan, const hpl_level_tables *levels, int n_levels, const float *pc1,
@@ -628,17 +688,16 @@ extern "C" int hpl_plan_run_range(hpl_plan *plan, const hpl_level_tables *levels
     // carve the activation matrices and the split-K scratch out of the workspace
     char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
     char *const end = reinterpret_cast<char *>(workspace) + workspace_bytes;
+    const int64_t need = plan_layout(*plan, levels, n_levels, sym);
+    HPL_REQUIRE(w + need - 256 <= end, "hpl_plan_run: workspace of %lld bytes is too small (hpl_plan_workspace_bytes: %lld)",
+                (long long)workspace_bytes, (long long)need);
     plan->base.resize(plan->bufs.size());
     plan->rows.resize(plan->bufs.size());
     for (size_t i = 0; i < plan->bufs.size(); ++i) {
         plan->rows[i] = sym[plan->bufs[i].rows_sym];
-        plan->base[i] = reinterpret_cast<float *>(w);
-        w += buf_bytes(plan->rows[i], plan->bufs[i].cols);
+        plan->base[i] = plan->lay_off[i] >= 0 ? reinterpret_cast<float *>(w + plan->lay_off[i]) : nullptr;
     }
     float *splitk = reinterpret_cast<float *>(w);
-    w += SPLITK_WS_BYTES;
-    HPL_REQUIRE(w <= end, "hpl_plan_run: workspace of %lld bytes is too small (hpl_plan_workspace_bytes: %lld)",
-                (long long)workspace_bytes, (long long)hpl_plan_workspace_bytes(plan, levels, n_levels));
     Runner r{*plan, levels, n_levels, sym, {pc1, pc2}, out, splitk, to_stream(stream), stream};
     r.sf = sf; r.loss = loss;
     r.main_s = to_stream(stream);

@@ -128,7 +128,9 @@ class Trainer(object):
         self.gen = GenerateDataUnsymmetric(self.args, device=self.device, wide_up=self.model.lattice_hint())
         if self.device.type == 'cuda':
             ops.enable_weight_bank()          # one batched weight re-layout per training step
-        self.opt = torch.optim.Adam([p for p in self.model.parameters() if p.requires_grad], lr=lr, weight_decay=0)
+        # (fused: the same update, two launches instead of sixteen)
+        self.opt = torch.optim.Adam([p for p in self.model.parameters() if p.requires_grad], lr=lr, weight_decay=0,
+                                    fused=self.device.type == 'cuda')
         self.reducer = None
         if distributed:
             parallel.broadcast_parameters(self.model)

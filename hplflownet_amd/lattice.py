@@ -277,7 +277,14 @@ class LatticePipeline(object):
             self._thread = None
 
     def _top_up(self):
-        while len(self._inflight) < self.depth and self._next < self._end:
+        depth = self.depth
+        if self.native:
+            nb = self.gen.native_builder()
+            if nb.fused and not any(nb.seen):
+                # no pair observed yet: every level is bounded at 16 x the cloud size (~1 GB of arena per build at N = 8 192).
+                # The first build runs alone; its counts tighten the bounds (~0.26 GB) before further pairs are enqueued.
+                depth = 1
+        while len(self._inflight) < depth and self._next < self._end:
             st = self.streams[self._next % len(self.streams)]
             with torch.cuda.stream(st):                 # a reader's host-to-device copies belong to this stream too
                 item = self.source(self._next)
@@ -593,7 +600,10 @@ class NativeLatticeBuild(object):
                     self.nb.lib.hpl_lattice_stats(self.handle, st)
                     self.nb.launches = int(st[0])
                     self.nb.fallbacks += 0 if st[1] else 1
+                    first = not any(self.nb.seen)
                     self.nb.observe([(int(arr[L].H0), int(arr[L].H1)) for L in range(n)])
+                    if first:
+                        torch.cuda.empty_cache()       # (the loose first arena's block would otherwise stay reserved beside the tight ones)
                 self.nb.release(self.handle)
                 self.handle = None
                 lat = NativeLattice(self.arena, arr, n, [int(e or 0) for e in extras], self.gen.wide_up)

@@ -376,11 +376,12 @@ _NO_SPLITK = bool(os.environ.get('HPL_NO_SPLITK'))      # A/B switch for benchma
 
 
 def _splitk_workspace(device, st):
-    """Per-(device, stream) scratch for split-K partial tiles: 64 M floats = 256 MB (csrc/executor.hip: same)."""
+    """Per-(device, stream) scratch for split-K partial tiles: 16 M floats = 64 MB (csrc/executor.hip: same size, so that both
+    issue paths pick the same split counts: a launch fits its splits to the scratch)."""
     key = (device, st)
     ws = _SPLITK_WS.get(key)
     if ws is None:
-        ws = _SPLITK_WS[key] = torch.empty(64 << 20, dtype=torch.float32, device=device)
+        ws = _SPLITK_WS[key] = torch.empty(16 << 20, dtype=torch.float32, device=device)
     return ws
 
 

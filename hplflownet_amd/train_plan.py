@@ -443,7 +443,11 @@ class TrainPlan(ForwardPlan):
             raise _lib.HplError('hpl_plan_workspace_bytes: %s' % self._lib.hpl_last_error().decode())
         ws = self._ws.get('train')
         if ws is None or ws.numel() < need:
-            ws = self._ws['train'] = torch.empty(int(need * 1.1), dtype=torch.uint8, device=p1.device)
+            # (pairs differ in their vertex counts: head room, so that the ~1.5 GB block is not re-allocated every few steps -- a
+            # hipFree + hipMalloc of that size stalls the step for tens of milliseconds)
+            self._ws.pop('train', None)
+            del ws
+            ws = self._ws['train'] = torch.empty(int(need * 1.3), dtype=torch.uint8, device=p1.device)
         self.refresh_weights()
         self.gflat.zero_()
         self.gimg.zero_()
