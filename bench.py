@@ -331,12 +331,18 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
     # the native (fused) builder on a producer thread: the tables of the training path (tap lists, symmetry verdicts) are added
     # there too, off the thread that issues the ~900 launches of the step
     nat = not os.environ.get('HPL_TRAIN_PY_LATTICE')
-    pipe = LatticePipeline(gen, lambda i: pairs[i % len(pairs)], 0, warmup + steps, depth=2, stream=side, for_training=True,
+    pipe = LatticePipeline(gen, lambda i: pairs[i % len(pairs)], 0, warmup + steps * (2 if os.environ.get('HPL_TRAIN_PROBE_TRACE') else 1), depth=2, stream=side, for_training=True,
                            native=nat, threaded=nat)
     keep = []
 
+    trace = bool(os.environ.get('HPL_TRAIN_PROBE_TRACE'))
+
     def one():
+        t_a = time.perf_counter()
         (i, _), lat, ev = pipe.get()
+        if trace:
+            ev.synchronize()
+            print('   lattice wait %.2f ms' % ((time.perf_counter() - t_a) * 1e3), file=sys.stderr)
         main.wait_event(ev)
         p1, p2 = pairs[i % len(pairs)]
         r = tplan.step(p1, p2, sfs[i % len(pairs)], lat) if native else None
@@ -365,6 +371,12 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
         for _ in range(warmup):
             one()
         torch.cuda.synchronize()
+        if os.environ.get('HPL_TRAIN_PROBE_TRACE'):          # diagnostic: every step on its own (synchronised), to stderr
+            for k in range(steps):
+                t1 = time.perf_counter()
+                one()
+                torch.cuda.synchronize()
+                print('train probe step %d: %.2f ms' % (k, (time.perf_counter() - t1) * 1e3), file=sys.stderr)
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = one()

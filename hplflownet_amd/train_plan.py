@@ -307,7 +307,15 @@ class TrainPlan(ForwardPlan):
             self.bucket_range.append((o0, o))
         self.reducer.adopt_flat(self.gflat, self.bucket_range)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._side = torch.cuda.Stream(device=dev) if side_stream else None
+        # The side stream is a HIGH-priority stream: HIP maps the normal-priority streams of a process round robin onto 4 hardware
+        # queues, and a process that has made a few (bench.py: three forward streams) gets a side stream that SHARES the queue of
+        # the stream the step runs on -- every fence then drains that queue (measured inside bench.py: 22.9 ms per step instead of
+        # 13.0; with GPU_MAX_HW_QUEUES=8: 13.2).  High-priority streams have queues of their own.  side_stream may also be a
+        # torch.cuda.Stream of the caller's choosing, or False / None for none.
+        if isinstance(side_stream, torch.cuda.Stream):
+            self._side = side_stream
+        else:
+            self._side = torch.cuda.Stream(device=dev, priority=-1) if side_stream else None
         super(TrainPlan, self).__init__(model)
         self._finish_unlayout()
 
