@@ -37,8 +37,7 @@ class GConvDesc(ctypes.Structure):
                 ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('w_rows', c_i32),
                 ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64),
                 ('tile_idx', c_vp), ('tile_mask', c_vp), ('tile_bm', c_i32), ('clock_probe', c_vp),
-                ('Y2', c_vp), ('ldy2', c_i64), ('rows2', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64),
-                ('post_Wt', c_vp), ('post_ldw', c_i64), ('post_bias', c_vp), ('post_N', c_i32), ('post_act', c_i32)]
+                ('Y2', c_vp), ('ldy2', c_i64), ('rows2', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64)]
 
 
 class Ref(ctypes.Structure):
@@ -62,8 +61,7 @@ class Op(ctypes.Structure):
                 ('res_mod_sym', c_i32), ('level', c_i32), ('table', c_i32), ('order', c_i32), ('F', c_i32), ('C', c_i32),
                 ('N', c_i32), ('weight', c_i32), ('bias', c_i32), ('act', c_i32), ('slope', c_f32), ('use_norm', c_i32),
                 ('reg_stride_sym', c_i32), ('ext', c_i32), ('cond', c_i32), ('cond_level', c_i32), ('out2', Ref),
-                ('rows2_sym', c_i32), ('post_weight', c_i32), ('post_bias', c_i32), ('post_N', c_i32), ('post_act', c_i32), ('post_mid', Ref),
-                ('b', Ref), ('flags', c_i32), ('aux', c_i32)]
+                ('rows2_sym', c_i32), ('b', Ref), ('flags', c_i32), ('aux', c_i32)]
 
 
 class LevelTables(ctypes.Structure):

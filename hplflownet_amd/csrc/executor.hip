@@ -225,7 +225,7 @@ struct Runner {
         if (has_out2) {
             if ((rc = view(op.out2, Y2, "gconv second output"))) return rc;
             rows2 = symv(sym, op.rows2_sym);
-            HPL_REQUIRE(Y2.cols >= (op.post_weight >= 0 ? op.post_N : op.N) && rows2 >= 0 && rows2 <= Y2.rows, "hpl_plan_run: second output (%lld rows of %lld, N=%d of %d)",
+            HPL_REQUIRE(Y2.cols >= op.N && rows2 >= 0 && rows2 <= Y2.rows, "hpl_plan_run: second output (%lld rows of %lld, N=%d of %d)",
                         (long long)rows2, (long long)Y2.rows, op.N, Y2.cols);
         }
         HPL_REQUIRE(op.weight >= 0 && op.weight < (int)pl.weights.size(), "hpl_plan_run: weight image %d", op.weight);
@@ -260,22 +260,10 @@ struct Runner {
         HPL_REQUIRE(op.table != HPL_TBL_REGULAR || (reg > 0 && (op.F - 1) * reg + M <= A.rows),
                     "hpl_plan_run: regular stride %lld x %d taps outside the %lld input rows", (long long)reg, op.F,
                     (long long)A.rows);
-        // conv + trailing 1x1 conv: one launch where launches are what costs (few rows), two where the separate dense GEMM is
-        // the faster second half (measured end to end: fusing every narrow pair of the N=8192 model loses 2.5 %)
-        static const int64_t fuse_max_rows = getenv("HPL_FUSE_MAX_ROWS") ? atoll(getenv("HPL_FUSE_MAX_ROWS")) : 8192;
-        const bool paired = op.post_weight >= 0;
-        const bool fused = paired && M <= fuse_max_rows;
-        View Mid = {};
-        if (paired && !fused) {
-            if ((rc = view(op.post_mid, Mid, "gconv intermediate"))) return rc;
-            HPL_REQUIRE(Mid.cols >= op.N && Mid.rows >= M, "hpl_plan_run: intermediate of a conv pair too small");
-        }
-        HPL_REQUIRE(!paired || (op.post_weight < (int)pl.weights.size() && op.post_bias < (int)pl.biases.size() && op.post_N > 0),
-                    "hpl_plan_run: fused trailing conv refers to weight %d / bias %d", op.post_weight, op.post_bias);
         const bool accum = (op.flags & HPL_FLAG_ACCUM) != 0, scatter = (op.flags & HPL_FLAG_SCATTER) != 0;
-        HPL_REQUIRE(!(accum && has_res) && !(scatter && (paired || has_out2 || ngroups >= 2 || !t.corr2 || op.aux <= 0 || op.N % op.aux)),
+        HPL_REQUIRE(!(accum && has_res) && !(scatter && (has_out2 || ngroups >= 2 || !t.corr2 || op.aux <= 0 || op.N % op.aux)),
                     "hpl_plan_run: accumulate / scatter flags on an op they do not fit");
-        HPL_REQUIRE(A.cols >= op.C && (scatter || (Y.cols >= (paired ? op.post_N : op.N) && Y.rows >= M)), "hpl_plan_run: gconv shapes (C=%d of %d, N=%d of %d)",
+        HPL_REQUIRE(A.cols >= op.C && (scatter || (Y.cols >= op.N && Y.rows >= M)), "hpl_plan_run: gconv shapes (C=%d of %d, N=%d of %d)",
                     op.C, A.cols, op.N, Y.cols);
         HPL_REQUIRE(!scatter || (Y.cols >= op.aux && Y.rows >= t.H1), "hpl_plan_run: scatter target too small");
         const bool prof = pl.profile_tag >= 0 && op.tag == pl.profile_tag;
@@ -304,14 +292,7 @@ struct Runner {
                 d.res = Y.p; d.ldres = Y.ld; d.res_mod = M;
             }
             d.Y = Y.p; d.ldy = Y.ld;
-            if (paired && !fused) { d.Y = Mid.p; d.ldy = Mid.ld; }
-            else
             if (last && has_out2) { d.Y2 = Y2.p; d.ldy2 = Y2.ld; d.rows2 = rows2; }
-            if (fused) {            // (single-pass ops only: plan.py fuses narrow layers, which never run as tap groups)
-                const hpl_weight &w2 = pl.weights[op.post_weight];
-                d.post_Wt = w2.Wt; d.post_ldw = w2.ldw; d.post_N = op.post_N; d.post_act = op.post_act;
-                d.post_bias = op.post_bias >= 0 ? pl.biases[op.post_bias] : nullptr;
-            }
             d.row_perm = row_perm;
             if (row_perm && ti && tm) { d.tile_idx = ti; d.tile_mask = tm; d.tile_bm = ngroups >= 2 ? t.group_tile_bm : t.tile_bm; }
             // split-operand image of the same rows (csrc/gconv3.hip takes the launch if it qualifies): k-blocks of 8 rows
@@ -328,7 +309,6 @@ struct Runner {
             bracket(prof, true);
             return r;
         };
-        HPL_REQUIRE(!paired || (ngroups < 2 && op.F <= 15), "hpl_plan_run: a conv pair on a multi-pass op");
         if (ngroups >= 2) {
             for (int g = 0; g < ngroups; ++g) {
                 rc = pass(t.up_group_cut[g], t.up_group_cut[g + 1] - t.up_group_cut[g], t.up_group_perm[g], g == 0,
@@ -344,21 +324,7 @@ struct Runner {
             }
             return HPL_OK;
         }
-        rc = pass(0, op.F, perm, true, true, tidx, tmask);
-        if (rc || !paired || fused) return rc;
-        // second half of an unfused pair: the plain 1x1 conv on the intermediate matrix
-        const hpl_weight &w2 = pl.weights[op.post_weight];
-        hpl_gconv_desc d = {};
-        d.A = Mid.p; d.lda = Mid.ld; d.rows_a = Mid.rows;
-        d.M = M; d.C = op.N; d.F = 1;
-        d.Wt = w2.Wt; d.ldw = w2.ldw; d.N = op.post_N;
-        d.w_rows = (int32_t)imin(w2.rows, cdiv((int64_t)op.N, 32) * 32);
-        d.act = op.post_act; d.slope = op.slope;
-        d.bias = op.post_bias >= 0 ? pl.biases[op.post_bias] : nullptr;
-        d.Y = Y.p; d.ldy = Y.ld;
-        if (has_out2) { d.Y2 = Y2.p; d.ldy2 = Y2.ld; d.rows2 = rows2; }
-        if (M * op.post_N <= SPLITK_ELEMS) { d.ws = splitk; d.ws_bytes = SPLITK_WS_BYTES; }
-        return hpl_gconv_forward(&d, hs);
+        return pass(0, op.F, perm, true, true, tidx, tmask);
     }
 
     int run_op(const hpl_op &op) {
@@ -623,7 +589,7 @@ int64_t plan_layout(hpl_plan &pl, const hpl_level_tables *lv, int n_levels, cons
         const bool side = (op.flags & HPL_FLAG_SIDE) != 0;
         const int at = emg ? 0 : i;
         touch(op.a, at, side); touch(op.b, at, side); touch(op.res, at, side);
-        touch(op.out, at, false); touch(op.out2, at, false); touch(op.post_mid, at, false);
+        touch(op.out, at, false); touch(op.out2, at, false);
     }
     std::vector<int> order;
     for (int b = 0; b < nb; ++b) if (last[b] >= 0) order.push_back(b);

@@ -470,80 +470,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
 #ifdef HPL_TIMING
     HPL_T(5, parked);
 #endif
-    // ---- fused trailing 1x1 conv (narrow layers: the one column tile of this workgroup holds whole rows): the activated
-    // tile goes to LDS [BM][N + 1] (the operand rings are free now), a second MFMA pass contracts it with post_Wt --
-    // the same k-ordered fma chain per output element as a separate launch of this kernel would run (bit-identical),
-    // without the launch and without the round trip of the intermediate matrix through HBM.
-    if constexpr (!COMPACT && BN <= 64) {
-        if (p.post_Wt && p.splits <= 1) {
-            static_assert(BM * (BN + 1) <= 2 * BK * LDA_S + 2 * BK * LDB_S, "the activated tile must fit the operand rings");
-            float *T = smem;
-            const int ldT = p.N + 1;
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = wn * WTN + j * 32 + li;
-                    if (n >= p.N) continue;
-                    const float bsv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const int64_t m = Vs[row];
-                        float v = 0.f;
-                        if (m >= 0) {
-                            v = acc[i][j][r] + bsv;
-                            if (p.res) v += p.res[(m % p.res_mod) * p.ldres + n];
-                            if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
-                        }
-                        T[row * ldT + n] = v;
-                    }
-                }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            const float *ta = T + (wm * WTM + li) * ldT + hi;
-            int ncol[TN];
-            bool nok[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) { ncol[j] = wn * WTN + j * 32 + li; nok[j] = ncol[j] < p.post_N; }
-#pragma unroll 4
-            for (int kk = 0; kk < p.N; kk += 2) {
-                float a2[TM], b2[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a2[i] = ta[i * 32 * ldT + kk];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b2[j] = nok[j] ? p.post_Wt[(int64_t)(kk + hi) * p.post_ldw + ncol[j]] : 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i], b2[j], acc[i][j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (!nok[j]) continue;
-                    const int n = ncol[j];
-                    const float bsv = p.post_bias ? p.post_bias[n] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t m = Vs[wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
-                        if (m < 0) continue;
-                        float v = acc[i][j][r] + bsv;
-                        if (p.post_act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
-                        p.Y[m * p.ldy + n] = v;
-                        if (p.Y2 && m < p.rows2) p.Y2[m * p.ldy2 + n] = v;
-                    }
-                }
-            return;
-        }
-    }
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // Fast form (gconv3.hip's: every operand below 2 GB, residual not wrapped, no scatter): output rows by 16-byte LDS reads,
     // 32-bit byte offsets, out-of-range offsets instead of branches, the residual loads of a block before its stores.  The
@@ -660,43 +586,6 @@ __global__ void k_gconv_finish(const GParams p) {
     }
 }
 
-// split-K epilogue with the fused trailing 1x1 conv: 8 rows per pass of a workgroup; the activated rows wait in LDS, every
-// output element is the k-ordered fmaf chain the MFMA pass of the unsplit kernel runs (bit-identical)
-__global__ void __launch_bounds__(256) k_gconv_finish_post(const GParams p) {
-    constexpr int ROWS = 8;
-    __shared__ float v_s[ROWS][65];
-    const int64_t total = p.M * p.N;
-    const int t = threadIdx.x;
-    for (int64_t row0 = (int64_t)blockIdx.x * ROWS; row0 < p.M; row0 += (int64_t)gridDim.x * ROWS) {
-        for (int idx = t; idx < ROWS * p.N; idx += 256) {
-            const int r = idx / p.N, n = idx - r * p.N;
-            const int64_t m = row0 + r;
-            float v = 0.f;
-            if (m < p.M) {
-                float acc = 0.f;
-                for (int sidx = 0; sidx < p.splits; ++sidx) acc += p.partial[(int64_t)sidx * total + m * p.N + n];
-                v = acc + (p.bias ? p.bias[n] : 0.f);
-                if (p.res) v += p.res[(m % p.res_mod) * p.ldres + n];
-                if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
-            }
-            v_s[r][n] = v;
-        }
-        __syncthreads();
-        for (int idx = t; idx < ROWS * p.post_N; idx += 256) {
-            const int r = idx / p.post_N, n = idx - r * p.post_N;
-            const int64_t m = row0 + r;
-            if (m >= p.M) continue;
-            float acc = 0.f;
-            for (int k = 0; k < p.N; ++k) acc = fmaf(v_s[r][k], p.post_Wt[(int64_t)k * p.post_ldw + n], acc);
-            float v = acc + (p.post_bias ? p.post_bias[n] : 0.f);
-            if (p.post_act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
-            p.Y[m * p.ldy + n] = v;
-            if (p.Y2 && m < p.rows2) p.Y2[m * p.ldy2 + n] = v;
-        }
-        __syncthreads();
-    }
-}
-
 // one thread per output element; sequential fmaf chain in k order (what one MFMA lane does)
 __global__ void k_gconv_naive(const GParams p) {
     const int64_t total = p.M * p.N;
@@ -743,7 +632,7 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     HPL_REQUIRE(d->nbr || d->F == 1 || d->reg_stride > 0, "%s: F > 1 needs a neighbour table or reg_stride", who);
     HPL_REQUIRE(!d->res || (d->res_mod > 0 && d->ldres >= d->N), "%s: bad residual description", who);
     HPL_REQUIRE(!d->scat || d->scat_c > 0, "%s: bad scatter description", who);
-    HPL_REQUIRE(d->scat || d->post_Wt || d->ldy >= d->N, "%s: ldy %lld < N %d", who, (long long)d->ldy, d->N);
+    HPL_REQUIRE(d->scat || d->ldy >= d->N, "%s: ldy %lld < N %d", who, (long long)d->ldy, d->N);
     HPL_REQUIRE(d->act == HPL_ACT_NONE || d->act == HPL_ACT_LEAKY, "%s: unknown activation %d", who, d->act);
     p.A = d->A; p.lda = d->lda; p.rows_a = d->rows_a;
     p.nbr = d->nbr; p.nbr_stride = d->nbr_stride; p.reg_stride = d->reg_stride;
@@ -752,7 +641,7 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.bias = d->bias; p.res = d->res; p.ldres = d->ldres; p.res_mod = d->res_mod;
     p.Y = d->Y; p.ldy = d->ldy;
     p.Y2 = d->Y2; p.ldy2 = d->ldy2; p.rows2 = d->Y2 ? d->rows2 : 0;
-    HPL_REQUIRE(!d->Y2 || (!d->scat && (d->post_Wt || d->ldy2 >= d->N) && d->rows2 >= 0), "%s: bad second destination", who);
+    HPL_REQUIRE(!d->Y2 || (!d->scat && d->ldy2 >= d->N && d->rows2 >= 0), "%s: bad second destination", who);
     p.scat = d->scat; p.scat_stride = d->scat_stride; p.scat_c = d->scat_c;
     p.row_perm = d->row_perm;
     p.tile_idx = (d->tile_idx && d->tile_mask && d->row_perm) ? d->tile_idx : nullptr;
@@ -766,14 +655,6 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     }
     p.ws = d->ws; p.ws_bytes = d->ws ? d->ws_bytes : 0; p.splits = 1; p.partial = nullptr;
     p.Wt3 = d->Wt3; p.w3_plane_stride = d->wt3_plane_stride;
-    p.post_Wt = d->post_Wt; p.post_ldw = d->post_ldw; p.post_N = d->post_N; p.post_bias = d->post_bias; p.post_act = d->post_act;
-    p.epi_fast = 0;
-    if (p.post_Wt) {
-        HPL_REQUIRE(!d->scat && d->N <= 64 && d->N % 2 == 0 && d->post_N >= 1 && d->post_N <= 64 && d->post_ldw >= d->post_N &&
-                        (d->post_act == HPL_ACT_NONE || d->post_act == HPL_ACT_LEAKY) && d->ldy >= d->post_N &&
-                        (!d->Y2 || d->ldy2 >= d->post_N),
-                    "%s: the fused trailing conv needs even N <= 64 and post_N <= 64 (N=%d post_N=%d), no scatter", who, d->N, d->post_N);
-    }
     p.col_share = 0; p.col_rows = 0;
     p.tiles_m = p.tiles_n = 0;
     p.a_bytes = ((d->rows_a - 1) * d->lda + d->C) * 4;
@@ -828,7 +709,7 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
     {   // the epilogue's 32-bit buffer addressing (see k_gconv): every destination / residual below 2 GB, rows below 2^24
         const int64_t lim = (int64_t)0x7fffffff;
         static const int epi = getenv("HPL_GCONV_EPILOGUE") ? atoi(getenv("HPL_GCONV_EPILOGUE")) : 1;
-        p.epi_fast = (epi && !p.scat && !p.post_Wt && p.M < (1 << 24) && p.M * (p.splits > 1 ? p.N : p.ldy) * 4 < lim && p.ldy * 4 < (1 << 24) &&
+        p.epi_fast = (epi && !p.scat && p.M < (1 << 24) && p.M * (p.splits > 1 ? p.N : p.ldy) * 4 < lim && p.ldy * 4 < (1 << 24) &&
                       (!p.res || (p.res_mod > 0 && p.res_mod < (1 << 24) && imin(p.res_mod, p.M) * p.ldres * 4 < lim && p.ldres * 4 < (1 << 24))) &&
                       (!p.Y2 || (p.rows2 * p.ldy2 * 4 < lim && p.ldy2 * 4 < (1 << 24)))) ? 1 : 0;
     }
@@ -886,12 +767,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     const int64_t t128 = cdiv(p.M, 128), t64 = cdiv(p.M, 64);
     // HPL_TILE=<name>: force one tile configuration (tools/bench_gconv.py sweeps them)
     static const char *force = getenv("HPL_TILE");
-    // a fused trailing conv (N, post_N <= 64) picks the tile by the wider of the two: one column tile covers both
-    const int nsel = p.post_Wt ? (p.N > p.post_N ? p.N : p.post_N) : p.N;
-    if (p.post_Wt && force && *force) {
-        set_error("hpl_gconv_forward: HPL_TILE cannot be combined with a fused trailing conv");
-        return HPL_EINVAL;
-    }
+    const int nsel = p.N;
     if (force && *force) {
         const std::string f(force);
         if (f == "128x128") launch_cfg<128, 128, 2, 4>(p, avec, s);
@@ -919,9 +795,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
         if (t128 >= 512) launch_cfg<128, 32, 4, 1>(p, avec, s);
         else launch_cfg<64, 32, 2, 1>(p, avec, s);
     }
-    if (p.splits > 1 && p.post_Wt) {
-        k_gconv_finish_post<<<(int)imin(cdiv(p.M, 8), 2048), 256, 0, s>>>(p);
-    } else if (p.splits > 1) {
+    if (p.splits > 1) {
         const int g = (int)imin(cdiv(p.M * p.N, 256), 2048);
         k_gconv_finish<<<g, 256, 0, s>>>(p);
     }
@@ -1023,7 +897,6 @@ extern "C" int hpl_gconv_forward_naive(const hpl_gconv_desc *d, hplStream stream
     GParams p;
     int rc = fill_params(d, p, "hpl_gconv_forward_naive");
     if (rc != HPL_OK) return rc;
-    HPL_REQUIRE(!d->post_Wt, "hpl_gconv_forward_naive: the reference kernel has no fused trailing conv (post_Wt)");
     if (p.M == 0) return HPL_OK;
     const int grid = (int)imin(cdiv(p.M * p.N, 256), 8192);
     k_gconv_naive<<<grid, 256, 0, to_stream(stream)>>>(p);

@@ -52,9 +52,6 @@ struct GParams {
     float *Y2; int64_t ldy2; int64_t rows2;   // optional second destination: rows < rows2 are also written to Y2
     float *ws; int64_t ws_bytes;
     const void *Wt3; int64_t w3_plane_stride;      // split weight image (hpl_weight_split3) or nullptr
-    // optional trailing 1x1 conv fused into the epilogue (N, post_N <= 64: one column tile holds a whole row):
-    // Y = act2(post_bias + act(bias + res + A*Wt) * post_Wt)
-    const float *post_Wt; int64_t post_ldw; int post_N; const float *post_bias; int post_act;
     int epi_fast;                       // 32-bit buffer addressing in the epilogue (set by the launch functions)
 };
 

@@ -291,14 +291,12 @@ def _mat(x, what):
 
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
               scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True, reg_stride=0, tiles=None,
-              out2=None, rows2=0, Wt3=None, post=None):
+              out2=None, rows2=0, Wt3=None):
     """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
     row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged.
     nbr None and reg_stride > 0: tap f of row m reads row f*reg_stride + m (no table: the displacement
     filter of the correlation layer, whose taps are the F blocks of H1 virtual vertices).
     out2 / rows2: rows m < rows2 of the result are also stored to the matrix (view) `out2`."""
-    if naive and post is not None:
-        raise _lib.HplError('the naive reference kernel has no fused trailing conv (post)')
     d = GConvDesc()
     d.A, d.lda, d.rows_a, a_cols = _mat(A, 'activation')
     if nbr is not None:
@@ -321,12 +319,6 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
     d.Wt, d.ldw, d.N = ptr(Wt), wsh[1], N
     d.w_rows = min(wsh[0], round_up(F * C, 32))     # rows past the image read as zero
     d.act, d.slope = act, slope
-    if post is not None:          # fused trailing 1x1 conv: (k-major image [>= N, ldw2], bias or None, N2, act2)
-        W2, b2, N2, act2 = post
-        if W2.shape[0] < N or W2.shape[1] < N2 or not W2.is_contiguous():
-            raise _lib.HplError('post conv image %s too small for %d -> %d' % (tuple(W2.shape), N, N2))
-        d.post_Wt, d.post_ldw, d.post_N, d.post_act = ptr(W2), W2.shape[1], N2, act2
-        d.post_bias = ptr(b2)
     if Wt3 is not None:           # weight_split3 of the image Wt is a row range of (same first row)
         d.Wt3, d.wt3_plane_stride = ptr(Wt3), Wt3.stride(0)
     if bias is not None:
@@ -339,7 +331,7 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
             raise _lib.HplError('scatter epilogue needs a zero-initialised `out`')
         d.scat, d.scat_stride, d.scat_c = ptr(scat), scat.stride(0), scat_c
     elif out is None:
-        out = torch.empty((M, post[2] if post is not None else N), dtype=torch.float32, device=A.device)
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     d.Y, d.ldy, _, _ = _mat(out, 'out')
     if out2 is not None:
         d.Y2, d.ldy2, r2, c2 = _mat(out2, 'out2')

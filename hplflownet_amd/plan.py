@@ -32,11 +32,6 @@ SYM_ZERO, SYM_N0, SYM_N1, SYM_NP, SYM_LEVEL0 = -1, 0, 1, 2, 8
 S_H0, S_H1, S_HP, S_FH0, S_IN0, S_INP, S_FH1 = range(7)
 BUF_OUT = -2
 
-#: HPL_FUSE_NARROW=1: a narrow conv and the 1x1 conv behind it are one op (hpl_op.post_*), which the executor runs as ONE
-#: launch below HPL_FUSE_MAX_ROWS rows (default 8192) and as two above.  Bit-identical to two launches and measured on
-#: the N=8192 model: 270-285 pairs/s with it, 277-283 without, single-pair forward 5.0 ms against 4.87 ms -- back-to-back
-#: launches on one stream cost less than the serial second contraction in the epilogue.  Off by default.
-FUSE_NARROW = os.environ.get('HPL_FUSE_NARROW', '0') != '0'
 #: profiling classes (hpl_op.tag): the wide stencil convs that dominate the step, everything else
 TAG_OTHER, TAG_WIDE_BLUR = 0, 1
 
@@ -73,8 +68,6 @@ def _op(*fields, **kw):
     o = Op(*fields)
     o.out2 = kw.get('out2') or _NONE
     o.rows2_sym = kw.get('rows2', SYM_ZERO)
-    o.post_weight, o.post_bias, o.post_N, o.post_act = kw.get('post', (-1, -1, 0, 0))[:4]
-    o.post_mid = kw['post'][4] if len(kw.get('post', ())) > 4 else _NONE
     o.b = kw.get('b') or _NONE
     o.flags, o.aux = kw.get('flags', 0), kw.get('aux', 0)
     return o
@@ -124,17 +117,16 @@ class _Program(object):
         return self.bias(t)
 
     def gconv(self, a, out, M, C, N, wid, bias=-1, act=0, slope=0.1, F=1, level=0, table=TBL_NONE, order=ORD_NONE,
-              res=None, res_mod=SYM_ZERO, reg_stride=SYM_ZERO, tag=TAG_OTHER, out2=None, rows2=SYM_ZERO, post=None, flags=0, aux=0,
+              res=None, res_mod=SYM_ZERO, reg_stride=SYM_ZERO, tag=TAG_OTHER, out2=None, rows2=SYM_ZERO, flags=0, aux=0,
               wcols=False):
         """out2 / rows2: the first `rows2` rows of the result are written to a second view as well (a layer output that
         feeds two concatenation buffers is stored by its producer, not copied)."""
         self.ops.append(_op(OP_GCONV, tag, a.c(), out.c(), res.c() if res is not None else _NONE, M, res_mod, level, table,
                             order, F, C, N, wid, bias, act, slope, 0, reg_stride, 0, *self.cond,
-                            out2=out2.c() if out2 is not None else None, rows2=rows2, post=post or (-1, -1, 0, 0),
-                            flags=flags, aux=aux))
+                            out2=out2.c() if out2 is not None else None, rows2=rows2, flags=flags, aux=aux))
         self.meta.append(dict(kind='gconv', a=a, out=out, res=res, M=M, C=C, N=N, wid=wid, bias=bias, act=act, slope=slope, F=F,
                               level=level, table=table, order=order, res_mod=res_mod, reg_stride=reg_stride, out2=out2,
-                              rows2=rows2, cond=self.cond, post=post, tag=tag, wcols=wcols))
+                              rows2=rows2, cond=self.cond, tag=tag, wcols=wcols))
 
     def gsum(self, a, out, M, K, N, level, bias=-1, act=0, slope=0.1, res=None, res_mod=SYM_ZERO):
         """hpl_gather_sum through the level's pc2 correlation table: out[m] = act(bias + res[m % res_mod] + sum_k a[corr2[k][m], k*N:])."""
@@ -188,30 +180,13 @@ def _conv_stack(P, x, mods, M, rows_sym, F, level, table, order, slope, out=None
     """bcl._run_conv_stack: first conv through `table` (F taps), the rest 1x1; returns the output ref.  out2 / rows2:
     second destination of the LAST conv (_Program.gconv)."""
     n = len(mods)
-    skip = False
     for i, m in enumerate(mods):
-        if skip:                    # this 1x1 conv ran in the epilogue of the conv before it
-            skip = False
-            continue
         conv = _conv_of(m)
         act = 1 if isinstance(m, _ConvReLU) else 0
         O = conv.weight.shape[0]
-        post = None
-        if FUSE_NARROW and i + 1 < n:
-            nxt = _conv_of(mods[i + 1])
-            O2 = nxt.weight.shape[0]
-            wide_first = i == 0 and table == TBL_BLUR0 and conv.in_channels >= GROUPS_MIN_CHANNELS      # (tap-group passes)
-            if O <= 64 and O % 2 == 0 and O2 <= 64 and not wide_first and (i > 0 or (F <= 15 and order != ORD_GROUPS)):
-                # conv + the 1x1 conv behind it as one launch (hpl_gconv_desc.post_*): the intermediate matrix never exists
-                post = (P.weight(nxt.weight, O, O2, 1, O, 0), P.bias(nxt.bias), O2, 1 if isinstance(mods[i + 1], _ConvReLU) else 0,
-                        P.buf(rows_sym, O).c())          # (the intermediate matrix of the two-launch form: big levels)
-                skip = True
-        final = i == n - 1 or (skip and i + 1 == n - 1)
-        O_out = post[2] if post else O
-        o = out if (final and out is not None) else P.buf(rows_sym, O_out)
+        final = i == n - 1
+        o = out if (final and out is not None) else P.buf(rows_sym, O)
         second = dict(out2=out2, rows2=rows2) if (final and out2 is not None) else {}
-        if post:
-            second['post'] = post
         if i == 0:
             Ctot = conv.weight.numel() // (O * F)
             ordr = order

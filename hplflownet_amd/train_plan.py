@@ -23,7 +23,7 @@ import torch
 from . import _lib, ops
 from ._lib import LevelTables, RelayoutJob, check, ptr, stream
 from .bcl import _ConvReLU
-from .plan import (BUF_OUT, FUSE_NARROW, ForwardPlan, ORD_NONE, OP_GCONV, OP_GSUM, OP_INVERT, S_FH0, S_FH1, S_H0, S_H1, S_HP, S_IN0, S_INP, SYM_N0, SYM_N1,
+from .plan import (BUF_OUT, ForwardPlan, ORD_NONE, OP_GCONV, OP_GSUM, OP_INVERT, S_FH0, S_FH1, S_H0, S_H1, S_HP, S_IN0, S_INP, SYM_N0, SYM_N1,
                    SYM_NP, SYM_LEVEL0, SYM_ZERO, TBL_BLUR0, TBL_BLUR_PAIR, TBL_CORR1, TBL_CORR2, TBL_CSR_C0, TBL_CSR_PAIR, TBL_NONE,
                    TBL_REGULAR, _R, build_program, level_tables, lsym)
 
@@ -191,7 +191,6 @@ class _Backward(object):
         if m.get('wcols'):
             return self._zproj(m)
         P, sim, cond = self.P, self.sim, m['cond']
-        assert m['post'] is None, 'fused conv pairs (HPL_FUSE_NARROW) have no native backward'
         M, N, F = m['M'], m['N'], m['F']
         w, C, O, _, Ctot, c0 = P.wmeta[m['wid']]
         out, a = m['out'], m['a']
@@ -283,8 +282,6 @@ class TrainPlan(ForwardPlan):
     rank a bucket's all-reduce starts as soon as the program has produced it)."""
 
     def __init__(self, model, reducer=None, side_stream=True):
-        if FUSE_NARROW:
-            raise _lib.HplError('HPL_FUSE_NARROW has no native backward')
         self.params = [p for p in model.parameters()]
         if any(not p.requires_grad for p in self.params):
             raise _lib.HplError('the native training step expects every parameter to require a gradient')

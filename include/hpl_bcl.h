@@ -245,15 +245,6 @@ typedef struct hpl_gconv_desc {
      * rounding class; 16/6 of the fp32-MFMA rate).  NULL: fp32 MFMA. */
     const void *Wt3;
     int64_t wt3_plane_stride;   /* bytes between the planes */
-    /* optional fused trailing 1x1 conv of a narrow layer (even N <= 64, post_N <= 64, no scatter): the result above is
-     * not stored; Y[m, n2] = post_act(post_bias[n2] + sum_n act(...)[m, n] * post_Wt[n * post_ldw + n2]) is (ldy, ldy2
-     * >= post_N) -- the pair conv + 1x1 conv of a blur_conv / corr_conv stack (models/bilateralNN.py:219,
-     * models/bnn_flow.py:202-208 are single expressions) as ONE launch, bit-identical to two calls. */
-    const float *post_Wt;       /* [>= N][post_ldw] k-major image of the 1x1 conv (hpl_weight_relayout with F = 1) */
-    int64_t post_ldw;
-    const float *post_bias;     /* [post_N] or NULL */
-    int32_t post_N;
-    int32_t post_act;           /* HPL_ACT_* (same slope) */
 } hpl_gconv_desc;
 
 /* Row order for tap skipping: perm = the M vertices grouped by their F-bit tap-presence mask (bit f set iff
@@ -533,12 +524,6 @@ typedef struct hpl_op {
     int32_t cond_level;
     hpl_ref out2;             /* gconv: optional second destination (buf == -1: none), see hpl_gconv_desc.Y2 */
     int32_t rows2_sym;        /* rows of the result that go to out2 as well */
-    int32_t post_weight;      /* gconv: fused trailing 1x1 conv (hpl_gconv_desc.post_*): weight image index or -1 */
-    int32_t post_bias;        /*        its bias index or -1 */
-    int32_t post_N;           /*        its output channels (`out` / `out2` then hold post_N columns) */
-    int32_t post_act;
-    hpl_ref post_mid;         /*        where the first conv's result goes when the executor runs the two convs as two launches
-                                        (rows above its fusion threshold: a separate dense launch is the faster form there) */
     hpl_ref b;                /* second input of the backward ops (buf == -1: none) */
     int32_t flags;            /* HPL_FLAG_* */
     int32_t aux;

@@ -444,39 +444,6 @@ def test_split_k_row_order_independent_and_second_destination(ops, M, C, O, F, d
     assert rel_err(outs[0].cpu().numpy(), y_naive.cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('M,C,F,N1,N2,ws', [(5000, 68, 15, 64, 64, False), (300, 68, 15, 64, 64, True), (70000, 68, 15, 64, 64, False),
-                                            (2100, 128, 15, 32, 32, True), (9000, 36, 1, 64, 64, False), (777, 64, 15, 32, 64, True),
-                                            (4096, 3, 1, 32, 32, False)])
-def test_fused_trailing_conv_is_bit_identical_to_two_launches(ops, M, C, F, N1, N2, ws):
-    """hpl_gconv_desc.post_*: conv + the 1x1 conv behind it in one launch (MFMA second pass over the activated tile in LDS,
-    or the split-K finish kernel's fmaf chain) == two launches, bit for bit; second destination and strided output included."""
-    torch.manual_seed(M + N1)
-    A = torch.randn(M + 5, C, device=DEV)
-    nbr = None
-    if F > 1:
-        nbr = torch.randint(0, M + 5, (F, M), device=DEV, dtype=torch.int32)
-        nbr[torch.rand(F, M, device=DEV) > 0.7] = -1
-    Wt = torch.zeros(ops.round_up(F * C, 32), N1, device=DEV)
-    Wt[:F * C] = torch.randn(F * C, N1, device=DEV) / (F * C) ** 0.5
-    b1 = torch.randn(N1, device=DEV)
-    W2 = torch.randn(N1, ops.round_up(N2, 4), device=DEV) / N1 ** 0.5
-    b2 = torch.randn(N2, device=DEV)
-    res = torch.randn(M, N1, device=DEV)
-    y1 = ops.gconv_raw(A, nbr, M, C, F, Wt, N1, bias=b1, act=ops.ACT_LEAKY, res=res, split_k=ws)
-    want = ops.gconv_raw(y1, None, M, N1, 1, W2, N2, bias=b2, act=ops.ACT_LEAKY, split_k=False)
-    buf = torch.zeros(M, N2 + 12, device=DEV)
-    out2 = torch.zeros(M // 2, N2, device=DEV)
-    got = ops.gconv_raw(A, nbr, M, C, F, Wt, N1, bias=b1, act=ops.ACT_LEAKY, res=res, split_k=ws, out=buf[:, 4:4 + N2],
-                        out2=out2, rows2=M // 2, post=(W2, b2, N2, ops.ACT_LEAKY))
-    assert torch.equal(got, want) and torch.equal(out2, want[:M // 2])
-    assert float(buf[:, :4].abs().max()) == 0.0 and float(buf[:, 4 + N2:].abs().max()) == 0.0
-    # no bias / no activation on the second conv
-    got = ops.gconv_raw(A, nbr, M, C, F, Wt, N1, bias=b1, act=ops.ACT_LEAKY, split_k=ws, post=(W2, None, N2, ops.ACT_NONE))
-    want = ops.gconv_raw(ops.gconv_raw(A, nbr, M, C, F, Wt, N1, bias=b1, act=ops.ACT_LEAKY, split_k=ws), None, M, N1, 1, W2, N2,
-                         split_k=False)
-    assert torch.equal(got, want)
-
-
 def test_fast_and_generic_epilogues_are_bit_identical():
     """hpl_gconv_forward's epilogue has a fast form (32-bit buffer addressing, residual loads batched per block) and the
     generic form it falls back to for operands of 2 GB and more; HPL_GCONV_EPILOGUE=0 forces the generic one.  Same bits on:

@@ -172,3 +172,48 @@ def test_bench_refuses_a_job_it_cannot_place():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env, cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 2 and 'visible' in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+
+
+def _flat_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from hplflownet_amd import parallel as P
+    P.init_distributed(backend='gloo')
+    model = _make_model(seed=0)
+    red = P.GradAllReducer(model.parameters(), bucket_bytes=1024, overlap=False)
+    # the layout train_plan.TrainPlan uses: one flat arena in bucket order, .grad = views of it
+    flat = torch.zeros(sum(p.numel() for p in model.parameters()))
+    ranges, o = [], 0
+    for b in red.buckets:
+        o0 = o
+        for p in b:
+            p.grad = flat[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+        ranges.append((o0, o))
+    red.adopt_flat(flat, ranges)
+    x, t = _sample(rank)
+    loss = torch.norm(model(x) - t, p=2, dim=1).mean()
+    grads = torch.autograd.grad(loss, list(model.parameters()))
+    for p, g in zip(model.parameters(), grads):
+        p.grad.copy_(g)                                # (what the native backward does: write into the arena)
+    for b in reversed(range(len(red.buckets))):        # any order, as long as every rank uses the same one
+        red.launch_flat(b)
+    red.finish_flat()
+    torch.save({'grads': [p.grad.clone() for p in model.parameters()], 'views': all(p.grad.data_ptr() >= flat.data_ptr() for p in model.parameters())},
+               os.path.join(out_dir, 'f%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_flat_arena_all_reduce():
+    """GradAllReducer.adopt_flat / launch_flat / finish_flat (the native training step's gradients live in one arena): the mean of
+    the two ranks' gradients, in place, no packing copies."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_flat_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        res = [torch.load(os.path.join(d, 'f%d.pt' % r)) for r in range(world)]
+    assert res[0]['views'] and res[1]['views']
+    model = _make_model(seed=0)
+    loss = sum(torch.norm(model(_sample(s)[0]) - _sample(s)[1], p=2, dim=1).mean() for s in (0, 1)) / 2
+    loss.backward()
+    for p, a, b in zip(model.parameters(), res[0]['grads'], res[1]['grads']):
+        assert torch.equal(a, b) and torch.allclose(p.grad, a, atol=1e-6, rtol=1e-5)
