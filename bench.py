@@ -47,22 +47,17 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s 
 def split3_takes(M, N, C, F, scat=False):
     """Mirror of hpl_gc::launch_split3 (csrc/gconv3.hip): which launches run on the bf16 MFMA with split operands."""
     from hplflownet_amd import ops
-    env = lambda k, d: int(os.environ.get(k, d))
-    if not (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N >= 256 and F <= 15 and M >= env('HPL_SPLIT3_FLOOR_ROWS', 1024)):
+    if not (ops.SPLIT3 and not scat and C >= 32 and C % 4 == 0 and N >= 256 and F <= 15 and M >= 1024):
         return False
     tiles = -(-M // 128) * -(-N // 256)
-    fills = tiles >= env('HPL_SPLIT3_FILL_TILES', 128)
-    min_rows = env('HPL_SPLIT3_MIN_ROWS', 8192)
+    fills = tiles >= 128
     if F == 1:
-        return M >= min_rows or fills
-    if M >= env('HPL_SPLIT3_MIN_ROWS_STENCIL', 16384) or fills:
+        return M >= 8192 or fills
+    if M >= 16384 or fills:
         return True
-    if M < env('HPL_SPLIT3_MID_MIN_ROWS', 1024):
-        return False
     # mid-size stencils: only split over K into one round of workgroups (partial tiles in the split-K workspace)
     splitk = min(8, 256 // max(1, tiles), (-(-F * C // 32)) // 16)
-    return (os.environ.get('HPL_SPLIT3_MID_SPLITK', '1') != '0' and splitk >= 2 and N % 256 == 0 and M * N <= (8 << 20) and
-            splitk * M * N * 4 <= (256 << 20))
+    return splitk >= 2 and N % 256 == 0 and M * N <= (8 << 20) and splitk * M * N * 4 <= (64 << 20)
 
 
 def gconv_class(M, N, K=1 << 20):
@@ -183,7 +178,7 @@ def mfma_ceiling(dev):
     """Sustained v_mfma_f32_32x32x2_f32 rate with no memory traffic on this device (TFLOP/s),
     best of three 10-ms bursts (the first burst after an idle period runs at a lower clock)."""
     from hplflownet_amd import _lib
-    L = _lib.load()
+    L = _lib.load_diag()                  # libhplbcl_diag.so (include/hpl_diag.h): not part of the product library
     out = torch.empty(1024 * 256, device=dev)
     best = 0.0
     for _ in range(3):
@@ -330,19 +325,12 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
     # build and one optimiser step per timed step
     # the native (fused) builder on a producer thread: the tables of the training path (tap lists, symmetry verdicts) are added
     # there too, off the thread that issues the ~900 launches of the step
-    nat = not os.environ.get('HPL_TRAIN_PY_LATTICE')
-    pipe = LatticePipeline(gen, lambda i: pairs[i % len(pairs)], 0, warmup + steps * (2 if os.environ.get('HPL_TRAIN_PROBE_TRACE') else 1), depth=2, stream=side, for_training=True,
-                           native=nat, threaded=nat)
+    pipe = LatticePipeline(gen, lambda i: pairs[i % len(pairs)], 0, warmup + steps, depth=2, stream=side, for_training=True,
+                           native=True, threaded=True)
     keep = []
 
-    trace = bool(os.environ.get('HPL_TRAIN_PROBE_TRACE'))
-
     def one():
-        t_a = time.perf_counter()
         (i, _), lat, ev = pipe.get()
-        if trace:
-            ev.synchronize()
-            print('   lattice wait %.2f ms' % ((time.perf_counter() - t_a) * 1e3), file=sys.stderr)
         main.wait_event(ev)
         p1, p2 = pairs[i % len(pairs)]
         r = tplan.step(p1, p2, sfs[i % len(pairs)], lat) if native else None
@@ -371,12 +359,6 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
         for _ in range(warmup):
             one()
         torch.cuda.synchronize()
-        if os.environ.get('HPL_TRAIN_PROBE_TRACE'):          # diagnostic: every step on its own (synchronised), to stderr
-            for k in range(steps):
-                t1 = time.perf_counter()
-                one()
-                torch.cuda.synchronize()
-                print('train probe step %d: %.2f ms' % (k, (time.perf_counter() - t1) * 1e3), file=sys.stderr)
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = one()
@@ -425,9 +407,7 @@ def source_stamp():
     h = hashlib.sha256()
     for f in ('gconv.hip', 'gconv3.hip', 'gconv_common.h', 'executor.hip', 'row_order.hip'):
         h.update(open(os.path.join(ROOT, 'hplflownet_amd', 'csrc', f), 'rb').read())
-    for k in ('HPL_MATH', 'HPL_SPLIT3_BN', 'HPL_TAP_GROUPS', 'HPL_TILE', 'HPL_WG3', 'HPL_SPLIT3_MIN_ROWS', 'HPL_SPLIT3_MIN_ROWS_STENCIL', 'HPL_SPLIT3_FILL_TILES', 'HPL_SPLIT3_FLOOR_ROWS', 'HPL_SPLIT3_MID_MIN_ROWS',
-              'HPL_SPLIT3_NB', 'HPL_SPLIT3_BN256_PCT', 'HPL_PERM_MIN_ROWS', 'HPL_SPLIT3_MID_SPLITK', 'HPL_ROW_ORDER', 'HPL_FUSE_NARROW', 'HPL_SPLIT3_EPILOGUE',
-              'HPL_GCONV_EPILOGUE'):
+    for k in ('HPL_MATH', 'HPL_SPLIT3_EPILOGUE', 'HPL_GCONV_EPILOGUE'):
         h.update(('%s=%s;' % (k, os.environ.get(k, ''))).encode())
     return h.hexdigest()
 
@@ -601,7 +581,7 @@ def main():
             reducer = parallel.GradAllReducer(model.parameters(), overlap=False)
             tplan = TrainPlan(model, reducer=reducer)
         else:
-            ops.enable_weight_bank(not os.environ.get('HPL_NO_BANK'))     # one batched weight re-layout per step
+            ops.enable_weight_bank(True)     # one batched weight re-layout per step
             reducer = parallel.GradAllReducer(model.parameters())
 
         def compute(i, lat):
@@ -633,8 +613,7 @@ def main():
             return model(p1[None], p2[None], lat)
 
     overlap = not (a.no_lattice or a.no_overlap)
-    # HPL_PRIO: which stream gets the high hardware-queue priority ('lattice' | 'forward' | 'none')
-    prio = os.environ.get('HPL_PRIO', 'lattice')
+    prio = 'lattice'          # the lattice stream gets the high hardware-queue priority (swept in round 2: forward / none are slower)
     side = [torch.cuda.Stream(device=dev, priority=-1 if prio == 'lattice' else 0) for _ in range(max(1, a.lattice_streams))] \
         if overlap else None
     # forwards of consecutive pairs alternate over a.streams HIP streams: the launch-bound deep levels of
@@ -704,7 +683,7 @@ def main():
     with torch.set_grad_enabled(a.train):
         # one-time costs (weight images, allocator pools of every stream, lazy module loads) are paid by
         # PREWARM untimed steps of our own, so that --warmup 0 still measures the steady state
-        PREWARM = int(os.environ.get('HPL_BENCH_PREWARM', '3'))
+        PREWARM = 3
         if overlap:
             run_pipelined(0, PREWARM + a.warmup)
         else:
@@ -719,8 +698,7 @@ def main():
         plan = model.forward_plan() if native else None
         if plan is not None:
             from hplflownet_amd.plan import TAG_WIDE_BLUR
-            if not os.environ.get('HPL_BENCH_NO_INLOOP_EVENTS'):
-                plan.profile(TAG_WIDE_BLUR)       # HIP events around the wide stencil convs, on the stream they run on
+            plan.profile(TAG_WIDE_BLUR)       # HIP events around the wide stencil convs, on the stream they run on
         t0 = time.perf_counter()
         if overlap:
             y = run_pipelined(PREWARM + a.warmup, a.steps)

@@ -112,22 +112,16 @@ _SIGNATURES = {
                                            c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
     'hpl_weight_relayout_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp, c_vp]),
     'hpl_weight_split3': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
-    'hpl_split3_info': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
-                                       ctypes.POINTER(ctypes.c_int)]),
     'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,
                                            c_i64, c_i64, c_i64, ctypes.c_int, c_vp]),
     'hpl_tap_order_scratch_ints': (c_i64, [c_i64]),
     'hpl_tap_order': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp]),
-    'hpl_tap_order_keyed': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp,
-                                           c_vp]),
     'hpl_tile_index': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_vp, c_vp, c_vp]),
     'hpl_gconv_forward': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
     'hpl_gconv_forward_naive': (ctypes.c_int, [ctypes.POINTER(GConvDesc), c_vp]),
     'hpl_gconv_wgrad': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,
                                        c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     'hpl_tap_lists': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'hpl_mfma_probe': (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp]),
-    'hpl_mfma_probe_data': (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
     'hpl_colsum': (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     'hpl_leaky_bwd': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_i64, ctypes.c_int, c_vp]),
     'hpl_transpose': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
@@ -184,6 +178,25 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+DIAG_PATH = os.path.join(_HERE, 'libhplbcl_diag.so')
+_diag = None
+
+
+def load_diag():
+    """libhplbcl_diag.so (include/hpl_diag.h): the MFMA rate probes of bench.py / tools -- not part of the product library."""
+    global _diag
+    if _diag is None:
+        if not os.path.exists(DIAG_PATH):
+            raise HplError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"`' % DIAG_PATH)
+        lib = ctypes.CDLL(DIAG_PATH)
+        lib.hpl_mfma_probe.restype = ctypes.c_int
+        lib.hpl_mfma_probe.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp]
+        lib.hpl_mfma_probe_data.restype = ctypes.c_int
+        lib.hpl_mfma_probe_data.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp]
+        _diag = lib
+    return _diag
 
 
 def check(rc, what):

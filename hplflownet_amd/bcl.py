@@ -101,7 +101,6 @@ def pointwise_conv(x, conv, act, use_leaky, out=None):
 GROUPS_MIN_CHANNELS = 256
 
 
-_NO_TILES = bool(os.environ.get('HPL_NO_TILES'))       # A/B switch: no precomputed per-tile index tables
 
 
 class NbrTable(object):
@@ -109,7 +108,7 @@ class NbrTable(object):
 
     #: smaller tables are not reordered: on the coarse levels > 90 % of the taps are present (measured:
     #: level 2 of the N=8192 frustum skips < 3 % of the slices), the sort costs more than it saves
-    PERM_MIN_ROWS = int(os.environ.get('HPL_PERM_MIN_ROWS', '16384'))
+    PERM_MIN_ROWS = 16384
 
     def __init__(self, t):
         self.t = t
@@ -123,27 +122,24 @@ class NbrTable(object):
         #: points per vertex -> most neighbour slots empty) is where the multi-pass contraction pays
         #: (bcn1_, 42 % of the taps present: 2.62 -> 2.08 ms; bcn2_, 72 %: no gain)
         self.vertices_per_point = None
-        #: set by the lattice builder: (vkeys0, H0, vkeys1) lattice keys of the table's rows (ops.tap_order): the row
-        #: orders then keep spatially close vertices together inside a mask group
-        self.keys = None
 
     @property
     def perm(self):
         """Row order grouping vertices by tap-presence mask (see gconv row_perm)."""
         if self._perm is False:
             F, M = self.t.shape
-            self._perm = ops.tap_order(self.t, self.keys) if (1 < F <= 15 and M >= self.PERM_MIN_ROWS) else None
+            self._perm = ops.tap_order(self.t) if (1 < F <= 15 and M >= self.PERM_MIN_ROWS) else None
         return self._perm
 
     #: number of tap groups of the multi-pass contraction (ops.gconv tap_groups); env for A/B runs
     #: (hpl_level_tables carries at most 4 groups: larger values are clamped)
-    TAP_GROUPS = min(4, int(os.environ.get('HPL_TAP_GROUPS', '2')))      # swept 1 / 2 / 3 / 5 end to end: 193 / 205 / 204 / 173 pairs/s
+    TAP_GROUPS = 2      # swept 1 / 2 / 3 / 5 end to end: 193 / 205 / 204 / 173 pairs/s (round 2); 1 / 3: 316 / 310 vs 353 (round 4)
     #: levels with at least this many lattice vertices per input point get the passes (level 0: 3.2, level 1:
     #: 1.34 -- bcn1_ and bcn2_; measured end to end 2.0 -> 1.2: 212.5 -> 218.5 pairs/s)
-    GROUPS_MIN_SPARSITY = float(os.environ.get('HPL_GROUPS_MIN_SPARSITY', '1.2'))
+    GROUPS_MIN_SPARSITY = 1.2
     #: ... and at least this many rows: the passes run on the split-operand kernel's 128 x 256 tiles, which take a launch that
     #: fills half the CUs in one round or splits over K (csrc/gconv3.hip) -- clouds of 2 048 points: 384 -> 720 pairs/s, 1 024: 620 -> 930
-    GROUPS_MIN_ROWS = int(os.environ.get('HPL_GROUPS_MIN_ROWS', '2048'))
+    GROUPS_MIN_ROWS = 2048
 
     def groups(self):
         """[(f0, f1, perm)] for TAP_GROUPS groups of consecutive taps, each with its own row order
@@ -156,21 +152,21 @@ class NbrTable(object):
                 self._groups = None
             else:
                 cuts = [round(i * F / G) for i in range(G + 1)]
-                self._groups = [(f0, f1, ops.tap_order(self.t[f0:f1], self.keys)) for f0, f1 in zip(cuts[:-1], cuts[1:])]
+                self._groups = [(f0, f1, ops.tap_order(self.t[f0:f1])) for f0, f1 in zip(cuts[:-1], cuts[1:])]
         return self._groups
 
     @property
     def perm_tiles(self):
         """(tile_idx, tile_mask) of the single-pass row order (ops.tile_index), None without one."""
         if self._perm_tiles is False:
-            self._perm_tiles = ops.tile_index(self.t, self.perm) if (self.perm is not None and not _NO_TILES) else None
+            self._perm_tiles = ops.tile_index(self.t, self.perm) if self.perm is not None else None
         return self._perm_tiles
 
     def group_tiles(self):
         """[(tile_idx, tile_mask)] aligned with groups(), None without groups."""
         if self._group_tiles is False:
             g = self.groups()
-            self._group_tiles = [ops.tile_index(self.t[f0:f1], pm, BM=ops.GROUP_TILE_BM) for f0, f1, pm in g] if (g and not _NO_TILES) else None
+            self._group_tiles = [ops.tile_index(self.t[f0:f1], pm, BM=ops.GROUP_TILE_BM) for f0, f1, pm in g] if g else None
         return self._group_tiles
 
     #: per-tap vertex lists pay for wide layers only (wgrad tap mode needs C >= 128-ish) and big tables

@@ -681,7 +681,7 @@ extern "C" int hpl_plan_run_range(hpl_plan *plan, const hpl_level_tables *levels
     auto is_emg = [](const hpl_op &op) { return op.kind == HPL_OP_COPY && op.a.buf == -1; };
     // every el_minus_gr copy of the forward in one launch, ahead of the layers (hpl_plan_create checked that nothing
     // else writes those columns: plan->hoist_emg)
-    static const int batch_emg = getenv("HPL_EMG_BATCH") ? atoi(getenv("HPL_EMG_BATCH")) : 1;
+    constexpr int batch_emg = 1;
     const bool hoist = batch_emg && plan->hoist_emg;
     if (hoist && op_begin == 0) {
         EmgJobs jobs;

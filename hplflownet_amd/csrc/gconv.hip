@@ -28,43 +28,10 @@ using namespace hpl;
 using namespace hpl_gc;
 
 
-#ifdef HPL_TIMING
-// Diagnostic build only (tools/tile_timing.py, -DHPL_TIMING): per-wave cycle stamps of the first workgroups of the
-// last k_gconv launch.  Record layout per (workgroup, wave): [0] start, [1] main loop entered, [2] main loop left,
-// [3] end, [4] slices, [5] cycles parked at the end-of-step waitcnt + barrier, [6] wall clock (100 MHz) at start, [7] (wall clock at end << 4) | XCC id.
-#define HPL_TIMING_WGS 8192
-__device__ long long g_timing[HPL_TIMING_WGS * 8 * 8];
-extern "C" int hpl_timing_read(long long *dst_host) {
-    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_timing), sizeof(long long) * HPL_TIMING_WGS * 8 * 8) == hipSuccess ? 0 : -2;
-}
-// ablation switch of the diagnostic build: 1 = every gathered row / weight row load hits a small resident set of
-// cache lines (no L2 misses), 2 = no global loads in the main loop at all (LDS keeps stale data)
-__device__ int g_abl;
-extern "C" int hpl_timing_ablate(int mode) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_abl), &mode, sizeof(int)) == hipSuccess ? 0 : -2;
-}
-extern "C" int hpl_timing_reset(void) {
-    void *p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_timing)) != hipSuccess) return -2;
-    return hipMemset(p, 0, sizeof(long long) * HPL_TIMING_WGS * 8 * 8) == hipSuccess ? 0 : -2;
-}
-#define HPL_T(slot, val)                                                                            \
-    do {                                                                                            \
-        if (lane == 0 && blockIdx.x < HPL_TIMING_WGS && wave < 8)                                   \
-            g_timing[((size_t)blockIdx.x * 8 + wave) * 8 + (slot)] = (long long)(val);              \
-    } while (0)
-#else
-#define HPL_T(slot, val) do { } while (0)
-#endif
 
 namespace {
-// -DHPL_PROLOGUE_PRIO=1: s_setprio(3) over the tile prologue.  Measured (profiles/r02w_prologue_prio.txt): the prologue
-// shrinks 21 k -> 15 k cycles and the co-resident workgroup's loop slows by the same amount (the matrix pipe is shared:
-// zero-sum), kernel time unchanged -> off.
-#ifndef HPL_PROLOGUE_PRIO
-#define HPL_PROLOGUE_PRIO 0
-#endif
-constexpr bool PROLOGUE_PRIO = HPL_PROLOGUE_PRIO != 0;
+// (s_setprio(3) over the tile prologue was measured in round 2, profiles/r02w_prologue_prio.txt: the prologue shrinks 21 k -> 15 k
+// cycles and the co-resident workgroup's loop slows by the same amount -- zero-sum, removed.)
 
 // COMPACT: the LDS budget of a third workgroup per CU (160 KiB / 3 = 54 613 B): A rows padded by 1 instead of 2 floats
 // (the transposing store stays conflict-free: bank = 4*kq + r over kq < 8, r < 4), slice list of 512 entries (K <= 16 384).
@@ -111,14 +78,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
         probe_c = (long long)__builtin_readcyclecounter();
         probe_w = (long long)__builtin_amdgcn_s_memrealtime();
     }
-    // the few hundred instructions of the prologue compete for issue slots with the co-resident workgroup's main loop
-    // (older waves win the arbitration): run them at raised priority, back to 0 before the main loop
-    if (PROLOGUE_PRIO) __builtin_amdgcn_s_setprio(3);
-#ifdef HPL_TIMING
-    HPL_T(0, __builtin_readcyclecounter());
-    HPL_T(6, __builtin_amdgcn_s_memrealtime());                                   // 100 MHz wall clock at start
-    long long parked = 0;
-#endif
     const int wm = wave / WGN, wn = wave % WGN;
     const int li = lane & 31, hi = lane >> 5;
 
@@ -213,18 +172,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
             for (int i = 0; i < A_PASSES; ++i) rows_n[i] = Is[fi * BM + arow0 + i * A_ROWS_PER_PASS];
         }
     };
-#ifdef HPL_TIMING
-    const int abl = g_abl;
-#endif
     auto load_a = [&](int set, int i) {
         if (AVEC) {
             const bool ok = (f_t < p.F) && (rows_n[i] >= 0);
-#ifdef HPL_TIMING
-            if (abl == 2) { ra[set][i] = make_float4(1.f, 2.f, 3.f, 4.f); return; }
-            const unsigned off = ok ? (unsigned)(abl == 1 ? (rows_n[i] & 63) : rows_n[i]) * lda_b + (unsigned)c_t * 4u : OOB;
-#else
             const unsigned off = ok ? (unsigned)rows_n[i] * lda_b + (unsigned)c_t * 4u : OOB;
-#endif
             const float4_t v = buffer_load_f32x4(rsrc_a, (int)off, 0, 0);
             ra[set][i] = make_float4(v.x, v.y, v.z, v.w);
         } else {   // generic path: any C / alignment, element by element
@@ -249,12 +200,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
     (void)rsrc_b;
     const int wave_brow0 = (wave * 64) / B_F4_PER_ROW;         // first tile row of this wave's 64 lanes
     auto load_b_lds = [&](int buf, int k0, int i) {
-#ifdef HPL_TIMING
-        if (abl == 2) return;
-        const unsigned off = bvalid ? boff0 + (unsigned)((abl == 1 ? (k0 & 255) : k0) + i * B_ROWS_PER_PASS) * ldw_b : OOB;
-#else
         const unsigned off = bvalid ? boff0 + (unsigned)(k0 + i * B_ROWS_PER_PASS) * ldw_b : OOB;
-#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             lrsrc_b,
             (__attribute__((address_space(3))) void *)(Bs + buf * BK * LDB_S + (wave_brow0 + i * B_ROWS_PER_PASS) * LDB_S),
@@ -426,25 +372,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifdef HPL_TIMING
-            if (kk == BK / 2 - 1) {
-                const long long t0_ = __builtin_readcyclecounter();
-                pieces(kk);
-                __syncthreads();
-                parked += __builtin_readcyclecounter() - t0_;
-                continue;
-            }
-#endif
             pieces(kk);
         }
-#ifndef HPL_TIMING
         __syncthreads();
-#endif
         cur ^= 1;
     };
-    if (PROLOGUE_PRIO) __builtin_amdgcn_s_setprio(0);
-    HPL_T(1, __builtin_readcyclecounter());
-    HPL_T(4, nsl);
     {
         using T = std::true_type;
         using F = std::false_type;
@@ -466,10 +398,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
         if (t < nsl) step((int)Ks[lo + t], -1, -1, F{}, F{}, P0{});
     }
 
-    HPL_T(2, __builtin_readcyclecounter());
-#ifdef HPL_TIMING
-    HPL_T(5, parked);
-#endif
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // Fast form (gconv3.hip's: every operand below 2 GB, residual not wrapped, no scatter): output rows by 16-byte LDS reads,
     // 32-bit byte offsets, out-of-range offsets instead of branches, the residual loads of a block before its stores.  The
@@ -562,10 +490,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
         atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 1,
                   (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - probe_w));
     }
-    HPL_T(3, __builtin_readcyclecounter());
-#ifdef HPL_TIMING
-    HPL_T(7, (__builtin_amdgcn_s_memrealtime() << 4) | (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15));   // wall clock at end | XCC id
-#endif
 }
 
 // split-K epilogue: Y = act(bias + res + sum_s partial[s]) in fixed split order
@@ -648,11 +572,7 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.tile_mask = d->tile_mask;
     p.tile_bm = d->tile_bm;
     p.clock_probe = reinterpret_cast<long long *>(d->clock_probe);
-    {
-        const char *e = getenv("HPL_PERM_CHUNK");
-        p.perm_chunk = e ? atoi(e) : 4;      // measured on bcn1_/bcn2_ (64-row tiles): 1: 2.61/1.33 ms, 2: 2.73/1.31, 4: 2.62/1.26, 8: 2.66/1.26, 16: 2.96/1.27
-        if (p.perm_chunk < 1) p.perm_chunk = 1;
-    }
+    p.perm_chunk = 4;      // measured on bcn1_/bcn2_ (64-row tiles): 1: 2.61/1.33 ms, 2: 2.73/1.31, 4: 2.62/1.26, 8: 2.66/1.26, 16: 2.96/1.27
     p.ws = d->ws; p.ws_bytes = d->ws ? d->ws_bytes : 0; p.splits = 1; p.partial = nullptr;
     p.Wt3 = d->Wt3; p.w3_plane_stride = d->wt3_plane_stride;
     p.col_share = 0; p.col_rows = 0;
@@ -687,7 +607,7 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
         // Mid-size launches: a few hundred tiles on 256 CUs leave the chip unevenly loaded (544 tiles of a level-0 conv
         // on dense data = 2.1 per CU: the CUs holding three set the time, 71 %).  Splitting K multiplies the work items;
         // pick the split count with the best (load balance) x (1 - cost of writing and re-reading the partial tiles).
-        static const int mid = getenv("HPL_SPLIT_MID") ? atoi(getenv("HPL_SPLIT_MID")) : 1;
+        constexpr int mid = 1;
         constexpr int WG_PER_CU = 16 / (WGM * WGN);                    // four waves per SIMD fill a CU
         const double slots = 256.0 * WG_PER_CU;
         if (mid && tiles < 6 * slots) {
@@ -714,7 +634,7 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
                       (!p.Y2 || (p.rows2 * p.ldy2 * 4 < lim && p.ldy2 * 4 < (1 << 24)))) ? 1 : 0;
     }
     p.col_share = 0; p.col_rows = 0;
-    static const int col_order = getenv("HPL_TILE_ORDER") ? atoi(getenv("HPL_TILE_ORDER")) : 1;
+    constexpr int col_order = 1;
     if (col_order && p.row_perm && p.splits == 1) {
         // every column tile is cut into 8 / gcd(8, tiles_n) interleaved runs of tile-rows, so that the runs
         // divide evenly among the 8 XCDs (tiles_n = 8: one whole column per XCD; 4: two XCDs per column;
@@ -730,7 +650,7 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
         // third workgroup covers the dispatch gaps and prologues of the other two -- slots occupied 0.91 -> 0.93 of 768,
         // dominant launch 816 -> 789 us alone (profiles/r02y_wg3.txt); in the three-stream pipeline the throughput is
         // unchanged (the GPU is matrix-pipe bound there).  HPL_WG3=0 switches it off.
-        static const int wg3 = getenv("HPL_WG3") ? atoi(getenv("HPL_WG3")) : 1;
+        constexpr int wg3 = 1;
         if (wg3 && avec && p.F > 1 && p.F <= 8 && nk <= 512 && p.splits == 1) {      // (a tap group: <= 8 taps staged)
             k_gconv<BM, BN, WGM, WGN, true, 8, true><<<grid, 64 * WGM * WGN, 0, s>>>(p);
             return;
@@ -765,24 +685,9 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     }
     // Tile selection.
     const int64_t t128 = cdiv(p.M, 128), t64 = cdiv(p.M, 64);
-    // HPL_TILE=<name>: force one tile configuration (tools/bench_gconv.py sweeps them)
-    static const char *force = getenv("HPL_TILE");
     const int nsel = p.N;
-    if (force && *force) {
-        const std::string f(force);
-        if (f == "128x128") launch_cfg<128, 128, 2, 4>(p, avec, s);
-        else if (f == "128x128w4") launch_cfg<128, 128, 2, 2>(p, avec, s);
-        else if (f == "128x128w16") launch_cfg<128, 128, 4, 4>(p, avec, s);
-        else if (f == "64x128") launch_cfg<64, 128, 2, 2>(p, avec, s);
-        else if (f == "64x128w8") launch_cfg<64, 128, 2, 4>(p, avec, s);
-        else if (f == "128x64") launch_cfg<128, 64, 2, 2>(p, avec, s);
-        else if (f == "128x64w8") launch_cfg<128, 64, 4, 2>(p, avec, s);
-        else if (f == "64x64") launch_cfg<64, 64, 2, 2>(p, avec, s);
-        else if (f == "128x32") launch_cfg<128, 32, 4, 1>(p, avec, s);
-        else if (f == "64x32") launch_cfg<64, 32, 2, 1>(p, avec, s);
-        else { set_error("hpl_gconv_forward: unknown HPL_TILE '%s'", force); return HPL_EINVAL; }
-    } else if (nsel > 64) {
-        // Measured on the model's shapes (tools/bench_gconv.py, HPL_TILE sweep): 4 waves per SIMD beat
+    if (nsel > 64) {
+        // Measured on the model's shapes (a sweep of ten tile configurations, rounds 1-2): 4 waves per SIMD beat
         // bigger tiles everywhere -- 64x128 with 8 waves (2 workgroups per CU) when it yields >= 512
         // tiles, else 64x64 with 4 waves (4 workgroups per CU); 64-row tiles also skip more absent
         // taps than 128-row tiles (58.6 % vs 62.5 % of the slices executed on bcn1_).
@@ -1488,7 +1393,7 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
     // Slabs of the vertex loop per tile: workgroups run 2 per CU (512 at a time); pick the count that
     // minimises rounds x (slab length + the cost of the atomic epilogue, ~256 vertices' worth).  In tap
     // mode the lists are ~half of M and unequal; finer slabs even them out (~16 workgroups per slot).
-    static const int force_splits = getenv("HPL_WGRAD_SPLITS") ? atoi(getenv("HPL_WGRAD_SPLITS")) : 0;
+    constexpr int force_splits = 0;
     int64_t splits = 1;
     {
         const int64_t len = tap ? imax(1, m_len / 2) : m_len;
@@ -1512,7 +1417,7 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
         else k_wgrad<BN_, false, false><<<grid, 256, 0, s>>>(p);             \
     } while (0)
     if (bn == 128 && vec) {     // 8 waves (2x4): 4 waves per SIMD, 2-5 % over 4 waves
-        static const bool deep = getenv("HPL_WGRAD_DEEP") ? atoi(getenv("HPL_WGRAD_DEEP")) != 0 : true;
+        constexpr bool deep = true;
         if (tap && deep) k_wgrad<128, true, true, 512, true><<<grid, 512, 0, s>>>(p);
         else if (tap) k_wgrad<128, true, true, 512><<<grid, 512, 0, s>>>(p);
         else if (deep) k_wgrad<128, true, false, 512, true><<<grid, 512, 0, s>>>(p);
@@ -1521,123 +1426,5 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
     if (bn == 128) LAUNCH(128); else if (bn == 64) LAUNCH(64); else LAUNCH(32);
 #undef LAUNCH
     HPL_CHECK_LAUNCH("hpl_gconv_wgrad");
-    return HPL_OK;
-}
-
-// ------------------------------------------------------------------------------------------
-// Diagnostic: sustained rate of v_mfma_f32_32x32x2_f32 with no memory traffic (what the chip
-// gives at its actual clock under this instruction mix).  Used by tools/ and bench.py to quote
-// the measured ceiling next to the 157.3 TFLOP/s datasheet peak.
-// ------------------------------------------------------------------------------------------
-namespace {
-__global__ void __launch_bounds__(256) k_mfma_probe(float *out, int iters) {
-    floatx16 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float a = (float)threadIdx.x * 1e-3f, b = 1.0f + (float)blockIdx.x * 1e-6f;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-        }
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[i][r];
-    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-// the same number of MFMAs as one dependent chain per wave (one accumulator, as the 32x32-per-wave tiles)
-__global__ void __launch_bounds__(256) k_mfma_probe_chain(float *out, int iters) {
-    floatx16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float a = (float)threadIdx.x * 1e-3f, b = 1.0f + (float)blockIdx.x * 1e-6f;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int u = 0; u < 64; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += acc[r];
-    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-}  // namespace
-
-namespace {
-// The same MFMA stream on operands that CHANGE from instruction to instruction (eight pseudo-random values per lane
-// and operand, rotated): the matrix pipe's switching activity -- hence power, hence the clock the chip sustains --
-// is that of real data, not of the constant operands of k_mfma_probe.  mode 2 adds the LDS fragment traffic of the
-// gather-GEMM loop (two ds_read_b32 per MFMA).
-template <int MODE>
-__global__ void __launch_bounds__(256) k_mfma_probe_data(float *out, int iters, long long *clk) {
-    __shared__ float lds[2 * 32 * 130];
-    floatx16 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float a[8], b[8];
-    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        h = h * 1664525u + 1013904223u;
-        a[i] = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
-        h = h * 1664525u + 1013904223u;
-        b[i] = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
-    }
-    for (int i = threadIdx.x; i < 2 * 32 * 130; i += 256) lds[i] = a[i & 7] * 0.5f + b[(i >> 3) & 7];
-    __syncthreads();
-    long long c0 = 0, w0 = 0;
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); w0 = __builtin_amdgcn_s_memrealtime(); }
-    const int lane = threadIdx.x & 63;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (MODE == 2) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float av = lds[((u * 4 + i) & 31) * 130 + lane + ((it & 1) ? 4160 : 0)];
-                    const float bv = lds[((u * 4 + i + 7) & 31) * 130 + 64 + (lane & 31) + ((it & 1) ? 0 : 4160)];
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(u + i) & 7], b[(u * 3 + i) & 7], acc[i], 0, 0, 0);
-            }
-        }
-    }
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
-        clk[0] = __builtin_readcyclecounter() - c0;
-        clk[1] = __builtin_amdgcn_s_memrealtime() - w0;
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[i][r];
-    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-}  // namespace
-
-extern "C" int hpl_mfma_probe_data(float *out, int blocks, int iters, int mode, long long *clk, hplStream stream) {
-    HPL_REQUIRE(out && blocks > 0 && iters > 0 && (mode == 1 || mode == 2), "hpl_mfma_probe_data: bad arguments");
-    if (mode == 1) k_mfma_probe_data<1><<<blocks, 256, 0, to_stream(stream)>>>(out, iters, clk);
-    else k_mfma_probe_data<2><<<blocks, 256, 0, to_stream(stream)>>>(out, iters, clk);
-    HPL_CHECK_LAUNCH("hpl_mfma_probe_data");
-    return HPL_OK;
-}
-
-extern "C" int hpl_mfma_probe(float *out, int blocks, int iters, hplStream stream) {
-    HPL_REQUIRE(out && blocks > 0 && iters != 0, "hpl_mfma_probe: bad arguments");
-    if (iters < 0) k_mfma_probe_chain<<<blocks, 256, 0, to_stream(stream)>>>(out, -iters);
-    else k_mfma_probe<<<blocks, 256, 0, to_stream(stream)>>>(out, iters);
-    HPL_CHECK_LAUNCH("hpl_mfma_probe");
     return HPL_OK;
 }

@@ -44,18 +44,9 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-// Diagnostic build (-DHPL_PHASE_PROBE=1, tools/gpu/phase_probe.sh): every wave of the sampled workgroups accumulates the shader
-// cycles it spends in the four parts of a ping-pong half-step (memory phase up to its wait, first barrier, compute phase,
-// second barrier) into clock_probe[8 + 4 * wave row ..]; timing only (the stamps are scalar memory reads: they add waits)
-#ifndef HPL_PHASE_PROBE
-#define HPL_PHASE_PROBE 0
-#endif
-// Ping-pong schedule of the 8-wave tile (see gconv3_body): 1 = on; -DHPL_PP=0 builds the one-barrier form for A/B runs
-// (measured variants that did not pay -- one barrier per half-step, the non-MFMA work in the memory phase, register caps --
-// are in DESIGN.md 4.1 and profiles/r03s_variants_ab.txt, r04b_split3_pp3_ab.txt, not in this file)
-#ifndef HPL_PP
-#define HPL_PP 1
-#endif
+// (Diagnostic builds of rounds 3-4 -- per-phase cycle stamps, per-workgroup residence records, the one-barrier form of the 8-wave
+// tile -- produced profiles/r03s_phase_probe.txt, r03s_variants_ab.txt, r04b_split3_pp3_ab.txt, r04h_tile_balance.txt and were removed
+// in round 5; DESIGN.md 4.1 / 4.8 quote their results.)
 
 namespace {
 
@@ -102,7 +93,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     // of the dense launch's time was not MFMA issue).  Hazards: an A stage is written two half-steps and a weight stage three
     // half-steps before it is read, i.e. >= 3 barriers before the first reader of either row; a stage's last reader (the
     // late row, one barrier behind) is still >= 1 barrier ahead of its next writer.
-    constexpr bool PP = WGN == 4 && HPL_PP != 0;
+    constexpr bool PP = WGN == 4;
     static_assert(A_PASSES == 2 || A_PASSES == 4, "two halves of a slice per thread");
     // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read of an LDS-DMA pipeline)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NA * A_STAGE + NB * B_STAGE + ((F_LDS + 1) * BM + BM + 8) * 4 + KLIST * 2];
@@ -124,11 +115,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     const bool probe = p.clock_probe && (blockIdx.x & 63) == 0 && t == 0;
     long long probe_c = 0, probe_w = 0;
     if (probe) { probe_c = (long long)__builtin_readcyclecounter(); probe_w = (long long)__builtin_amdgcn_s_memrealtime(); }
-    // -DHPL_PHASE_PROBE=2 (tools/tile_probe.py): EVERY workgroup leaves 4 words at clock_probe[64 + 4 * blockIdx.x]: wall ticks
-    // (100 MHz) at entry and exit, shader cycles of the main loop, slices | HW_ID << 16 | XCC id << 48
-    const bool tprobe = HPL_PHASE_PROBE == 2 && p.clock_probe && t == 0;
-    long long tp_w0 = 0, tp_c0 = 0, tp_loop = 0;
-    if (tprobe) tp_w0 = (long long)__builtin_amdgcn_s_memrealtime();
 
     // ---- tile prologue: output rows, source rows of every (tap, tile row), tap masks
     if (p.tile_idx && p.tile_bm == BM) {
@@ -351,8 +337,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     };
 
     using S2 = std::integral_constant<int, 2>;
-    const int tp_nsl = nsl;
-    if (tprobe) tp_c0 = (long long)__builtin_readcyclecounter();
     if (nsl > 0) {
         // the slice list is read through a register: lane l holds entry ks_cb + l (refilled every 32 slices), an entry is a
         // v_readlane -- no LDS round trip (+ the in-order wait behind whatever else is queued there) in front of the half-steps
@@ -381,13 +365,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         if (PP && wm == 1) asm volatile("s_barrier" ::: "memory");      // the second wave row runs one phase behind
 
         int sta = 0, stb = 0;                        // stages of the half-step being multiplied (A ring, B ring)
-        unsigned long long ph_t = HPL_PHASE_PROBE == 1 ? __builtin_readcyclecounter() : 0ull, ph_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
-        auto stamp = [&](int k) {
-            if (HPL_PHASE_PROBE != 1) return;
-            const unsigned long long now = __builtin_readcyclecounter();
-            ph_acc[k] += now - ph_t;
-            ph_t = now;
-        };
         // One half-step g = 2*s + h: multiply (A stage sta, B stage stb; slice entry e_cur);
         //   B: LDS-direct loads of the weight fragments of half-step g + NB - 1 (slice kt_b, half hb) -> B stage (stb + NB - 1) % NB
         //   W: split + store half h of slice s + 1 (register set SETW) -> A stage (sta + 2) % 3
@@ -421,13 +398,9 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                     }
                 // the loads of the compute phase before last have landed (in flight: the last compute phase's); fragments here,
                 // the LDS stores of the last compute phase done
-                const unsigned long long ph_issue = HPL_PHASE_PROBE == 1 ? __builtin_readcyclecounter() : 0ull;      // (read behind the wait)
                 wait_vm_lgkm0(inflight_tag);
-                if (HPL_PHASE_PROBE == 1) ph_acc[4] += ph_issue - ph_t;
                 __builtin_amdgcn_sched_barrier(0);
-                stamp(0);
                 asm volatile("s_barrier" ::: "memory");
-                stamp(1);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- compute phase: the 24 MFMAs of the wave's 64 rows and, in their shadow, everything else of the half-step
                 // that does not depend on the barrier: the weight loads three half-steps ahead, index reads + gathered loads,
@@ -475,9 +448,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 }
                 // (own LDS stores: waited for at the end of the next memory phase, one barrier before anybody reads them)
                 __builtin_amdgcn_sched_barrier(0);
-                stamp(2);
                 asm volatile("s_barrier" ::: "memory");
-                stamp(3);
                 __builtin_amdgcn_sched_barrier(0);
                 sta = sta == 2 ? 0 : sta + 1;
                 stb = stb == NB - 1 ? 0 : stb + 1;
@@ -603,13 +574,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             if constexpr (ASETS == 3) { if (sl + 2 < nsl) slice_tail(sl + 2, S2{}); }
         }
         if (PP && wm == 0) asm volatile("s_barrier" ::: "memory");      // (the second wave row's last compute phase)
-        if (tprobe) tp_loop = (long long)__builtin_readcyclecounter() - tp_c0;
-        if (HPL_PHASE_PROBE == 1 && p.clock_probe && (blockIdx.x & 15) == 0 && lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 8 + 4 * wm + k, ph_acc[k]);
-            atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 20 + wm, ph_acc[4]);
-            if (wn == 0) atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 16 + wm, (unsigned long long)(2 * nsl));
-        }
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -701,14 +665,6 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 1,
                   (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - probe_w));
     }
-    if (tprobe) {
-        long long *rec = p.clock_probe + 64 + 4 * (int64_t)blockIdx.x;
-        rec[0] = tp_w0;
-        rec[1] = (long long)__builtin_amdgcn_s_memrealtime();
-        rec[2] = tp_loop;
-        rec[3] = (long long)tp_nsl | ((long long)(__builtin_amdgcn_s_getreg(4 | (31 << 11))) << 16) |
-                 ((long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 48);
-    }
 }
 
 template <int WGN, int F_LDS, int NB = 3>
@@ -759,22 +715,6 @@ extern "C" int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, v
     return HPL_OK;
 }
 
-// Diagnostic: residency of the kernel variants (variant 0: 128x128 F<=8, 1: 128x128 F<=15, 2: 128x256 F<=8, 3: 128x256 F<=15)
-extern "C" int hpl_split3_info(int variant, int *blocks_per_cu, int *lds_bytes, int *vgprs) {
-    HPL_REQUIRE(variant >= 0 && variant < 4 && blocks_per_cu && lds_bytes && vgprs, "hpl_split3_info: bad arguments");
-    const void *fn = variant == 0 ? (const void *)k_gconv3<2, 8> : variant == 1 ? (const void *)k_gconv3<2, 15>
-                   : variant == 2 ? (const void *)k_gconv3w<8, 4> : (const void *)k_gconv3w<15, 4>;
-    hipFuncAttributes at;
-    if (hipFuncGetAttributes(&at, fn) != hipSuccess) { set_error("hpl_split3_info: hipFuncGetAttributes failed"); return HPL_EHIP; }
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, variant < 2 ? 256 : 512, 0) != hipSuccess) {
-        set_error("hpl_split3_info: occupancy query failed");
-        return HPL_EHIP;
-    }
-    *blocks_per_cu = nb; *lds_bytes = (int)at.sharedSizeBytes; *vgprs = at.numRegs;
-    return HPL_OK;
-}
-
 // HPL_MATH=f32 keeps every launch on the fp32 MFMA (A/B runs, parity baselines)
 bool hpl_gc::split3_enabled() {
     static const bool on = !(getenv("HPL_MATH") && std::string(getenv("HPL_MATH")) == "f32");
@@ -785,14 +725,14 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // qualifying launches: row-ordered stencil passes (or dense GEMMs) of wide layers, no scatter / split-K
     if (!split3_enabled() || p.scat || p.C < 32 || p.K > 32768) return false;
     if (p.F > 15 || (p.w_bytes / (p.ldw * 4)) % 8 != 0) return false;
-    static const int min_rows = getenv("HPL_SPLIT3_MIN_ROWS") ? atoi(getenv("HPL_SPLIT3_MIN_ROWS")) : 8192;
+    constexpr int min_rows = 8192;
     // single-pass stencils of the mid-size levels (bcn3_: 9 433 rows x 15 taps x 388 channels) run faster on the fp32 kernel's
     // 64 x 64 tiles (0.31 vs 0.45 ms: a 128-row tile unites many more tap masks); dense launches gain from 8 192 rows on
-    static const int min_rows_stencil = getenv("HPL_SPLIT3_MIN_ROWS_STENCIL") ? atoi(getenv("HPL_SPLIT3_MIN_ROWS_STENCIL")) : 16384;
+    constexpr int min_rows_stencil = 16384;
     // ... unless the launch still fills most of the GPU with 128 x 256 tiles in ONE round (small clouds: at N = 2 048 points the
     // two wide Up convs are 51 x 4 and 68 x 2 tiles -- on the fp32 kernel they were 1.18 + 0.59 ms of a 3.7 ms forward)
-    static const int fill_tiles = getenv("HPL_SPLIT3_FILL_TILES") ? atoi(getenv("HPL_SPLIT3_FILL_TILES")) : 128;
-    static const int floor_rows = getenv("HPL_SPLIT3_FLOOR_ROWS") ? atoi(getenv("HPL_SPLIT3_FLOOR_ROWS")) : 1024;
+    constexpr int fill_tiles = 128;
+    constexpr int floor_rows = 1024;
     if (p.N < 256 || p.M < floor_rows) return false;
     const int64_t tiles256 = cdiv(p.M, BM3) * cdiv(p.N, 256);
     const bool fills = tiles256 >= fill_tiles;
@@ -801,8 +741,8 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // only split over K into enough workgroups for one round (partial tiles in the caller's workspace), else on the fp32 kernel
     int splitk = 1;
     if (p.F > 1 && p.M < min_rows_stencil && !fills) {
-        static const int mid_split = getenv("HPL_SPLIT3_MID_SPLITK") ? atoi(getenv("HPL_SPLIT3_MID_SPLITK")) : 1;
-        static const int mid_min_rows = getenv("HPL_SPLIT3_MID_MIN_ROWS") ? atoi(getenv("HPL_SPLIT3_MID_MIN_ROWS")) : 1024;      // (round 4: from 8 192; N = 2 048 clouds +8 %, N = 8 192 unchanged)
+        constexpr int mid_split = 1;
+        constexpr int mid_min_rows = 1024;      // (round 4: from 8 192; N = 2 048 clouds +8 %, N = 8 192 unchanged)
         if (p.M < mid_min_rows) return false;
         const int64_t tiles = tiles256;
         const int nk_all = (p.K + BK - 1) / BK;
@@ -812,10 +752,10 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     p.tiles_m = (int)cdiv(p.M, BM3);
     // 128 x 256 tiles (8 waves, one workgroup per CU) where N allows: 5-12 % faster than 128 x 128 on every wide launch of
     // the model (profiles/r03c_split3_kernel_ab.txt) although they leave fewer tiles per CU
-    static const int wide = getenv("HPL_SPLIT3_BN") ? atoi(getenv("HPL_SPLIT3_BN")) : 256;
+    constexpr int wide = 256;
     // any N: columns past N are neither loaded (the image's row length bounds the loads) nor stored; the wider tile unless
     // its padding costs more than it gains (N = 580, the data gradient of bcn1_: 3 x 256 = 768 vs 5 x 128 = 640 columns)
-    static const int pct = getenv("HPL_SPLIT3_BN256_PCT") ? atoi(getenv("HPL_SPLIT3_BN256_PCT")) : 108;
+    constexpr int pct = 108;
     const bool bn256 = splitk > 1 || (wide == 256 && cdiv(p.N, 256) * 256 * 100 <= cdiv(p.N, 128) * 128 * pct);
     const int BN = bn256 ? 256 : 128;
     p.tiles_n = (int)cdiv(p.N, BN);
@@ -847,7 +787,7 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     }
     // instances by the taps whose indices a tile stages in LDS: 1 (dense GEMMs), <= 8 (tap-group passes), <= 15
     // HPL_SPLIT3_NB=3: the three-stage pipeline for the 256-wide tile too (A/B runs)
-    static const int nb = getenv("HPL_SPLIT3_NB") ? atoi(getenv("HPL_SPLIT3_NB")) : 4;
+    constexpr int nb = 4;
     if (bn256 && nb == 4) {
         if (p.F == 1) k_gconv3w<1, 4><<<grid, 512, 0, s>>>(p);
         else if (p.F <= 8) k_gconv3w<8, 4><<<grid, 512, 0, s>>>(p);

@@ -118,14 +118,7 @@ int order_of(hpl_lattice *b, const int32_t *nbr, int64_t stride, int F, int64_t 
     const int64_t tiles = cdiv(M, bm);
     int32_t *ti = b->take<int32_t>(tiles * F * bm), *tm = b->take<int32_t>(tiles * 8);
     if (b->overflow) return HPL_ENOMEM;
-    // HPL_ROW_ORDER=1: Morton order of the lattice keys inside every mask group.  Measured (profiles/r03b_traffic_*.txt):
-    // the L2-miss traffic of the dominant launch does not move (1.549 vs 1.547 GB) -- the uses of a source row by its
-    // <= 15 consumers are different taps, i.e. a whole tap's worth of slices apart in time, far beyond what a 4 MB L2
-    // holds -- while the 64-bit sort costs 0.2 ms per lattice; the default is the plain (mask, row id) order.
-    static const bool keyed = getenv("HPL_ROW_ORDER") && atoi(getenv("HPL_ROW_ORDER")) == 1;
-    const int64_t H0 = b->n_vert[0];
-    int rc = keyed ? hpl_tap_order_keyed(nbr, stride, F, M, b->vk[0], 4 * b->n[0], H0, b->vk[1], 4 * b->n[1], p, b->scratch, b->hs)
-                   : hpl_tap_order(nbr, stride, F, M, p, b->scratch, b->hs);
+    int rc = hpl_tap_order(nbr, stride, F, M, p, b->scratch, b->hs);
     if (rc) return rc;
     rc = hpl_tile_index(nbr, stride, F, M, p, bm, ti, tm, b->hs);
     if (rc) return rc;

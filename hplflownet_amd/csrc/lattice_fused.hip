@@ -857,7 +857,7 @@ int enqueue(Plan &plan, Level *lv_stage, int32_t *dims_host, hipEvent_t counts_e
         // lattice launches showed up with 20 % of the GPU's busy time).  384 workgroups per task keep every grid-stride loop
         // short at N = 8 192 (one build alone: 0.76 ms, uncapped 0.78) and take the build's cost in the pipeline to ~0
         // (pairs/s with the build ~ without it; 1-9 % over the uncapped grids depending on the box).
-        static const int64_t max_blocks = getenv("HPL_FUSED_MAX_BLOCKS") ? atoll(getenv("HPL_FUSED_MAX_BLOCKS")) : 384;
+        constexpr int64_t max_blocks = 384;
         auto add = [&](int kind, int level, int job, int64_t nblk) {
             if (l.n >= MAX_TASKS) return;
             nblk = imin(nblk, max_blocks);

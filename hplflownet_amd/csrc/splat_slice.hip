@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t chunk) {
 // vertex's contributor list in CSR order (deterministic, no shuffles, no idle lanes when CV is not
 // a power of two -- the Down layers have CV = 17).  Lanes of one vertex read the same csr words
 // (one L1 broadcast); the feature rows are read as CV consecutive 16-byte words.
-template <typename V>
+template <typename V, int R>
 __global__ void __launch_bounds__(256) k_splat(const float *__restrict__ feat, int64_t ldf, uint32_t CV,
                                                const int32_t *__restrict__ csr_ptr,
                                                const int32_t *__restrict__ csr_pt,
@@ -83,21 +83,24 @@ __global__ void __launch_bounds__(256) k_splat(const float *__restrict__ feat, i
         const float sc = norm ? norm[v] : 1.0f;
         const float *col = feat + (int64_t)cq * VW;
         V acc = ops::zero();
-        int32_t j = b;
-        for (; j + 4 <= e; j += 4) {           // four independent row loads in flight
-            int32_t pt[4];
-            float w[4];
-            V x[4];
+        // R contributors per round, all predicated: the index / weight words of a round are independent loads, then its (up to)
+        // R row words are -- three dependent loads deep for segments of up to R contributors.  (A scalar tail loop over the last 1-3
+        // contributors was two more dependent loads per contributor: the common case on the fine levels, ~3 contributors per vertex.)
+        // Absent slots add w = 0 times 0: the sum and its order are those of the plain loop.
+        for (int32_t j = b; j < e; j += R) {
+            int32_t pt[R];
+            float w[R];
+            V x[R];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { pt[u] = csr_pt[j + u]; w[u] = csr_w[j + u]; }
+            for (int u = 0; u < R; ++u) {
+                const bool ok = j + u < e;
+                pt[u] = ok ? csr_pt[j + u] : -1;
+                w[u] = ok ? csr_w[j + u] : 0.f;
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const V *>(col + (int64_t)pt[u] * ldf);
+            for (int u = 0; u < R; ++u) x[u] = pt[u] >= 0 ? *reinterpret_cast<const V *>(col + (int64_t)pt[u] * ldf) : ops::zero();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ops::fma(acc, w[u], x[u]);
-        }
-        for (; j < e; ++j) {
-            const V x = *reinterpret_cast<const V *>(col + (int64_t)csr_pt[j] * ldf);
-            ops::fma(acc, csr_w[j], x);
+            for (int u = 0; u < R; ++u) ops::fma(acc, w[u], x[u]);
         }
         V *dst = reinterpret_cast<V *>(out + (int64_t)v * ldo + (int64_t)cq * VW);
         acc = ops::scale(acc, sc);
@@ -230,8 +233,8 @@ int splat_launch(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr, 
     const uint32_t total = (uint32_t)(H * cv);
     int chunk;
     const int grid = xcd_grid(imin(cdiv((int64_t)total, 256), 256 * 32), &chunk);
-    if (vec) k_splat<float4><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate);
-    else k_splat<float><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate);
+    if (vec) k_splat<float4, 8><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate);
+    else k_splat<float, 8><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate);
     HPL_CHECK_LAUNCH("hpl_splat");
     return HPL_OK;
 }

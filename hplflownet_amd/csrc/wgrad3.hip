@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
 bool hpl_gc::launch_wgrad3(WParams &p, bool tap, int64_t m_len, hipStream_t s) {
     // qualifying launches: the wide layers (tap mode stencils, dense 1x1 convs) with enough vertices to fill the chip
     static const int on = getenv("HPL_WGRAD3") ? atoi(getenv("HPL_WGRAD3")) : 1;
-    static const int min_rows = getenv("HPL_WGRAD3_MIN_ROWS") ? atoi(getenv("HPL_WGRAD3_MIN_ROWS")) : 8192;
+    constexpr int min_rows = 8192;
     if (!on || !split3_enabled()) return false;
     if (!(tap || (p.F == 1 && !p.nbr))) return false;
     if (p.N < 256 || p.N % 4 != 0 || p.C < 128 || p.C % 4 != 0 || p.M < min_rows) return false;
@@ -276,7 +276,7 @@ bool hpl_gc::launch_wgrad3(WParams &p, bool tap, int64_t m_len, hipStream_t s) {
     const int tiles = (tap ? p.F : 1) * p.c_tiles * p.tiles_n;
     // slabs of the vertex loop: one workgroup per CU at a time; ~8 workgroups per CU over the launch even out the unequal
     // tap lists, each with >= 512 vertices (the atomic epilogue of a 128 x 256 tile costs about 100 vertices' worth)
-    static const int force = getenv("HPL_WGRAD3_SPLITS") ? atoi(getenv("HPL_WGRAD3_SPLITS")) : 0;
+    constexpr int force = 0;
     const int64_t len = tap ? imax(1, m_len / 2) : m_len;
     int64_t splits = imax(1, imin(cdiv(2048, tiles), cdiv(len, 512)));
     // dense layers: equal slabs, so one workgroup per CU in ONE round is the best cut (measured: 25 841 x 1024 x 1024 in 7

@@ -222,7 +222,7 @@ class _FlowNetBase(nn.Module):
     HEAD_IN = None
     #: on a device-built lattice the Down path runs once per PAIR (both clouds stacked), in inference and
     #: in training; False forces the per-cloud path (what reference-format lattices use)
-    pair_batched = not os.environ.get('HPL_NO_PAIR')      # env: A/B switch for benchmarking
+    pair_batched = True
     #: inference on a device-built lattice runs as ONE native call (plan.ForwardPlan: the same launches issued by
     #: csrc/executor.hip instead of ~130 Python round trips); False forces the Python path below
     native_forward = not os.environ.get('HPL_NO_NATIVE')

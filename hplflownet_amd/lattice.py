@@ -136,14 +136,10 @@ class GenerateDataUnsymmetric(object):
             lv.blur = PairBlur(blur_p, H[0]) if blur_p is not None else [None, None]
             if blur_p is not None:
                 lv.blur[0].vertices_per_point = H[0] / float(n[0])
-                lv.blur.pair.keys = (vk[0], H[0], vk[1])
-                lv.blur[0].keys = (vk[0], H[0], None)
             lv.emg = emg
             lv.emg_pair = emg_p
             lv.pair = ops.PairTables(lv.clouds[0], lv.clouds[1])
             lv.corr1 = NbrTable(corr1) if corr1 is not None else None
-            if lv.corr1 is not None:
-                lv.corr1.keys = (vk[0], H[0], None)
             if cf_r != -1 and cc_r == bcn_r:
                 lv.corr1 = lv.blur[0]          # same offsets, same table: share it
             lv.corr2 = NbrTable(corr2) if corr2 is not None else None
@@ -495,8 +491,7 @@ class NativeBuilder(object):
         # fused driver (csrc/lattice_fused.hip): the whole build enqueued by hpl_lattice_begin, one read-back per pair.
         # HPL_LATTICE_FUSED=0 keeps the staged driver (one read-back per level); specs it cannot build stay staged too.
         self.fused = os.environ.get('HPL_LATTICE_FUSED', '1') != '0' and \
-            all(int(lvl[1]) == 1 and (int(lvl[2]), int(lvl[3])) in ((-1, -1), (1, 1)) for lvl in sfm) and \
-            os.environ.get('HPL_ROW_ORDER', '0') != '1'
+            all(int(lvl[1]) == 1 and (int(lvl[2]), int(lvl[3])) in ((-1, -1), (1, 1)) for lvl in sfm)
         sp.fused = 1 if self.fused else 0
         self.spec = sp
         self.free = []

@@ -132,21 +132,14 @@ class PairTables(object):
         return out
 
 
-def tap_order(nbr, keys=None):
+def tap_order(nbr):
     """int32 [F<=15, M] neighbour table -> int32 [M] permutation sorting the rows by tap-presence mask
-    (deterministic: ties by row id).  keys = (vkeys0 [4, >=H0], H0, vkeys1 [4, >=M-H0] or None): the lattice key of
-    every vertex -- rows of one mask group then follow the Morton code of their key (hpl_tap_order_keyed)."""
+    (deterministic: ties by row id)."""
     F, M = nbr.shape
     L = _lib.load()
     perm = torch.empty(M, dtype=torch.int32, device=nbr.device)
     scratch = torch.empty((int(L.hpl_tap_order_scratch_ints(M)) + 1) // 2, dtype=torch.int64, device=nbr.device)
-    if keys is None or os.environ.get('HPL_ROW_ORDER') != '1':          # (the Morton order buys nothing: csrc/lattice_builder.hip)
-        check(L.hpl_tap_order(ptr(nbr), nbr.stride(0), F, M, ptr(perm), ptr(scratch), stream()), 'hpl_tap_order')
-    else:
-        vk0, H0, vk1 = keys
-        check(L.hpl_tap_order_keyed(ptr(nbr), nbr.stride(0), F, M, ptr(vk0), vk0.stride(0), H0, ptr(vk1),
-                                    vk1.stride(0) if vk1 is not None else 0, ptr(perm), ptr(scratch), stream()),
-              'hpl_tap_order_keyed')
+    check(L.hpl_tap_order(ptr(nbr), nbr.stride(0), F, M, ptr(perm), ptr(scratch), stream()), 'hpl_tap_order')
     return perm
 
 
@@ -347,7 +340,7 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
         if CLOCK_PROBE is not None and N > 64 and M >= 16384:
             d.clock_probe = CLOCK_PROBE.data_ptr()
     st = stream()
-    if split_k and not _NO_SPLITK and scat is None and M * N <= _SPLITK_MAX_ELEMS:
+    if split_k and scat is None and M * N <= _SPLITK_MAX_ELEMS:
         ws = _splitk_workspace(A.device, st)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     lib = _lib.load()
@@ -364,7 +357,6 @@ CLOCK_PROBE = None
 
 _SPLITK_MAX_ELEMS = 8 << 20          # split-K is offered for outputs of <= 8 M elements (the launch picks the count)
 _SPLITK_WS = {}
-_NO_SPLITK = bool(os.environ.get('HPL_NO_SPLITK'))      # A/B switch for benchmarking
 
 
 def _splitk_workspace(device, st):

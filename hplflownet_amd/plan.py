@@ -468,7 +468,7 @@ class ForwardPlan(object):
         self.hint = model.lattice_hint()
         self._ws = {}            # workspaces, one per (stream, slot)
         self._slot = 0
-        self.slots = int(os.environ.get('HPL_PLAN_SLOTS', '4'))      # forwards in flight before a workspace is reused (bench: 3 forward streams)
+        self.slots = 4          # forwards in flight before a workspace is reused (bench: 3 forward streams)
         self._fence = {}
 
     def _program(self, model):

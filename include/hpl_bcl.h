@@ -169,10 +169,6 @@ int hpl_weight_unlayout_batch(const hpl_relayout_job *jobs /* DEVICE */, int njo
  * mid = bf16_rne(w - hi), lo = bf16_rne(w - hi - mid): w == hi + mid + lo exactly.  plane_stride >= k_rows*ldw*2. */
 int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride, hplStream stream);
 
-/* Diagnostic: residency of the split-operand kernel variants (0: 128x128 tile, <= 8 taps; 1: 128x128, <= 15 taps;
- * 2: 128x256, <= 8; 3: 128x256, <= 15): workgroups per CU by the occupancy API, static LDS bytes, registers. */
-int hpl_split3_info(int variant, int *blocks_per_cu, int *lds_bytes, int *vgprs);
-
 /* inverse scatter for weight gradients: W[base + r*sr + q*sq + f*sf] (+)= Wt[(f*R + r)*ldw + q] */
 int hpl_weight_unlayout(const float *Wt, int64_t ldw, int R, int Q, int F, float *W, int64_t base,
                         int64_t sr, int64_t sq, int64_t sf, int accumulate, hplStream stream);
@@ -253,15 +249,6 @@ typedef struct hpl_gconv_desc {
 int64_t hpl_tap_order_scratch_ints(int64_t M);
 int hpl_tap_order(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, int32_t *perm,
                   int32_t *scratch, hplStream stream);
-/* The same with a locality-preserving order inside every mask group: rows follow the Morton code of their lattice
- * key (transforms/transforms.py:179-192 `last_pc`: the key of every vertex), so that a tile of consecutive rows is a
- * spatially compact set of vertices and neighbouring tiles gather overlapping source rows.  Row m < H0 is vertex m
- * of the first key array (coordinate j at vkeys0[j*vstride0 + m], as hpl_lattice_hash writes them), row m >= H0
- * vertex m - H0 of the second (the stacked pair tables); vkeys1 may be NULL when M <= H0. */
-int hpl_tap_order_keyed(const int32_t *nbr, int64_t nbr_stride, int F, int64_t M, const int32_t *vkeys0,
-                        int64_t vstride0, int64_t H0, const int32_t *vkeys1, int64_t vstride1, int32_t *perm,
-                        int32_t *scratch, hplStream stream);
-
 /* Per-tile gather indices of a row-ordered launch: tile j covers output rows row_perm[j*BM .. j*BM+BM) (identity
  * when row_perm is NULL); tile_idx[j][f][r] = nbr[f][row_perm[j*BM + r]] (-1 past M), tile_mask[j][0] = taps present
  * in the tile, [2 + b] = taps present in its b-th block of 32 rows, [j][6] = the tile that is scheduled j-th (most taps
@@ -298,18 +285,6 @@ int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, const int32_t *
                     const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
                     const int32_t *tap_m, const int32_t *tap_row, const int32_t *tap_ptr,
                     int64_t tap_max, float *dbias, hplStream stream);
-
-/* Diagnostic: `blocks` workgroups of 4 waves each issue iters*64 v_mfma_f32_32x32x2_f32 per wave
- * with no memory traffic; out needs blocks*256 floats.  flops = blocks*4*|iters|*64*4096.
- * iters > 0: four independent accumulators per wave; iters < 0: ONE accumulator (every MFMA
- * depends on the previous one, as in the 32x32-per-wave tiles of the gather-GEMM). */
-int hpl_mfma_probe(float *out, int blocks, int iters, hplStream stream);
-/* The same instruction stream (four accumulators per wave) on operands that change with every MFMA: mode 1 = eight
- * pseudo-random register values per lane and operand, rotated; mode 2 = operands read from LDS with two ds_read_b32
- * per MFMA, as in the gather-GEMM loop.  The chip clocks to its power budget: real data toggles the multipliers and
- * lowers the sustained clock below what hpl_mfma_probe's constant operands reach.  clk (DEVICE, optional):
- * clk[0] = shader cycles, clk[1] = 100 MHz wall ticks spent by workgroup 0 in the MFMA loop. */
-int hpl_mfma_probe_data(float *out, int blocks, int iters, int mode, long long *clk, hplStream stream);
 
 /* out[n] = sum_m X[m*ld + n]   (bias gradients) */
 int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStream stream);

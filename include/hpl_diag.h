@@ -1,0 +1,26 @@
+/*
+ * hpl_diag.h -- libhplbcl_diag.so: measurement helpers beside the product library (include/hpl_bcl.h).  Nothing of the hot path
+ * links or loads this library; bench.py and tools/ do.  stream: a hipStream_t as void*.  Returns 0, -1 (bad argument), -2 (HIP).
+ */
+#ifndef HPL_DIAG_H
+#define HPL_DIAG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Diagnostic: `blocks` workgroups of 4 waves each issue iters*64 v_mfma_f32_32x32x2_f32 per wave
+ * with no memory traffic; out needs blocks*256 floats.  flops = blocks*4*|iters|*64*4096.
+ * iters > 0: four independent accumulators per wave; iters < 0: ONE accumulator (every MFMA
+ * depends on the previous one, as in the 32x32-per-wave tiles of the gather-GEMM). */
+int hpl_mfma_probe(float *out, int blocks, int iters, void *stream);
+/* The same instruction stream (four accumulators per wave) on operands that change with every MFMA: mode 1 = eight
+ * pseudo-random register values per lane and operand, rotated; mode 2 = operands read from LDS with two ds_read_b32
+ * per MFMA, as in the gather-GEMM loop.  The chip clocks to its power budget: real data toggles the multipliers and
+ * lowers the sustained clock below what hpl_mfma_probe's constant operands reach.  clk (DEVICE, optional):
+ * clk[0] = shader cycles, clk[1] = 100 MHz wall ticks spent by workgroup 0 in the MFMA loop. */
+int hpl_mfma_probe_data(float *out, int blocks, int iters, int mode, long long *clk, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPL_DIAG_H */

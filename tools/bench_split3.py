@@ -15,12 +15,6 @@ pc1, pc2, sf = synthetic_pair(8192, 0)
 gen = H.GenerateDataUnsymmetric(types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP), device=dev)
 t1 = torch.from_numpy(pc1.T.copy()).to(dev); t2 = torch.from_numpy(pc2.T.copy()).to(dev)
 lat = gen.build(t1, t2)
-import ctypes
-from hplflownet_amd import _lib
-for v in range(4):
-    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    _lib.check(_lib.load().hpl_split3_info(v, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), 'hpl_split3_info')
-    print('variant %d: %d workgroups/CU, %d B LDS, %d registers' % (v, a.value, b.value, c.value))
 reps = int(os.environ.get('REPS', '5'))
 rounds = int(os.environ.get('ROUNDS', '3'))
 cases = [('dgrad bcn1_ g0', 0, 1024, 580, 0, 8), ('dgrad bcn2_ g0', 1, 512, 324, 0, 8), ('bcn1_ g0', 0, 580, 1024, 0, 8), ('bcn1_ g1', 0, 580, 1024, 8, 15), ('bcn2_ g0', 1, 324, 512, 0, 8),

@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hplflownet_amd import _lib
-L = _lib.load()
+L = _lib.load_diag()
 for blocks in (256, 512, 1024):
     out = torch.empty(blocks * 256, device='cuda')
     iters = 4000
