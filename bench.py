@@ -424,6 +424,7 @@ def host_report(host, steps, threaded=False):
     spin = lat_mod.WAIT['s'] * 1e3 / steps
     d['lattice_wait_ms'] = d['lattice_build_ms'] if threaded else spin
     d['lattice_producer_idle_ms'] = spin if threaded else 0.0
+    d['lattice_producer_busy_ms'] = lat_mod.BUSY['s'] * 1e3 / steps if threaded else 0.0      # CPU time of the producer thread per step
     d['forward_wait_ms'] = plan_mod.WAIT['s'] * 1e3 / steps
     d['busy_ms'] = d['lattice_build_ms'] + d['forward_enqueue_ms'] - d['lattice_wait_ms'] - d['forward_wait_ms']
     return d
@@ -694,7 +695,7 @@ def main():
         timers.only = {dominant}
         host = dict.fromkeys(host, 0.0)
         from hplflownet_amd import lattice as _lat_mod, plan as _plan_mod
-        _lat_mod.WAIT['s'] = _plan_mod.WAIT['s'] = 0.0
+        _lat_mod.WAIT['s'] = _plan_mod.WAIT['s'] = _lat_mod.BUSY['s'] = 0.0
         plan = model.forward_plan() if native else None
         if plan is not None:
             from hplflownet_amd.plan import TAG_WIDE_BLUR

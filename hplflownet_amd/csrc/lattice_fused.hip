@@ -858,8 +858,9 @@ int enqueue(Plan &plan, Level *lv_stage, int32_t *dims_host, hipEvent_t counts_e
         // short at N = 8 192 (one build alone: 0.76 ms, uncapped 0.78) and take the build's cost in the pipeline to ~0
         // (pairs/s with the build ~ without it; 1-9 % over the uncapped grids depending on the box).
         constexpr int64_t max_blocks = 384;
+        bool dropped = false;
         auto add = [&](int kind, int level, int job, int64_t nblk) {
-            if (l.n >= MAX_TASKS) return;
+            if (l.n >= MAX_TASKS) { dropped = true; return; }
             nblk = imin(nblk, max_blocks);
             Task &k = l.t[l.n++];
             k.kind = kind; k.level = level; k.job = job; k.blk0 = blk; k.nblk = (int)nblk;
@@ -910,6 +911,8 @@ int enqueue(Plan &plan, Level *lv_stage, int32_t *dims_host, hipEvent_t counts_e
                 break;
             }
         }
+        // (shipped specs peak at 14 tasks per launch: a spec that needs more must fail here, not produce incomplete tables)
+        HPL_REQUIRE(!dropped, "hpl_lattice_begin: launch %d of the fused build needs more than %d tasks", t, MAX_TASKS);
         if (l.n == 0) continue;
         static const int split = getenv("HPL_FUSED_SPLIT") ? atoi(getenv("HPL_FUSED_SPLIT")) : 0;
         if (split) {        // diagnostic: every task as a launch of its own, so that a kernel trace times the tasks

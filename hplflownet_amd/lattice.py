@@ -37,6 +37,8 @@ def _filter_size(radius, d1=4):
 
 #: seconds the pipeline's host thread spent idle, waiting for vertex counts from the GPU (bench.py reports it)
 WAIT = {'s': 0.0}
+#: CPU seconds the producer thread of a LatticePipeline spent driving builds (bench.py reports it per step)
+BUSY = {'s': 0.0}
 
 class GenerateDataUnsymmetric(object):
     def __init__(self, args, device='cuda', wide_up=None):
@@ -258,7 +260,10 @@ class LatticePipeline(object):
                 try:
                     torch.cuda.set_device(dev)
                     for _ in range(count):
-                        if self._stop or not put(self._get()):
+                        c0 = time.thread_time()
+                        item = self._get()
+                        BUSY['s'] += time.thread_time() - c0           # CPU time of this thread (its waits for read-backs excluded)
+                        if self._stop or not put(item):
                             return
                 except BaseException as e:          # noqa: B902 -- handed to the consumer
                     put(e)
@@ -266,11 +271,21 @@ class LatticePipeline(object):
             self._thread.start()
 
     def close(self):
-        """Stop the producer thread (if any) and wait for it: call when the consumer abandons the pipeline early."""
+        """Stop the producer thread (if any) and wait for it, then finish the builds still in flight and give their native
+        builder handles back (each holds pinned staging memory and events): call when the consumer abandons the pipeline early."""
         self._stop = True
         if self._thread is not None:
-            self._thread.join(timeout=5.0)
+            self._thread.join()              # (the thread leaves its loop at the next put(): _stop is set)
             self._thread = None
+        while self._inflight:
+            b = self._inflight.popleft()
+            try:
+                b.finish()                   # the launches of a native build were all enqueued by begin: this waits for one read-back
+            except Exception:
+                pass
+            if getattr(b, 'handle', None) is not None:
+                b.nb.release(b.handle)
+                b.handle = None
 
     def _top_up(self):
         depth = self.depth

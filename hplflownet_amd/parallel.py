@@ -65,7 +65,10 @@ def pin_host_threads(local_rank, local_world, device_index=None):
     what matters at 8 ranks is that no rank's threads migrate across sockets or pile up on another rank's cores.
     Returns a dict describing what was done (for the bench line)."""
     info = {'numa_node': None, 'cpus': None, 'pinned': False}
-    if not hasattr(os, 'sched_setaffinity') or os.environ.get('HPL_NO_PIN'):
+    # Off unless HPL_PIN=1: the slot arithmetic below assumes the GPUs are spread evenly and contiguously over the NUMA nodes, which
+    # has never been checked on a real 8-GPU node (the builder's boxes have one GPU) -- a wrong guess would put two ranks on one
+    # core slice silently, in the very run it is meant to help.
+    if not hasattr(os, 'sched_setaffinity') or os.environ.get('HPL_PIN') != '1':
         return info
     try:
         allowed = sorted(os.sched_getaffinity(0))

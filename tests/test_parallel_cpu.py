@@ -74,6 +74,7 @@ def _worker(rank, world, port, out_dir):
     P.barrier()
     tmax = P.max_over_ranks(1.0 + rank)
     gathered = P.gather_floats([10.0 + rank, -1.0 * rank])
+    os.environ['HPL_PIN'] = '1'                      # (off by default until validated on an 8-GPU node)
     pin = P.pin_host_threads(rank, world)            # (no GPU here: an even split of the visible cores by local rank)
     affinity = sorted(os.sched_getaffinity(0))
     torch.save({'seeds': seeds, 'gathered': gathered, 'pin': pin, 'affinity': affinity, 'grads': [p.grad.clone() for p in model.parameters()], 'same': same,
@@ -119,7 +120,10 @@ def test_cpulist_and_single_rank_helpers():
     assert P.gather_floats([1.5, 2]) == [[1.5, 2.0]]
     before = sorted(os.sched_getaffinity(0))
     try:
+        assert not P.pin_host_threads(1, 4)['pinned']                # default: off
+        os.environ['HPL_PIN'] = '1'
         info = P.pin_host_threads(1, 4)
+        os.environ.pop('HPL_PIN')
         if info['pinned']:
             now = sorted(os.sched_getaffinity(0))
             assert set(now) <= set(before) and len(now) >= min(2, len(before))

@@ -3,7 +3,7 @@
 # forward.  Outputs under gpurun_out/; copy the summaries into profiles/ (mfma_pmc.json / pmc_traffic.json are what bench.py reads).
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-R=${1:-r04}
+R=${1:-r05}
 export TMPDIR=/tmp
 python bench.py > gpurun_out/${R}_bench_plain.json 2> gpurun_out/${R}_bench_plain.err
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_driver_cmd.json 2> /dev/null
