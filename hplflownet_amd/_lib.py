@@ -26,6 +26,12 @@ class RelayoutJob(ctypes.Structure):
                 ('mirror', ctypes.c_int32), ('ldw', ctypes.c_int64)]
 
 
+class Split3Job(ctypes.Structure):
+    """Mirror of `hpl_split3_job`."""
+    _fields_ = [('Wt', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('k_rows', ctypes.c_int64), ('ldw', ctypes.c_int64),
+                ('plane_stride', ctypes.c_int64)]
+
+
 class GConvDesc(ctypes.Structure):
     """Mirror of `struct hpl_gconv_desc` (include/hpl_bcl.h)."""
     _fields_ = [('A', c_vp), ('lda', c_i64), ('rows_a', c_i64),
@@ -112,6 +118,7 @@ _SIGNATURES = {
                                            c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
     'hpl_weight_relayout_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp, c_vp]),
     'hpl_weight_split3': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    'hpl_weight_split3_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_vp]),
     'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,
                                            c_i64, c_i64, c_i64, ctypes.c_int, c_vp]),
     'hpl_tap_order_scratch_ints': (c_i64, [c_i64]),

@@ -704,6 +704,37 @@ __global__ void __launch_bounds__(256) k_weight_split3(const float *__restrict__
 
 }  // namespace
 
+// many images in one launch (a training step re-splits ~20 images after every optimiser step): blockIdx.y = job
+__global__ void __launch_bounds__(256) k_weight_split3_batch(const hpl_split3_job *__restrict__ jobs) {
+    const hpl_split3_job jb = jobs[blockIdx.y];
+    const float *Wt = jb.Wt;
+    unsigned char *dst = reinterpret_cast<unsigned char *>(jb.dst);
+    const int64_t ldw = jb.ldw, total = (jb.k_rows / 8) * ldw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t kb = i / ldw, n = i - kb * ldw;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = Wt[(kb * 8 + j) * ldw + n];
+        u32x4 h, m, l;
+        unsigned a, b, c;
+        split2(x[0], x[1], a, b, c); h.x = a; m.x = b; l.x = c;
+        split2(x[2], x[3], a, b, c); h.y = a; m.y = b; l.y = c;
+        split2(x[4], x[5], a, b, c); h.z = a; m.z = b; l.z = c;
+        split2(x[6], x[7], a, b, c); h.w = a; m.w = b; l.w = c;
+        *reinterpret_cast<u32x4 *>(dst + i * 16) = h;
+        *reinterpret_cast<u32x4 *>(dst + jb.plane_stride + i * 16) = m;
+        *reinterpret_cast<u32x4 *>(dst + 2 * jb.plane_stride + i * 16) = l;
+    }
+}
+
+extern "C" int hpl_weight_split3_batch(const hpl_split3_job *jobs, int njobs, int64_t max_elems, hplStream stream) {
+    HPL_REQUIRE(jobs && njobs > 0 && njobs <= 65535 && max_elems > 0, "hpl_weight_split3_batch: bad arguments");
+    dim3 grid((unsigned)imin(cdiv(max_elems / 8, 256), 2048), (unsigned)njobs);
+    k_weight_split3_batch<<<grid, 256, 0, to_stream(stream)>>>(jobs);
+    HPL_CHECK_LAUNCH("hpl_weight_split3_batch");
+    return HPL_OK;
+}
+
 extern "C" int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride,
                                  hplStream stream) {
     HPL_REQUIRE(Wt && dst && k_rows > 0 && k_rows % 8 == 0 && ldw > 0 && plane_stride >= k_rows * ldw * 2 &&

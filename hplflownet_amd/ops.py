@@ -491,8 +491,8 @@ class WeightBank(object):
             self.dirty = True
         return job
 
-    def refresh(self):
-        """One launch: every recorded image from the current parameter values."""
+    def refresh(self, lo=0, hi=None):
+        """One launch: every recorded image (or the images of jobs [lo, hi) in registration order) from the current parameter values."""
         if not self.jobs:
             return
         dev = next(iter(self.jobs.values()))[0].device
@@ -507,14 +507,19 @@ class WeightBank(object):
                 job[2] = prefix[-1]
                 prefix.append(prefix[-1] + job[3])
             self.total = prefix[-1]
+            self.prefix_host = prefix
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self.dev_jobs = raw.to(dev)
             self.dev_prefix = torch.tensor(prefix, dtype=torch.int64, device=dev)
             self.buf = torch.empty(self.total, dtype=torch.float32, device=dev)
             self.dirty = False
-        check(_lib.load().hpl_weight_relayout_batch(ptr(self.dev_jobs), len(self.jobs), ptr(self.dev_prefix),
-                                                    self.total, ptr(self.buf), stream()), 'hpl_weight_relayout_batch')
-        for job in self.jobs.values():
+        hi = len(self.jobs) if hi is None else hi
+        if hi <= lo:
+            return
+        check(_lib.load().hpl_weight_relayout_batch(self.dev_jobs.data_ptr() + lo * ctypes.sizeof(RelayoutJob), hi - lo,
+                                                    self.dev_prefix.data_ptr() + 8 * lo, self.prefix_host[hi] - self.prefix_host[lo],
+                                                    ptr(self.buf), stream()), 'hpl_weight_relayout_batch')
+        for job in list(self.jobs.values())[lo:hi]:
             job[4] = job[0]._version
 
 

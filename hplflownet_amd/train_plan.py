@@ -320,6 +320,7 @@ class TrainPlan(ForwardPlan):
     def _program(self, model):
         P = build_program(model, self.bank)
         self.n_fwd = len(P.ops)
+        self._n_fwd_jobs, self._n_fwd_weights = len(self.bank.jobs), len(P.weights)      # what the forward needs of the bank
         B = _Backward(P, model, self.params)
         B.leaf = next(o.out.buf for o in P.ops if o.kind == 5)          # the stacked input clouds (HPL_OP_LOAD): no gradient
         B.emit()
@@ -420,13 +421,48 @@ class TrainPlan(ForwardPlan):
         lat._train_tables = (arr, n, hold)
         return lat._train_tables
 
+    def _split_tables(self):
+        """Device tables of hpl_weight_split3_batch: the split images the forward reads / the ones only the backward reads."""
+        from ._lib import Split3Job
+        out = []
+        for sel in (lambda i: i < self._n_fwd_weights, lambda i: i >= self._n_fwd_weights):
+            items = [(img, w3) for i, (img, w3) in self._split3.items() if sel(i)]
+            if not items:
+                out.append(None)
+                continue
+            arr = (Split3Job * len(items))()
+            for a, (img, w3) in zip(arr, items):
+                a.Wt, a.dst, a.k_rows, a.ldw, a.plane_stride = img.data_ptr(), w3.data_ptr(), img.shape[0], img.shape[1], w3.stride(0)
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.gflat.device)
+            out.append((dev, len(items), max(img.numel() for img, _ in items)))
+        return out
+
     def refresh_weights(self):
-        """Weight images (one launch), their split planes, combined biases: from the current parameter values."""
-        self.bank.refresh()
-        for img, w3 in self._split3.values():
-            ops.weight_split3(img, out=w3)
+        """Start of a step.  On the current stream: the images the FORWARD reads (one re-layout launch, one split launch, the combined
+        biases).  On the side stream, beside the forward: the images only the backward reads, and the zeroing of the gradient
+        arenas -- the backward program waits for `self._bwd_ready`."""
+        if getattr(self, '_split_tabs', None) is None:
+            self._split_tabs = self._split_tables()
+        L = self._lib
+
+        def split(tab):
+            if tab is not None:
+                check(L.hpl_weight_split3_batch(tab[0].data_ptr(), tab[1], tab[2], stream()), 'hpl_weight_split3_batch')
+        main = torch.cuda.current_stream()
+        side = self._side if self._side is not None else main
+        if side is not main:
+            side.wait_stream(main)                # (the optimiser step of the last step, the gradients' last readers)
+        self.bank.refresh(0, self._n_fwd_jobs)
+        split(self._split_tabs[0])
         for t, (a, b) in self.prog.combined:
             torch.add(a.detach(), b.detach(), out=t)
+        with torch.cuda.stream(side):
+            self.bank.refresh(self._n_fwd_jobs, None)
+            split(self._split_tabs[1])
+            self.gflat.zero_()
+            self.gimg.zero_()
+            self._bwd_ready = torch.cuda.Event()
+            self._bwd_ready.record(side)
 
     @torch.no_grad()
     def step(self, pc1, pc2, sf, lat):
@@ -454,8 +490,6 @@ class TrainPlan(ForwardPlan):
             del ws
             ws = self._ws['train'] = torch.empty(int(need * 1.3), dtype=torch.uint8, device=p1.device)
         self.refresh_weights()
-        self.gflat.zero_()
-        self.gimg.zero_()
         out = torch.empty((p1.shape[1], 3), dtype=torch.float32, device=p1.device)
         st = stream()
         side = self._side.cuda_stream if self._side is not None else None
@@ -465,13 +499,15 @@ class TrainPlan(ForwardPlan):
         def run(lo, hi, join):
             check(self._lib.hpl_plan_run_range(self.handle, arr, n, ptr(p1), ptr(p2), ptr(s), ptr(out), ptr(self.loss), ws.data_ptr(),
                                                ws.numel(), st, side, lo, hi, join), 'hpl_plan_run_range')
+        run(0, self.n_fwd, 0)
+        torch.cuda.current_stream().wait_event(self._bwd_ready)          # the backward's weight images, the zeroed gradient arenas
         if not self.reducer._active():
-            run(0, n_ops, 1)
+            run(self.n_fwd, n_ops, 1)
         else:
             # several ranks: the program is issued in pieces that end with a bucket's un-layout, and the bucket's all-reduce starts
             # behind it -- on the side stream when there is one (the un-layout ran there): the main stream does not wait for a
             # weight gradient before the end of the step.  Every rank runs the same program: same order of collectives everywhere.
-            lo = 0
+            lo = self.n_fwd
             for k, hi in enumerate(self.cuts):
                 run(lo, hi, 0)
                 if self._side is not None:

@@ -168,6 +168,14 @@ int hpl_weight_unlayout_batch(const hpl_relayout_job *jobs /* DEVICE */, int njo
  * one output column are one 16-byte MFMA B fragment), plane p at dst + p*plane_stride bytes; hi = bf16_rne(w),
  * mid = bf16_rne(w - hi), lo = bf16_rne(w - hi - mid): w == hi + mid + lo exactly.  plane_stride >= k_rows*ldw*2. */
 int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride, hplStream stream);
+/* The same for many images in one launch (a training step re-splits every wide image after the optimiser step): jobs in DEVICE
+ * memory, max_elems = the largest k_rows * ldw among them (sizes the grid). */
+typedef struct hpl_split3_job {
+    const float *Wt;
+    void *dst;
+    int64_t k_rows, ldw, plane_stride;
+} hpl_split3_job;
+int hpl_weight_split3_batch(const hpl_split3_job *jobs /* DEVICE */, int njobs, int64_t max_elems, hplStream stream);
 
 /* inverse scatter for weight gradients: W[base + r*sr + q*sq + f*sf] (+)= Wt[(f*R + r)*ldw + q] */
 int hpl_weight_unlayout(const float *Wt, int64_t ldw, int R, int Q, int F, float *W, int64_t base,

@@ -82,7 +82,7 @@ def test_executor_struct_layouts_match_header(tmp_path):
         pytest.skip('no C compiler')
     mirrors = {'hpl_ref': _lib.Ref, 'hpl_buf': _lib.Buf, 'hpl_weight': _lib.Weight, 'hpl_op': _lib.Op,
                'hpl_level_tables': _lib.LevelTables, 'hpl_gconv_desc': _lib.GConvDesc, 'hpl_relayout_job': _lib.RelayoutJob,
-               'hpl_lattice_spec': _lib.LatticeSpec}
+               'hpl_lattice_spec': _lib.LatticeSpec, 'hpl_split3_job': _lib.Split3Job}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hpl_bcl.h"', 'int main(void) {']
     for cname, cls in mirrors.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
