@@ -15,6 +15,7 @@ def main():
     firsts = [i for i, r in enumerate(rows) if 'k_weight_relayout_batch' in r[0]]
     # the last COMPLETE step: between the last two re-layouts that are followed by a k_epe3d
     starts = [i for i in firsts if any('k_epe3d' in r[0] for r in rows[i:i + 400])]
+    starts = [i for k, i in enumerate(starts) if k == 0 or i - starts[k - 1] > 60]       # (a step re-lays its images in two launches)
     lo = starts[-2] if len(starts) >= 2 else starts[-1]
     hi = starts[-1] if len(starts) >= 2 else len(rows)
     sel = rows[lo:hi]
