@@ -193,6 +193,13 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
                                                                         acc[i][j], 0, 0, 0);
     };
 
+    // ROUND 5: the wait in front of the split + store is a FULL drain (vmcnt(0)), not "all but the newest three loads".  With the
+    // counted wait the kernel was correct alone and WRONG beside memory-bound kernels of another stream (weight gradients on the
+    // side stream of the training step; reproduced in isolation against a stream of elementwise kernels: relative error 2-4,
+    // tools/.. tests/test_gpu_wgrad3.py::test_concurrent_streams): whenever the rows of stage st+2 were still in flight while
+    // stage st+1 was split and stored, results went wrong -- also with the rows of st+1 known to have landed (a drain at the top
+    // of the step did not help, a drain here does), so the in-order-completion argument below is not the whole story on this
+    // chip.  Cost of the drain: < 1 % (the 24 MFMAs of a step cover the latency of the loads issued in front of them).
     // Step st multiplies LDS stage st & 1.  In flight at its start, oldest first: the indices of st+2, the rows of st+1.
     //   1. issue the index loads of st+3                        2. wait for the indices of st+2 (the oldest 3), issue its rows
     //   3. multiply                                             4. wait for the rows of st+1, split + store them into the other stage
@@ -221,7 +228,7 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
         pin_idx(ix_cur);
         issue_rows(fill, ix_cur, st + 2);      // rows(st+1), idx(st+3), rows(st+2)
         multiply(cur);
-        wait_vm(N6{});
+        wait_vm(N0{});
         pin_rows(ready);
         store_lds(cur ^ 1, ready);
         // the split of the next stage in the shadows of this stage's MFMAs (one basic block: nothing here is conditional)

@@ -489,3 +489,67 @@ def test_fast_and_generic_epilogues_are_bit_identical():
     assert len(got[0]) == len(got[1]) == 5
     for a, b in zip(*got):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize('kind', ['gconv_f32_stencil', 'gconv_f32_dense_splitk', 'gconv3_groups', 'gconv3_dense', 'wgrad_f32', 'splat', 'slice'])
+def test_results_do_not_depend_on_what_runs_beside_them(kind):
+    """Every kernel with hand-counted load waits (buffer loads the compiler's s_waitcnt bookkeeping does not see) on a side stream
+    while memory-bound kernels of another stream saturate HBM: the same result as alone.  (This disturbance exposed the
+    split-operand weight gradient in round 5, tests/test_gpu_wgrad3.py::test_concurrent_streams; the others passed it.)"""
+    import torch
+    from hplflownet_amd import ops
+    g = torch.Generator().manual_seed(2)
+    dev = 'cuda'
+    if kind in ('gconv_f32_stencil', 'wgrad_f32'):
+        M, C, N, F = 70000, 68, 64, 15
+    elif kind == 'gconv_f32_dense_splitk':
+        M, C, N, F = 1787, 260, 128, 1
+    elif kind == 'gconv3_groups':
+        M, C, N, F = 26000, 580, 1024, 8
+    elif kind == 'gconv3_dense':
+        M, C, N, F = 8192, 1024, 1024, 1
+    else:
+        M, C, N, F = 52000, 68, 68, 4
+    A = torch.randn(M, C, generator=g).to(dev)
+    nbr = None
+    if F > 1:
+        nbr = torch.randint(0, M, (F, M), generator=g).int()
+        nbr[torch.rand(F, M, generator=g) < 0.4] = -1
+        nbr = nbr.to(dev)
+    if kind.startswith('gconv'):
+        W = (torch.randn(N, C, F, generator=g) * 0.03).to(dev)
+        Wt = ops.weight_relayout(W, C, N, F, F, C * F, 1)
+        kw = {}
+        if kind.startswith('gconv3'):
+            kw['Wt3'] = ops.weight_split3(Wt)
+            if F > 1:
+                perm = ops.tap_order(nbr)
+                kw.update(row_perm=perm, tiles=ops.tile_index(nbr, perm, BM=128))
+        fn = lambda: ops.gconv_raw(A, nbr, M, C, F, Wt, N, **kw)
+    elif kind == 'wgrad_f32':
+        dY = torch.randn(M, N, generator=g).to(dev)
+        fn = lambda: ops.wgrad_raw(A, nbr, M, C, F, dY, N)
+    else:
+        H = 17000
+        off = torch.randint(0, H, (4, M), generator=g).int().to(dev)
+        bary = torch.rand(4, M, generator=g).to(dev)
+        cl = ops.CloudTables(bary, off, H)
+        Y = torch.randn(H, C, generator=g).to(dev)
+        fn = (lambda: ops.splat_raw(A, cl.csr(), H, True)) if kind == 'splat' else (lambda: ops.slice_raw(Y, bary, off, M))
+    ref = fn().clone()
+    torch.cuda.synchronize()
+    X = torch.randn(30000, 1024, device=dev)
+    side = torch.cuda.Stream(priority=-1)
+    for _ in range(8):
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            out = fn()
+        for _ in range(4):
+            Z = torch.relu(X) + 1
+        torch.cuda.synchronize()
+        if kind == 'wgrad_f32':
+            assert float((out - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+        else:
+            assert torch.equal(out, ref)

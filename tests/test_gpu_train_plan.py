@@ -62,10 +62,11 @@ def test_native_step_matches_autograd(arch, n, native_lat):
         assert worst[1] < 2e-4, worst
         # a second step on the same plan (buffers reused, arenas re-zeroed): the same numbers
         g1 = plan.gflat.clone()
-        plan.step(t[0], t[1], t[2], lat)
-        plan.finish()
-        torch.cuda.synchronize()
-        assert float((plan.gflat - g1).abs().max()) <= 2e-4 * float(g1.abs().max())
+        for _ in range(6 if side else 1):      # (with the side stream: weight gradients beside the data-gradient chain, several times)
+            plan.step(t[0], t[1], t[2], lat)
+            plan.finish()
+            torch.cuda.synchronize()
+            assert float((plan.gflat - g1).abs().max()) <= 2e-4 * float(g1.abs().max())
         del plan
 
 
