@@ -649,9 +649,8 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
         // three workgroups per CU (COMPACT LDS budget, 52.8 KB) for the tap-group passes of the big stencil launches: a
         // third workgroup covers the dispatch gaps and prologues of the other two -- slots occupied 0.91 -> 0.93 of 768,
         // dominant launch 816 -> 789 us alone (profiles/r02y_wg3.txt); in the three-stream pipeline the throughput is
-        // unchanged (the GPU is matrix-pipe bound there).  HPL_WG3=0 switches it off.
-        constexpr int wg3 = 1;
-        if (wg3 && avec && p.F > 1 && p.F <= 8 && nk <= 512 && p.splits == 1) {      // (a tap group: <= 8 taps staged)
+        // unchanged (the GPU is matrix-pipe bound there).
+        if (avec && p.F > 1 && p.F <= 8 && nk <= 512 && p.splits == 1) {      // (a tap group: <= 8 taps staged)
             k_gconv<BM, BN, WGM, WGN, true, 8, true><<<grid, 64 * WGM * WGN, 0, s>>>(p);
             return;
         }

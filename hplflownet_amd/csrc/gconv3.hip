@@ -817,16 +817,11 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
         if (!epi) p.epi_fast = 0;
     }
     // instances by the taps whose indices a tile stages in LDS: 1 (dense GEMMs), <= 8 (tap-group passes), <= 15
-    // HPL_SPLIT3_NB=3: the three-stage pipeline for the 256-wide tile too (A/B runs)
-    constexpr int nb = 4;
-    if (bn256 && nb == 4) {
+    // (a three-stage weight ring for the 256-wide tile was A/B'd in round 3 and lost: four stages stay)
+    if (bn256) {
         if (p.F == 1) k_gconv3w<1, 4><<<grid, 512, 0, s>>>(p);
         else if (p.F <= 8) k_gconv3w<8, 4><<<grid, 512, 0, s>>>(p);
         else k_gconv3w<15, 4><<<grid, 512, 0, s>>>(p);
-    } else if (bn256) {
-        if (p.F == 1) k_gconv3<4, 1><<<grid, 512, 0, s>>>(p);
-        else if (p.F <= 8) k_gconv3<4, 8><<<grid, 512, 0, s>>>(p);
-        else k_gconv3<4, 15><<<grid, 512, 0, s>>>(p);
     } else {
         if (p.F == 1) k_gconv3<2, 1><<<grid, 256, 0, s>>>(p);
         else if (p.F <= 8) k_gconv3<2, 8><<<grid, 256, 0, s>>>(p);
