@@ -9,7 +9,7 @@ configuration ("point-pairs/sec + EPE3D, N=8192").  Pairs shard over GPUs as ind
 `--gpus N` is weak scaling: every rank runs K steps on its own pairs, value = N*K / max-rank time.
 
 Printed JSON (rank 0, one line): the contract fields plus
-  roofline      dominant kernel (the wide gather-GEMM launches: bf16 MFMA with fp32-exact split operands by default,
+  roofline      dominant kernel (the wide gather-GEMM launches: fp16 MFMA with scaled fp16-pair operands by default, bf16 triples with HPL_MATH=bf16x3,
                 fp32 MFMA with HPL_MATH=f32): executed MFMA flops per launch / HIP-event launch time, as a fraction of
                 the matrix pipe's peak.  With several forward streams the launches inside the timed loop share the GPU
                 with other pairs' kernels, so the headline figures come from the single-stream pass right after the
@@ -39,8 +39,26 @@ if ROOT not in sys.path:
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 MFMA_BF16_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense = 1024 SIMDs x 1024 FLOP/clk (32x32x16 in 32 cycles) x 2.4 GHz
 SIMDS, PEAK_CLOCK_HZ = 1024, 2.4e9
-#: the split-operand path (csrc/gconv3.hip) spends 6 bf16 MFMA flops per fp32 flop it stands for
-SPLIT3_PRODUCTS = 6
+#: the split-operand path (csrc/gconv3.hip) spends 3 fp16 MFMA flops (scaled fp16 pairs, the default) or 6 bf16 MFMA flops
+#: (exact bf16 triples, HPL_MATH=bf16x3) per fp32 flop it stands for; both MFMAs run at the same rate (32 cycles per 32x32x16)
+def split_products():
+    from hplflownet_amd import ops
+    return 3 if ops.SPLIT_PLANES == 2 else 6
+
+
+def split_words():
+    from hplflownet_amd import ops
+    if ops.SPLIT_PLANES == 2:
+        return ('fp16', 'scaled fp16 pairs (2 x fp16 split operands) on the fp16 MFMA',
+                'fp32 operands as scaled fp16 pairs (x s = hi + lo to 2^-22, s the power of two of the matrix\'s largest magnitude); the 3 partial '
+                'products hi*hi + hi*lo + lo*hi are accumulated in fp32 on v_mfma_f32_32x32x16_f16: error vs float64 not larger than the '
+                'fp32-MFMA kernel\'s (tests/test_gpu_split3.py); HPL_MATH=bf16x3 selects exact bf16 triples (6 products), HPL_MATH=f32 the fp32-MFMA kernels',
+                'f32 (wide layers: fp32 operands as scaled fp16 pairs, 3 partial products, fp32 accumulate)')
+    return ('bf16', '3 x bf16 split operands on the bf16 MFMA',
+            'fp32 operands as exact sums of three bf16 terms (round-to-nearest splits); the 6 partial products with '
+            'i + j <= 2 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16: error vs float64 not larger than the '
+            'fp32-MFMA kernel\'s (tests/test_gpu_split3.py); HPL_MATH=f32 selects the fp32-MFMA kernels',
+            'f32 (wide layers: fp32 operands as exact 3 x bf16 splits, fp32 accumulate)')
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.29 TB/s measured copy)
 
 
@@ -162,10 +180,10 @@ class KernelTimers(object):
                 ef = flops_ex / flops
                 alg = flops / (ms * 1e-3) / 1e12                       # fp32 multiply-adds of the reference per second
                 peak = MFMA_BF16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
-                executed = alg * ef * (SPLIT3_PRODUCTS if split else 1)   # MFMA flops actually issued per second
-                d.update(bound='mfma', achieved=executed, peak=peak, unit='TFLOP/s (executed MFMA flops: %s)' % ('bf16' if split else 'fp32'),
+                executed = alg * ef * (split_products() if split else 1)   # MFMA flops actually issued per second
+                d.update(bound='mfma', achieved=executed, peak=peak, unit='TFLOP/s (executed MFMA flops: %s)' % (split_words()[0] if split else 'fp32'),
                          executed_fraction=ef, f32_equivalent_algorithmic_tflops=alg, gflop_per_step=flops / steps / 1e9,
-                         path='3 x bf16 split operands on the bf16 MFMA' if split else 'fp32 MFMA')
+                         path=split_words()[1] if split else 'fp32 MFMA')
             else:
                 d.update(bound='hbm', achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
                          mbytes_per_step=nbytes / steps / 1e6)
@@ -891,7 +909,7 @@ def main():
             lps = float(sum(len(lat0.levels[L].blur[0].groups() or [1]) for L, _, _ in wide))
             flop_per_busy = 1024.0 if split3 else 64.0
             peak = MFMA_BF16_PEAK_TFLOPS if split3 else MFMA_F32_PEAK_TFLOPS
-            products = SPLIT3_PRODUCTS if split3 else 1
+            products = split_products() if split3 else 1
             busy_per_launch = mirror_gf * 1e9 * products / flop_per_busy / lps                # matrix-pipe cycles per launch
             src = 'host mirror of the kernel\'s slice lists and %d-row block masks (bench.needed_slice_fraction)' % skip_rows
             stamp = source_stamp()
@@ -933,9 +951,10 @@ def main():
             roofline.update(peak=peak, launches_per_step=lps, gflop_per_step_algorithmic_f32=sum(alg_gf),
                             executed_fraction=mirror_gf / sum(alg_gf), executed_source=src,
                             mfma_busy_cycles_per_launch=busy_per_launch,
-                            kernel=('k_gconv3w<8,4> (gather-GEMM on the bf16 MFMA, every fp32 operand split exactly into 3 bf16 terms, 6 partial '
+                            kernel=('k_gconv3w<8,4,%d> (gather-GEMM on the %s MFMA, %s, %d partial '
                                     'products accumulated in fp32; 128x256 tiles, 8 waves in two ping-pong rows; blur convs of bcn1_/bcn2_ as two '
-                                    'tap-group passes each)')
+                                    'tap-group passes each)' % (ops.SPLIT_PLANES, split_words()[0], 'every fp32 operand a scaled fp16 pair' if ops.SPLIT_PLANES == 2
+                                                                else 'every fp32 operand split exactly into 3 bf16 terms', split_products()))
                             if split3 else 'k_gconv<64,128,2,4,true,8,COMPACT> (fp32-MFMA gather-GEMM, 64x128 tiles, 8 waves, 3 workgroups per CU)')
             # Kernel quality is what the kernel does alone on the GPU: with several forward streams the launches inside the timed
             # loop share the CUs with kernels of other pairs.  Headline = the single-stream pass right after the timed loop (same
@@ -952,9 +971,7 @@ def main():
                 roofline['measured'] = 'HIP events around the launches inside the timed loop'
             if split3:
                 roofline['f32_mfma_peak'] = MFMA_F32_PEAK_TFLOPS
-                roofline['arithmetic'] = ('fp32 operands as exact sums of three bf16 terms (round-to-nearest splits); the 6 partial products with '
-                                          'i + j <= 2 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16: error vs float64 not larger than the '
-                                          'fp32-MFMA kernel\'s (tests/test_gpu_split3.py); HPL_MATH=f32 selects the fp32-MFMA kernels')
+                roofline['arithmetic'] = split_words()[2]
         else:
             # other models / sizes: the dominant class of the per-class table, algorithmic = executed (no skipping counted)
             roofline.update(peak=ex.get('peak'), achieved=ex.get('achieved'), frac=ex.get('frac'), avg_launch_us=ex.get('avg_launch_us'),
@@ -987,7 +1004,7 @@ def main():
                 'value': world * a.steps / elapsed, 'unit': 'point-pairs/s', 'n_gpus': world, 'steps': a.steps,
                 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
                 'scaling': 'weak', 'vs_baseline': None,
-                'dtype': 'f32 (wide layers: fp32 operands as exact 3 x bf16 splits, fp32 accumulate)' if ops.SPLIT3 else 'f32', 'data': 'synthetic' if a.data == 'frustum' else 'synthetic (surface patches)',
+                'dtype': split_words()[3] if ops.SPLIT3 else 'f32', 'data': 'synthetic' if a.data == 'frustum' else 'synthetic (surface patches)',
                 'config': {'workload': ('full HPLFlowNet %s (7 levels, 19.3M params, random init), ' if full else 'HPLFlowNetShallow %s (5 levels, random init), ') % ('training step (fwd+bwd+grad all-reduce+Adam)' if a.train else 'inference') +
                                        ('FT3D-like synthetic pair' if a.data == 'frustum' else 'synthetic pair of surface patches') + ', N=%d, bs=1 per GPU' % a.points,
                            'num_points': a.points, 'step_includes_lattice_build': not a.no_lattice,

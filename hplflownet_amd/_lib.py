@@ -29,7 +29,7 @@ class RelayoutJob(ctypes.Structure):
 class Split3Job(ctypes.Structure):
     """Mirror of `hpl_split3_job`."""
     _fields_ = [('Wt', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('k_rows', ctypes.c_int64), ('ldw', ctypes.c_int64),
-                ('plane_stride', ctypes.c_int64)]
+                ('plane_stride', ctypes.c_int64), ('amax', ctypes.c_void_p), ('planes', ctypes.c_int32), ('pad_', ctypes.c_int32)]
 
 
 class GConvDesc(ctypes.Structure):
@@ -43,7 +43,8 @@ class GConvDesc(ctypes.Structure):
                 ('scat', c_vp), ('scat_stride', c_i64), ('scat_c', c_i32), ('w_rows', c_i32),
                 ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64),
                 ('tile_idx', c_vp), ('tile_mask', c_vp), ('tile_bm', c_i32), ('clock_probe', c_vp),
-                ('Y2', c_vp), ('ldy2', c_i64), ('rows2', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64)]
+                ('Y2', c_vp), ('ldy2', c_i64), ('rows2', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64),
+                ('wt3_planes', c_i32), ('a_amax', c_vp), ('w_amax', c_vp)]
 
 
 class Ref(ctypes.Structure):
@@ -58,7 +59,8 @@ class Buf(ctypes.Structure):
 
 class Weight(ctypes.Structure):
     """Mirror of `hpl_weight`."""
-    _fields_ = [('Wt', c_vp), ('ldw', c_i64), ('rows', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64)]
+    _fields_ = [('Wt', c_vp), ('ldw', c_i64), ('rows', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64),
+                ('w_amax', c_vp), ('wt3_planes', c_i32), ('pad_', c_i32)]
 
 
 class Op(ctypes.Structure):
@@ -118,7 +120,11 @@ _SIGNATURES = {
                                            c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
     'hpl_weight_relayout_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp, c_vp]),
     'hpl_weight_split3': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
-    'hpl_weight_split3_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_vp]),
+    'hpl_weight_split3_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp]),
+    'hpl_weight_split2h': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'hpl_amax': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
+    'hpl_gconv_wgrad_scaled': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,
+                                              c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,
                                            c_i64, c_i64, c_i64, ctypes.c_int, c_vp]),
     'hpl_tap_order_scratch_ints': (c_i64, [c_i64]),

@@ -6,6 +6,7 @@
 // the Python path uses (hpl_gconv_forward, hpl_splat, hpl_slice, hpl_transpose) -- same kernels, same
 // arguments, same results, without ~130 Python round trips.  Host cost per forward: the launches themselves.
 #include "common.h"
+#include "gconv_common.h"
 #include <stdlib.h>
 
 #include <algorithm>
@@ -18,6 +19,9 @@ namespace {
 
 constexpr int64_t SPLITK_ELEMS = 8 << 20;          // ops.py: split-K only for outputs of <= 8 M elements
 constexpr int64_t SPLITK_WS_BYTES = 64ll << 20;    // 16 M floats of partial tiles (a launch fits its split count to it)
+// behind it: the largest magnitudes of the matrices the wide (fp16-pair) launches of a run read, one scalar per reduction
+constexpr int AMAX_SLOTS = 4096;
+constexpr int64_t HEAD_BYTES = SPLITK_WS_BYTES + AMAX_SLOTS * 4;
 constexpr int MAX_SYMS = HPL_SYM_LEVEL0 + 8 * HPL_MAX_LEVELS;
 
 __global__ void k_copy_cols(const float *__restrict__ src, int64_t lds, float *__restrict__ dst, int64_t ldd,
@@ -97,6 +101,11 @@ struct hpl_plan {
     std::vector<int64_t> ul_offset;
     std::vector<hipEvent_t> fence;
     size_t fence_used = 0;
+    // largest magnitudes reduced so far in this run (hpl_amax of a view, valid until an op writes the matrix): the wide launches
+    // that read the same view share one reduction; a training step keeps them from its forward range to its backward ranges
+    struct AmaxEnt { int buf; int64_t row_off, rows; int col_off, cols; const float *slot; };
+    std::vector<AmaxEnt> amax;
+    int amax_used = 0;
     // workspace layout of the last run (a function of the plan and the row-count symbols): byte offset of every buffer
     std::vector<int64_t> lay_sym, lay_off;
     int64_t lay_total = 0;
@@ -146,6 +155,51 @@ struct Runner {
     float *loss = nullptr;
     hipStream_t main_s = nullptr, side_s = nullptr;
     bool side_busy = false;                 // side-stream work the main stream has not waited for yet
+    float *amax_base = nullptr;             // AMAX_SLOTS scalars in the workspace (cleared when a run starts at op 0)
+    const float *cur_a_amax = nullptr, *cur_b_amax = nullptr;      // of the op being issued (prepare_amax)
+
+    // the largest magnitude of columns [0, cols) of a view, reduced on the MAIN stream unless this run already has it
+    int amax_of(const hpl_ref &r, const View &v, int64_t rows, int cols, const float *&slot) {
+        const int64_t off = r.buf >= 0 ? symv(sym, r.row_off_sym) : 0;
+        for (const auto &e : pl.amax)
+            if (e.buf == r.buf && e.row_off == off && e.rows == rows && e.col_off == r.col_off && e.cols == cols) { slot = e.slot; return HPL_OK; }
+        HPL_REQUIRE(pl.amax_used < AMAX_SLOTS, "hpl_plan_run: more than %d operand reductions in one run", AMAX_SLOTS);
+        float *dst = amax_base + pl.amax_used++;
+        const int rc = hpl_gc::amax_launch(v.p, v.ld, rows, cols, dst, main_s);
+        if (rc) return rc;
+        if (r.buf >= 0) pl.amax.push_back({r.buf, off, rows, r.col_off, cols, dst});
+        slot = dst;
+        return HPL_OK;
+    }
+    void amax_forget(int buf) {
+        if (buf < 0) return;
+        for (size_t i = 0; i < pl.amax.size();)
+            if (pl.amax[i].buf == buf) { pl.amax[i] = pl.amax.back(); pl.amax.pop_back(); } else ++i;
+    }
+    // wide launches in the fp16-pair mode scale their operands by their largest magnitudes: reduce them (main stream, before a
+    // side-stream op is fenced) for the ops that can qualify (gconv_common.h split3_maybe / wgrad3.hip's test)
+    int prepare_amax(const hpl_op &op) {
+        cur_a_amax = cur_b_amax = nullptr;
+        if (hpl_gc::split_planes() != 2) return HPL_OK;
+        View A, B;
+        int rc;
+        if (op.kind == HPL_OP_GCONV) {
+            if (op.weight < 0 || op.weight >= (int)pl.weights.size() || pl.weights[op.weight].wt3_planes != 2 || !pl.weights[op.weight].Wt3) return HPL_OK;
+            const int64_t M = symv(sym, op.m_sym);
+            if ((op.flags & HPL_FLAG_SCATTER) || !hpl_gc::split3_maybe(M, op.C, op.F > 15 ? 15 : op.F, op.N)) return HPL_OK;
+            if ((rc = view(op.a, A, "gconv input"))) return rc;
+            return amax_of(op.a, A, A.rows, op.C, cur_a_amax);
+        }
+        if (op.kind == HPL_OP_WGRAD) {
+            const int64_t M = symv(sym, op.m_sym);
+            const bool taps = (op.flags & HPL_FLAG_TAPS) && op.table == HPL_TBL_BLUR0;
+            if (!(op.N >= 256 && op.C >= 128 && M >= 8192 && (taps || (op.F == 1 && op.table == HPL_TBL_NONE)))) return HPL_OK;
+            if ((rc = view(op.a, A, "wgrad input")) || (rc = view(op.b, B, "wgrad output gradient"))) return rc;
+            if ((rc = amax_of(op.a, A, A.rows, op.C, cur_a_amax))) return rc;
+            return amax_of(op.b, B, M, op.N, cur_b_amax);
+        }
+        return HPL_OK;
+    }
 
     hipEvent_t fence_event() {
         if (pl.fence_used == pl.fence.size()) {
@@ -296,9 +350,11 @@ struct Runner {
             d.row_perm = row_perm;
             if (row_perm && ti && tm) { d.tile_idx = ti; d.tile_mask = tm; d.tile_bm = ngroups >= 2 ? t.group_tile_bm : t.tile_bm; }
             // split-operand image of the same rows (csrc/gconv3.hip takes the launch if it qualifies): k-blocks of 8 rows
-            if (w.Wt3 && ((int64_t)f0 * op.C) % 8 == 0) {
+            if (w.Wt3 && ((int64_t)f0 * op.C) % 8 == 0 && (w.wt3_planes != 2 || cur_a_amax)) {
                 d.Wt3 = static_cast<const char *>(w.Wt3) + (int64_t)f0 * op.C / 8 * w.ldw * 16;
                 d.wt3_plane_stride = w.wt3_plane_stride;
+                d.wt3_planes = w.wt3_planes;
+                d.a_amax = cur_a_amax; d.w_amax = w.w_amax;
             }
             if (prof) d.clock_probe = pl.clock_probe;
             if (scatter) { d.scat = t.corr2; d.scat_stride = 15 * t.H0; d.scat_c = op.aux; }
@@ -418,9 +474,10 @@ struct Runner {
             HPL_REQUIRE(A.cols >= op.C && B.cols >= op.N && B.rows >= M, "hpl_plan_run: wgrad shapes");
             const hpl_weight &g = pl.weights[op.weight];
             const bool taps = (op.flags & HPL_FLAG_TAPS) && op.table == HPL_TBL_BLUR0 && t.up_tap_m && t.up_tap_row && t.up_tap_ptr;
-            return hpl_gconv_wgrad(A.p, A.ld, A.rows, nbr, stride, reg, M, op.C, op.F, B.p, B.ld, op.N, const_cast<float *>(g.Wt), g.ldw,
-                                   taps ? t.up_tap_m : nullptr, taps ? t.up_tap_row : nullptr, taps ? t.up_tap_ptr : nullptr,
-                                   taps ? t.up_tap_max : 0, op.bias >= 0 ? const_cast<float *>(pl.biases[op.bias]) : nullptr, hs);
+            return hpl_gconv_wgrad_scaled(A.p, A.ld, A.rows, nbr, stride, reg, M, op.C, op.F, B.p, B.ld, op.N, const_cast<float *>(g.Wt), g.ldw,
+                                          taps ? t.up_tap_m : nullptr, taps ? t.up_tap_row : nullptr, taps ? t.up_tap_ptr : nullptr,
+                                          taps ? t.up_tap_max : 0, op.bias >= 0 ? const_cast<float *>(pl.biases[op.bias]) : nullptr,
+                                          cur_a_amax, cur_b_amax, hs);
         }
         case HPL_OP_LEAKY_BWD: {
             View B;
@@ -597,7 +654,7 @@ int64_t plan_layout(hpl_plan &pl, const hpl_level_tables *lv, int n_levels, cons
     for (int b : order) size[b] = buf_bytes(sym[pl.bufs[b].rows_sym], pl.bufs[b].cols);
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return first[x] != first[y] ? first[x] < first[y] : size[x] > size[y]; });
     pl.lay_off.assign(nb, -1);
-    int64_t total = SPLITK_WS_BYTES;
+    int64_t total = HEAD_BYTES;
     std::vector<std::pair<int64_t, int64_t>> busy;          // (offset, end) of placed matrices alive together with the candidate
     std::vector<int> placed;
     for (int b : order) {
@@ -605,7 +662,7 @@ int64_t plan_layout(hpl_plan &pl, const hpl_level_tables *lv, int n_levels, cons
         for (int q : placed)
             if (first[q] <= last[b] && first[b] <= last[q] && size[q] > 0) busy.emplace_back(pl.lay_off[q], pl.lay_off[q] + size[q]);
         std::sort(busy.begin(), busy.end());
-        int64_t at = SPLITK_WS_BYTES;
+        int64_t at = HEAD_BYTES;
         for (const auto &iv : busy) {
             if (iv.first - at >= size[b]) break;
             at = std::max(at, iv.second);
@@ -668,7 +725,13 @@ extern "C" int hpl_plan_run_range(hpl_plan *plan, const hpl_level_tables *levels
     r.sf = sf; r.loss = loss;
     r.main_s = to_stream(stream);
     r.side_s = side_stream ? to_stream(side_stream) : nullptr;
+    r.amax_base = reinterpret_cast<float *>(w + SPLITK_WS_BYTES);
     plan->fence_used = 0;
+    if (op_begin == 0) {          // a new pair: nothing reduced yet
+        plan->amax.clear();
+        plan->amax_used = 0;
+        if (hpl_gc::split_planes() == 2 && hipMemsetAsync(r.amax_base, 0, AMAX_SLOTS * 4, r.main_s) != hipSuccess) { set_error("hpl_plan_run: hipMemsetAsync failed"); return HPL_EHIP; }
+    }
     auto active = [&](const hpl_op &op, bool &run) -> int {
         run = true;
         if (op.cond != HPL_COND_ALWAYS) {
@@ -723,6 +786,9 @@ extern "C" int hpl_plan_run_range(hpl_plan *plan, const hpl_level_tables *levels
         if ((rc = active(op, run))) return rc;
         if (!run) continue;
         const bool side = r.side_s && (op.flags & HPL_FLAG_SIDE);
+        if ((rc = r.prepare_amax(op))) return rc;
+        r.amax_forget(op.out.buf);
+        r.amax_forget(op.out2.buf);
         if (side) { if ((rc = r.to_side())) return rc; }
         else if (op.kind == HPL_OP_UNLAYOUT && (rc = r.join())) return rc;       // (it reads what the side-stream wgrads wrote)
         rc = r.run_op(op);

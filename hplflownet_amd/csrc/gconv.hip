@@ -575,6 +575,9 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.perm_chunk = 4;      // measured on bcn1_/bcn2_ (64-row tiles): 1: 2.61/1.33 ms, 2: 2.73/1.31, 4: 2.62/1.26, 8: 2.66/1.26, 16: 2.96/1.27
     p.ws = d->ws; p.ws_bytes = d->ws ? d->ws_bytes : 0; p.splits = 1; p.partial = nullptr;
     p.Wt3 = d->Wt3; p.w3_plane_stride = d->wt3_plane_stride;
+    p.planes = d->wt3_planes == 2 ? 2 : 3; p.a_amax = d->a_amax; p.w_amax = d->w_amax;
+    HPL_REQUIRE(!d->Wt3 || d->wt3_planes == 0 || d->wt3_planes == 2 || d->wt3_planes == 3, "%s: wt3_planes = %d", who, d->wt3_planes);
+    if (p.planes == 2 && !(p.a_amax && p.w_amax)) p.Wt3 = nullptr;      // fp16 pairs need both scales: the launch stays on the fp32 MFMA
     p.col_share = 0; p.col_rows = 0;
     p.tiles_m = p.tiles_n = 0;
     p.a_bytes = ((d->rows_a - 1) * d->lda + d->C) * 4;
@@ -1351,6 +1354,16 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
                                const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
                                const int32_t *tap_m, const int32_t *tap_row, const int32_t *tap_ptr,
                                int64_t tap_max, float *dbias, hplStream stream) {
+    return hpl_gconv_wgrad_scaled(A, lda, rows_a, nbr, nbr_stride, reg_stride, M, C, F, dY, lddy, N, dWt, ldw, tap_m, tap_row,
+                                  tap_ptr, tap_max, dbias, nullptr, nullptr, stream);
+}
+
+extern "C" int hpl_gconv_wgrad_scaled(const float *A, int64_t lda, int64_t rows_a, const int32_t *nbr,
+                                      int64_t nbr_stride, int64_t reg_stride, int64_t M, int C, int F,
+                                      const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
+                                      const int32_t *tap_m, const int32_t *tap_row, const int32_t *tap_ptr,
+                                      int64_t tap_max, float *dbias, const float *a_amax, const float *dy_amax,
+                                      hplStream stream) {
     HPL_REQUIRE(A && dY && dWt, "hpl_gconv_wgrad: null pointer");
     HPL_REQUIRE(M >= 0 && C > 0 && F > 0 && N > 0 && lda >= C && lddy >= N && ldw >= N,
                 "hpl_gconv_wgrad: bad sizes");
@@ -1361,6 +1374,7 @@ extern "C" int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, cons
     p.A = A; p.lda = lda; p.nbr = nbr; p.nbr_stride = nbr_stride; p.reg_stride = reg_stride;
     p.M = M; p.C = C; p.F = F; p.K = F * C; p.dY = dY; p.lddy = lddy; p.N = N; p.dWt = dWt; p.ldw = ldw;
     p.rows_a = rows_a;
+    p.a_amax = a_amax; p.dy_amax = dy_amax;
     const bool vec = (C % 4 == 0) && (lda % 4 == 0) && (lddy % 4 == 0) && aligned16(A) && aligned16(dY);
     const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
     // Tap mode (per-tap lists of present vertices given, wide layers): k tiles are aligned to taps so

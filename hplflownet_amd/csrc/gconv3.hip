@@ -40,6 +40,8 @@ using namespace hpl_gc;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -62,12 +64,25 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(sv, bf16x2));
 }
 
+// PL = 2 (round 5): (x0, x1) * s -> packed fp16 pairs hi / lo, hi = rne(x s), lo = rne(x s - hi): x s = hi + lo up to 2^-22 |x s|
+// (s: the power of two that puts the matrix's largest magnitude into [2^13, 2^14), gconv_common.h split_scale; the residual
+// x s - hi is exact in fp32, so lo is ONE rounding).  Three partial products hi*hi + hi*lo + lo*hi on the fp16 MFMA.
+__device__ __forceinline__ void split2h(float x0, float x1, float s, unsigned &h, unsigned &l) {
+    const float2_t v = {x0 * s, x1 * s};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    const float2_t hf = __builtin_convertvector(hh, float2_t);
+    const float2_t r = {v.x - hf.x, v.y - hf.y};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
 constexpr int BM3 = 128;
 
 // NB = stages of the weight-fragment ring (3 or 4); the gathered rows use NB - 1 register sets: with NB = 4 every load has one
 // more half-step to land (the end-of-half-step wait then leaves the loads of TWO half-steps in flight)
-template <int WGN, int F_LDS, int NB>
+template <int WGN, int F_LDS, int NB, int PL>
 __device__ __forceinline__ void gconv3_body(const GParams &p) {
+    static_assert(PL == 2 || PL == 3, "operand planes: 2 (fp16 pairs) or 3 (bf16 triples)");
     constexpr int BM = BM3, BN = 64 * WGN, NT = 128 * WGN;
     // Gathered loads: a thread's pass p fetches float4 column (t & 3) of HALF p & 1 of tile row t / 4 + (p / 2) * ROWS_PP: four
     // lanes = the 64 bytes a row contributes to a half-slice.  (Eight lanes per full 128-byte line would give every thread one
@@ -76,12 +91,12 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     constexpr int ROWS_PP = NT / 4;                 // rows covered by one gathered load instruction of the workgroup
     constexpr int A_PASSES = 2 * BM / ROWS_PP;      // float4 per thread and slice: 4 (WGN = 2) or 2 (WGN = 4)
     constexpr int HALF_PASSES = A_PASSES / 2;
-    constexpr int A_STAGE = 3 * 2 * BM * 16;        // bytes: [plane][kb 0..1][row][8 bf16]
-    constexpr int B_STAGE = 3 * 2 * BN * 16;        //        [plane][kb 0..1][n][8 bf16]
+    constexpr int A_STAGE = PL * 2 * BM * 16;       // bytes: [plane][kb 0..1][row][8 x 16 bit]
+    constexpr int B_STAGE = PL * 2 * BN * 16;       //        [plane][kb 0..1][n][8 x 16 bit]
     constexpr int NA = 3;                            // stages of the gathered-row ring
     constexpr int ASETS = NB - 1;                    // register sets of gathered rows in flight
     constexpr int B_BASE = NA * A_STAGE;             // LDS: A ring | B ring | indices
-    constexpr int B_CHUNKS_PER_WAVE = 3;            // 6 * WGN chunks of 1 KiB per half-step over 2 * WGN waves
+    constexpr int B_CHUNKS_PER_WAVE = PL;           // 2 * PL * WGN chunks of 1 KiB per half-step over 2 * WGN waves
     constexpr int KLIST = 1024;
     // (a 3-stage weight ring has its next half-step still in flight; the 4-wave tile runs two workgroups per CU in 128 registers)
     // PP: the two wave rows of the 8-wave tile (waves 0-3 / 4-7: one wave of each on every SIMD) run half a half-step apart.
@@ -222,9 +237,9 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     const int k4 = t & 3, arow0 = t >> 2;
     // weight planes: rows of the image that exist = p.w_bytes / (ldw * 4) (a multiple of 8 by contract)
     const unsigned w3_bytes = (unsigned)(p.w_bytes / 2);                  // (rows / 8) * ldw * 16 bytes per plane
-    __amdgpu_buffer_rsrc_t rsrc_b[3];
+    __amdgpu_buffer_rsrc_t rsrc_b[PL];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < PL; ++pl)
         rsrc_b[pl] = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned char *>(reinterpret_cast<const unsigned char *>(p.Wt3) + (int64_t)pl * p.w3_plane_stride),
             (short)0, (int)w3_bytes, 0x00020000);
@@ -285,17 +300,32 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     // (SQ_LDS_BANK_CONFLICT).  The fragment reads stay conflict-free: the XOR permutes rows inside aligned groups of 8.
     auto a_slot = [](int row, int kb) { return row ^ ((((row >> 5) & 3) << 1) ^ (kb << 2)); };
     const int kb_w = (t >> 1) & 1;
+    // PL = 2: the scales of the two operands (powers of two from the matrices' largest magnitudes, device scalars)
+    float s_a = 1.f, s_out = 1.f, s_out2 = 1.f;
+    if constexpr (PL == 2) {
+        s_a = split_scale(p.a_amax[0]);
+        s_out = split_unscale(s_a);
+        s_out2 = split_unscale(split_scale(p.w_amax[0]));
+    }
     auto store_a = [&](auto set_tag, int h, int st, int j) {
         constexpr int SET = decltype(set_tag)::value;
         const float4_t v = h ? ra[SET][2 * j + 1] : ra[SET][2 * j];      // (h is a literal at every call site)
         const int row = arow0 + j * ROWS_PP;
-        unsigned h0, m0_, l0, h1, m1, l1;
-        split2(v.x, v.y, h0, m0_, l0);
-        split2(v.z, v.w, h1, m1, l1);
         unsigned char *base = smem + st * A_STAGE + (kb_w * BM + a_slot(row, kb_w)) * 16 + (t & 1) * 8;
-        *reinterpret_cast<u32x2 *>(base) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2 *>(base + 2 * BM * 16) = u32x2{m0_, m1};
-        *reinterpret_cast<u32x2 *>(base + 4 * BM * 16) = u32x2{l0, l1};
+        if constexpr (PL == 2) {
+            unsigned h0, l0, h1, l1;
+            split2h(v.x, v.y, s_a, h0, l0);
+            split2h(v.z, v.w, s_a, h1, l1);
+            *reinterpret_cast<u32x2 *>(base) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(base + 2 * BM * 16) = u32x2{l0, l1};
+        } else {
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split2(v.x, v.y, h0, m0_, l0);
+            split2(v.z, v.w, h1, m1, l1);
+            *reinterpret_cast<u32x2 *>(base) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(base + 2 * BM * 16) = u32x2{m0_, m1};
+            *reinterpret_cast<u32x2 *>(base + 4 * BM * 16) = u32x2{l0, l1};
+        }
     };
     const unsigned b_colofs = ((unsigned)(n0 + wn * 64 + lane) < (unsigned)p.ldw) ? (unsigned)(n0 + wn * 64 + lane) * 16u : OOB;
     // weight fragments of half h of slice kt straight into stage st: wave (wm, wn) fetches k-block wm of the half for
@@ -304,7 +334,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         const unsigned kbg = (unsigned)(kt * (BK / 8) + h * 2 + wm);
         const unsigned off = kbg * ldw16 + b_colofs;      // (b_colofs = 0x80000000 for a column past the image: stays out of range)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < PL; ++pl)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 rsrc_b[pl],
                 (__attribute__((address_space(3))) void *)(smem + B_BASE + st * B_STAGE + ((pl * 2 + wm) * BN + wn * 64) * 16),
@@ -384,13 +414,21 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 for (int i = 0; i < 2; ++i)
                     need[i] = !blockskip || (((bmask[i] >> f_lo) | (two ? (bmask[i] >> (f_lo + 1)) : 0)) & 1);
             }
-            u32x4 af[3][2], bf[3][2];
-            constexpr int PA[6] = {0, 0, 1, 0, 2, 1};
-            constexpr int PB[6] = {0, 1, 0, 2, 0, 1};
+            u32x4 af[PL][2], bf[PL][2];
+            // partial products a_i * b_j, i + j <= PL - 1: 6 of the 9 (bf16 triples) / 3 of the 4 (fp16 pairs)
+            constexpr int NQ = PL == 3 ? 6 : 3;
+            constexpr int PA[6] = {0, 0, 1, 0, PL == 3 ? 2 : 0, 1};
+            constexpr int PB[6] = {0, 1, 0, PL == 3 ? 2 : 0, 0, 1};
+            auto mfma = [&](const u32x4 &a, const u32x4 &b, floatx16 &c) {
+                if constexpr (PL == 3)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+                else
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+            };
             if constexpr (PP) {
                 // ---- memory phase: only what has to wait for the barrier -- the twelve fragment reads of this half-step.
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         af[pl][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i] + pl * 2 * BM * 16);
@@ -425,18 +463,15 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 };
                 if (need[0] || need[1]) {
 #pragma unroll
-                    for (int q = 0; q < 6; ++q)
+                    for (int q = 0; q < NQ; ++q)
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
-                                                                                    __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
-                                                                                    acc[i][j], 0, 0, 0);
+                            for (int j = 0; j < 2; ++j) mfma(af[PA[q]][i], bf[PB[q]][j], acc[i][j]);
                     others();
                     // interleave: one MFMA, then a few of the other instructions
 #pragma unroll
-                    for (int k = 0; k < 24; ++k) {
+                    for (int k = 0; k < 4 * NQ; ++k) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
                         __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);      // 4 VALU / SALU
                         if (k % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
@@ -456,7 +491,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             }
             if (need[0] || need[1]) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         af[pl][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i] + pl * 2 * BM * 16);
@@ -481,17 +516,14 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             };
             if (need[0] || need[1]) {
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
-                                                                                __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
-                                                                                acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) mfma(af[PA[q]][i], bf[PB[q]][j], acc[i][j]);
                 rest();
 #pragma unroll
-                for (int k = 0; k < 24; ++k) {
+                for (int k = 0; k < 4 * NQ; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
                     __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);      // 4 VALU / SALU
                     if (k % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
@@ -574,6 +606,14 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             if constexpr (ASETS == 3) { if (sl + 2 < nsl) slice_tail(sl + 2, S2{}); }
         }
         if (PP && wm == 0) asm volatile("s_barrier" ::: "memory");      // (the second wave row's last compute phase)
+    }
+    if constexpr (PL == 2) {        // undo the operand scales: two exact multiplications by powers of two
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * s_out * s_out2;
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -667,15 +707,15 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     }
 }
 
-template <int WGN, int F_LDS, int NB = 3>
+template <int WGN, int F_LDS, int PL, int NB = 3>
 __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
-    gconv3_body<WGN, F_LDS, NB>(p);
+    gconv3_body<WGN, F_LDS, NB, PL>(p);
 }
 
 // the 8-wave tile (128 x 256, ping-pong wave rows): one workgroup per CU
-template <int F_LDS, int NB>
+template <int F_LDS, int NB, int PL>
 __global__ void __launch_bounds__(512, 2) k_gconv3w(const GParams p) {
-    gconv3_body<4, F_LDS, NB>(p);
+    gconv3_body<4, F_LDS, NB, PL>(p);
 }
 
 // Wt [k_rows][ldw] fp32 -> three bf16 planes [k_rows/8][ldw][8]
@@ -702,6 +742,80 @@ __global__ void __launch_bounds__(256) k_weight_split3(const float *__restrict__
     }
 }
 
+// largest magnitude of a [rows][cols] block: the bits of |x| order like unsigned integers (NaN above everything: it survives)
+__device__ __forceinline__ void amax_reduce(unsigned v, unsigned *slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (v) atomicMax(slot, v);
+    }
+}
+
+template <typename V>
+__global__ void __launch_bounds__(256) k_amax(const float *__restrict__ X, int64_t ld, int64_t rows, int colsv, unsigned *__restrict__ slot) {
+    constexpr int VW = sizeof(V) / 4;
+    const int64_t total = rows * colsv;
+    unsigned v = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / colsv;
+        const V x = *reinterpret_cast<const V *>(X + r * ld + (i - r * colsv) * VW);
+        const unsigned *e = reinterpret_cast<const unsigned *>(&x);
+#pragma unroll
+        for (int u = 0; u < VW; ++u) v = max(v, e[u] & 0x7fffffffu);
+    }
+    amax_reduce(v, slot);
+}
+
+__global__ void k_amax_clear(const hpl_split3_job *__restrict__ jobs, int njobs) {
+    for (int j = threadIdx.x; j < njobs; j += blockDim.x)
+        if (jobs[j].planes == 2 && jobs[j].amax) *jobs[j].amax = 0.f;
+}
+
+// the images of a split batch (planes == 2 jobs): blockIdx.y = job
+__global__ void __launch_bounds__(256) k_amax_batch(const hpl_split3_job *__restrict__ jobs) {
+    const hpl_split3_job jb = jobs[blockIdx.y];
+    unsigned v = 0;
+    if (jb.planes == 2) {
+        const int64_t total4 = jb.k_rows * jb.ldw / 4;      // (ldw % 4 == 0: the image is contiguous)
+        const uint4 *X = reinterpret_cast<const uint4 *>(jb.Wt);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+            const uint4 x = X[i];
+            v = max(max(v, x.x & 0x7fffffffu), max(max(x.y & 0x7fffffffu, x.z & 0x7fffffffu), x.w & 0x7fffffffu));
+        }
+    }
+    amax_reduce(v, reinterpret_cast<unsigned *>(jb.amax ? jb.amax : const_cast<float *>(jb.Wt)));      // (v == 0 for other jobs: no store)
+}
+
+// Wt [k_rows][ldw] fp32 -> two fp16 planes [k_rows/8][ldw][8] of Wt * split_scale(*amax)
+__device__ __forceinline__ void split2h_store(const float *x, float sc, unsigned char *dst, int64_t plane_stride, int64_t i) {
+    u32x4 h, l;
+    unsigned a, b;
+    split2h(x[0], x[1], sc, a, b); h.x = a; l.x = b;
+    split2h(x[2], x[3], sc, a, b); h.y = a; l.y = b;
+    split2h(x[4], x[5], sc, a, b); h.z = a; l.z = b;
+    split2h(x[6], x[7], sc, a, b); h.w = a; l.w = b;
+    *reinterpret_cast<u32x4 *>(dst + i * 16) = h;
+    *reinterpret_cast<u32x4 *>(dst + plane_stride + i * 16) = l;
+}
+
+__global__ void __launch_bounds__(256) k_weight_split2h(const float *__restrict__ Wt, int64_t k_rows, int64_t ldw,
+                                                         unsigned char *__restrict__ dst, int64_t plane_stride,
+                                                         const float *__restrict__ amax) {
+    const float sc = split_scale(amax[0]);
+    const int64_t total = (k_rows / 8) * ldw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t kb = i / ldw, n = i - kb * ldw;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = Wt[(kb * 8 + j) * ldw + n];
+        split2h_store(x, sc, dst, plane_stride, i);
+    }
+}
+
 }  // namespace
 
 // many images in one launch (a training step re-splits ~20 images after every optimiser step): blockIdx.y = job
@@ -710,11 +824,13 @@ __global__ void __launch_bounds__(256) k_weight_split3_batch(const hpl_split3_jo
     const float *Wt = jb.Wt;
     unsigned char *dst = reinterpret_cast<unsigned char *>(jb.dst);
     const int64_t ldw = jb.ldw, total = (jb.k_rows / 8) * ldw;
+    const float sc = jb.planes == 2 ? split_scale(jb.amax[0]) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t kb = i / ldw, n = i - kb * ldw;
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = Wt[(kb * 8 + j) * ldw + n];
+        if (jb.planes == 2) { split2h_store(x, sc, dst, jb.plane_stride, i); continue; }
         u32x4 h, m, l;
         unsigned a, b, c;
         split2(x[0], x[1], a, b, c); h.x = a; m.x = b; l.x = c;
@@ -727,11 +843,48 @@ __global__ void __launch_bounds__(256) k_weight_split3_batch(const hpl_split3_jo
     }
 }
 
-extern "C" int hpl_weight_split3_batch(const hpl_split3_job *jobs, int njobs, int64_t max_elems, hplStream stream) {
+extern "C" int hpl_weight_split3_batch(const hpl_split3_job *jobs, int njobs, int64_t max_elems, int any_pairs, hplStream stream) {
     HPL_REQUIRE(jobs && njobs > 0 && njobs <= 65535 && max_elems > 0, "hpl_weight_split3_batch: bad arguments");
+    if (any_pairs) {          // fp16-pair jobs: their largest magnitudes first
+        k_amax_clear<<<1, 256, 0, to_stream(stream)>>>(jobs, njobs);
+        dim3 ga((unsigned)imin(cdiv(max_elems / 4, 256), 256), (unsigned)njobs);
+        k_amax_batch<<<ga, 256, 0, to_stream(stream)>>>(jobs);
+    }
     dim3 grid((unsigned)imin(cdiv(max_elems / 8, 256), 2048), (unsigned)njobs);
     k_weight_split3_batch<<<grid, 256, 0, to_stream(stream)>>>(jobs);
     HPL_CHECK_LAUNCH("hpl_weight_split3_batch");
+    return HPL_OK;
+}
+
+// *slot (cleared by the caller) = max(*slot, largest magnitude of the block)
+int hpl_gc::amax_launch(const float *X, int64_t ld, int64_t rows, int cols, float *slot, hipStream_t s) {
+    if (rows <= 0) return HPL_OK;
+    const bool vec = cols % 4 == 0 && ld % 4 == 0 && aligned16(X);
+    const int cv = vec ? cols / 4 : cols;
+    const int grid = (int)imax(1, imin(cdiv(rows * cv, 256 * 4), 2048));
+    if (vec) k_amax<float4><<<grid, 256, 0, s>>>(X, ld, rows, cv, reinterpret_cast<unsigned *>(slot));
+    else k_amax<float><<<grid, 256, 0, s>>>(X, ld, rows, cv, reinterpret_cast<unsigned *>(slot));
+    HPL_CHECK_LAUNCH("hpl_amax");
+    return HPL_OK;
+}
+
+extern "C" int hpl_amax(const float *X, int64_t ld, int64_t rows, int32_t cols, float *slot, hplStream stream) {
+    HPL_REQUIRE(X && slot && rows >= 0 && cols > 0 && ld >= cols, "hpl_amax: bad arguments (rows=%lld cols=%d ld=%lld)", (long long)rows, cols, (long long)ld);
+    hipStream_t s = to_stream(stream);
+    if (hipMemsetAsync(slot, 0, 4, s) != hipSuccess) { set_error("hpl_amax: hipMemsetAsync failed"); return HPL_EHIP; }
+    return amax_launch(X, ld, rows, cols, slot, s);
+}
+
+extern "C" int hpl_weight_split2h(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride, float *amax,
+                                  hplStream stream) {
+    HPL_REQUIRE(Wt && dst && amax && k_rows > 0 && k_rows % 8 == 0 && ldw > 0 && plane_stride >= k_rows * ldw * 2 &&
+                    plane_stride % 16 == 0 && aligned16(dst),
+                "hpl_weight_split2h: bad arguments (k_rows=%lld ldw=%lld)", (long long)k_rows, (long long)ldw);
+    const int rc = hpl_amax(Wt, ldw, k_rows, (int32_t)ldw, amax, stream);
+    if (rc) return rc;
+    const int grid = (int)imin(cdiv(k_rows / 8 * ldw, 256), 16384);
+    k_weight_split2h<<<grid, 256, 0, to_stream(stream)>>>(Wt, k_rows, ldw, reinterpret_cast<unsigned char *>(dst), plane_stride, amax);
+    HPL_CHECK_LAUNCH("hpl_weight_split2h");
     return HPL_OK;
 }
 
@@ -747,9 +900,17 @@ extern "C" int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, v
 }
 
 // HPL_MATH=f32 keeps every launch on the fp32 MFMA (A/B runs, parity baselines)
-bool hpl_gc::split3_enabled() {
-    static const bool on = !(getenv("HPL_MATH") && std::string(getenv("HPL_MATH")) == "f32");
-    return on;
+bool hpl_gc::split3_enabled() { return split_planes() != 0; }
+
+// HPL_MATH: f32 = fp32 MFMA everywhere; bf16x3 = the exact bf16 triples of rounds 3-4; default = fp16 pairs
+int hpl_gc::split_planes() {
+    static const int planes = [] {
+        const char *m = getenv("HPL_MATH");
+        if (m && std::string(m) == "f32") return 0;
+        if (m && std::string(m) == "bf16x3") return 3;
+        return 2;
+    }();
+    return planes;
 }
 
 bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
@@ -818,14 +979,24 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     }
     // instances by the taps whose indices a tile stages in LDS: 1 (dense GEMMs), <= 8 (tap-group passes), <= 15
     // (a three-stage weight ring for the 256-wide tile was A/B'd in round 3 and lost: four stages stay)
-    if (bn256) {
-        if (p.F == 1) k_gconv3w<1, 4><<<grid, 512, 0, s>>>(p);
-        else if (p.F <= 8) k_gconv3w<8, 4><<<grid, 512, 0, s>>>(p);
-        else k_gconv3w<15, 4><<<grid, 512, 0, s>>>(p);
+    if (p.planes == 2) {
+        if (bn256) {
+            if (p.F == 1) k_gconv3w<1, 4, 2><<<grid, 512, 0, s>>>(p);
+            else if (p.F <= 8) k_gconv3w<8, 4, 2><<<grid, 512, 0, s>>>(p);
+            else k_gconv3w<15, 4, 2><<<grid, 512, 0, s>>>(p);
+        } else {
+            if (p.F == 1) k_gconv3<2, 1, 2><<<grid, 256, 0, s>>>(p);
+            else if (p.F <= 8) k_gconv3<2, 8, 2><<<grid, 256, 0, s>>>(p);
+            else k_gconv3<2, 15, 2><<<grid, 256, 0, s>>>(p);
+        }
+    } else if (bn256) {
+        if (p.F == 1) k_gconv3w<1, 4, 3><<<grid, 512, 0, s>>>(p);
+        else if (p.F <= 8) k_gconv3w<8, 4, 3><<<grid, 512, 0, s>>>(p);
+        else k_gconv3w<15, 4, 3><<<grid, 512, 0, s>>>(p);
     } else {
-        if (p.F == 1) k_gconv3<2, 1><<<grid, 256, 0, s>>>(p);
-        else if (p.F <= 8) k_gconv3<2, 8><<<grid, 256, 0, s>>>(p);
-        else k_gconv3<2, 15><<<grid, 256, 0, s>>>(p);
+        if (p.F == 1) k_gconv3<2, 1, 3><<<grid, 256, 0, s>>>(p);
+        else if (p.F <= 8) k_gconv3<2, 8, 3><<<grid, 256, 0, s>>>(p);
+        else k_gconv3<2, 15, 3><<<grid, 256, 0, s>>>(p);
     }
     return true;
 }

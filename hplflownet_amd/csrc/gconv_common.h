@@ -27,6 +27,30 @@ __device__ __forceinline__ int32x4_t make_rsrc(const void *base, int bytes) {
     return u.v;
 }
 
+// fp16-pair operands (round 5): a matrix is multiplied by the power of two s that puts its largest magnitude `amax` into
+// [2^13, 2^14) before it is split into fp16 hi + lo (hi cannot overflow -- fp16 reaches 65 504 --, lo of every element within
+// 2^-17 of the largest is a normal fp16 number, smaller ones keep an absolute error of 2^-39 amax); the product is multiplied by
+// 1 / s afterwards.  amax == 0 or denormal: s = 1.  NaN / inf in amax: the products are NaN / inf as in fp32.
+__host__ __device__ __forceinline__ float split_scale(float amax) {
+    unsigned bits;
+    __builtin_memcpy(&bits, &amax, 4);
+    const int e = (int)((bits >> 23) & 0xffu);
+    int sb = 267 - e;                        // biased exponent of 2^(13 - (e - 127))
+    sb = sb < 2 ? 2 : (sb > 252 ? 252 : sb);
+    const unsigned sbits = e == 0 ? 0x3f800000u : ((unsigned)sb << 23);
+    float s;
+    __builtin_memcpy(&s, &sbits, 4);
+    return s;
+}
+__host__ __device__ __forceinline__ float split_unscale(float s) {      // 1 / s for a power of two
+    unsigned bits;
+    __builtin_memcpy(&bits, &s, 4);
+    const unsigned ibits = (254u - ((bits >> 23) & 0xffu)) << 23;
+    float r;
+    __builtin_memcpy(&r, &ibits, 4);
+    return r;
+}
+
 constexpr int COL_CHUNK = 4;
 constexpr int BK = 32;   // contraction slice per step (floats) = one 128-byte line per gathered row
 
@@ -51,7 +75,9 @@ struct GParams {
     int splits; float *partial;         // split-K over the slice list: partial[split][M][N]
     float *Y2; int64_t ldy2; int64_t rows2;   // optional second destination: rows < rows2 are also written to Y2
     float *ws; int64_t ws_bytes;
-    const void *Wt3; int64_t w3_plane_stride;      // split weight image (hpl_weight_split3) or nullptr
+    const void *Wt3; int64_t w3_plane_stride;      // split weight image (hpl_weight_split3 / hpl_weight_split2h) or nullptr
+    int planes;                         // 3: bf16 triples; 2: fp16 pairs, with the largest magnitudes of A / of the weight image:
+    const float *a_amax; const float *w_amax;      //   DEVICE scalars (hpl_amax; hpl_weight_split2h)
     int epi_fast;                       // 32-bit buffer addressing in the epilogue (set by the launch functions)
 };
 
@@ -140,6 +166,12 @@ int fill_params(const hpl_gconv_desc *d, GParams &p, const char *who);
 bool launch_split3(GParams &p, hipStream_t s);
 // HPL_MATH=f32 keeps every launch on the fp32 MFMA (A/B runs, parity baselines)
 bool split3_enabled();
+// operand planes of the split kernels: 2 = fp16 pairs (default), 3 = bf16 triples (HPL_MATH=bf16x3), 0 = HPL_MATH=f32
+int split_planes();
+// *slot = max(*slot, largest magnitude of X[0 .. rows)[0 .. cols)) (gconv3.hip; the caller cleared the slot)
+int amax_launch(const float *X, int64_t ld, int64_t rows, int cols, float *slot, hipStream_t s);
+// the cheap part of launch_split3's test (the callers decide with it whether to compute the largest magnitude of A)
+inline bool split3_maybe(int64_t M, int C, int F, int N) { return C >= 32 && N >= 256 && M >= 1024 && F <= 15; }
 
 // weight gradient (gconv.hip: fp32 MFMA; wgrad3.hip: split operands on the bf16 MFMA)
 struct WParams {
@@ -154,6 +186,7 @@ struct WParams {
     const int32_t *tap_m; const int32_t *tap_row; const int32_t *tap_ptr; int c_tiles;
     float *dbias;        // optional: dbias[n] += sum_m dY[m, n] (by the k-tile-0 workgroups; not in tap mode)
     int64_t rows_a;      // rows of A (0 = unknown)
+    const float *a_amax; const float *dy_amax;     // optional DEVICE scalars (hpl_amax of A / dY): both given = fp16-pair operands
 };
 // the split-operand weight gradient (wgrad3.hip): true if it took the launch.  tap: p.tap_* are set (k tiles = (tap, channel
 // block)); m_len = longest vertex loop of a tile

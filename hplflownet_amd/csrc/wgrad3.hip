@@ -30,6 +30,8 @@ using namespace hpl_gc;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -49,16 +51,29 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(sv, bf16x2));
 }
 
-constexpr int W3_BKR = 128, W3_BN = 256, W3_BMS = 16, W3_NT = 512;
-constexpr int W3_SA = 320, W3_SB = 576;                    // bytes per LDS row: 128 / 256 bf16 + pad (16 dwords mod 64)
-constexpr int W3_A_STAGE = 3 * W3_BMS * W3_SA;            // [plane][m][c]
-constexpr int W3_B_STAGE = 3 * W3_BMS * W3_SB;            // [plane][m][n]
-constexpr int W3_STAGE = W3_A_STAGE + W3_B_STAGE;
+// PL = 2 (round 5): (x0, x1) * s -> packed fp16 pairs hi / lo (gconv3.hip split2h)
+__device__ __forceinline__ void split2h(float x0, float x1, float s, unsigned &h, unsigned &l) {
+    const float2_t v = {x0 * s, x1 * s};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    const float2_t hf = __builtin_convertvector(hh, float2_t);
+    const float2_t r = {v.x - hf.x, v.y - hf.y};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
 
-template <bool TAP>
+constexpr int W3_BKR = 128, W3_BN = 256, W3_BMS = 16, W3_NT = 512;
+constexpr int W3_SA = 320, W3_SB = 576;                    // bytes per LDS row: 128 / 256 x 16 bit + pad (16 dwords mod 64)
+
+// PL = 3: bf16 triples; PL = 2: fp16 pairs of both operands, each scaled by the power of two of its largest magnitude
+template <bool TAP, int PL>
 __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
     constexpr int BKR = W3_BKR, BN = W3_BN, BMS = W3_BMS, SA = W3_SA, SB = W3_SB;
+    constexpr int W3_A_STAGE = PL * W3_BMS * W3_SA;            // [plane][m][c]
+    constexpr int W3_B_STAGE = PL * W3_BMS * W3_SB;            // [plane][m][n]
+    constexpr int W3_STAGE = W3_A_STAGE + W3_B_STAGE;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * W3_STAGE];
+    float s_a = 1.f, s_d = 1.f;
+    if constexpr (PL == 2) { s_a = split_scale(p.a_amax[0]); s_d = split_scale(p.dy_amax[0]); }
 
     const int tile_k = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
     const int n0 = tile_n * BN;
@@ -128,20 +143,34 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
     auto store_lds = [&](int st, const Rows &r) {
         unsigned char *sa = smem + st * W3_STAGE + ar * SA + (t & 31) * 8;
         unsigned h0, m0, l0, h1, m1, l1;
-        split2(r.a.x, r.a.y, h0, m0, l0);
-        split2(r.a.z, r.a.w, h1, m1, l1);
-        *reinterpret_cast<u32x2 *>(sa) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2 *>(sa + BMS * SA) = u32x2{m0, m1};
-        *reinterpret_cast<u32x2 *>(sa + 2 * BMS * SA) = u32x2{l0, l1};
+        if constexpr (PL == 2) {
+            split2h(r.a.x, r.a.y, s_a, h0, l0);
+            split2h(r.a.z, r.a.w, s_a, h1, l1);
+            *reinterpret_cast<u32x2 *>(sa) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(sa + BMS * SA) = u32x2{l0, l1};
+        } else {
+            split2(r.a.x, r.a.y, h0, m0, l0);
+            split2(r.a.z, r.a.w, h1, m1, l1);
+            *reinterpret_cast<u32x2 *>(sa) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(sa + BMS * SA) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2 *>(sa + 2 * BMS * SA) = u32x2{l0, l1};
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float4_t &v = i ? r.b1 : r.b0;
             unsigned char *sb = smem + st * W3_STAGE + W3_A_STAGE + (br + 8 * i) * SB + (t & 63) * 8;
-            split2(v.x, v.y, h0, m0, l0);
-            split2(v.z, v.w, h1, m1, l1);
-            *reinterpret_cast<u32x2 *>(sb) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2 *>(sb + BMS * SB) = u32x2{m0, m1};
-            *reinterpret_cast<u32x2 *>(sb + 2 * BMS * SB) = u32x2{l0, l1};
+            if constexpr (PL == 2) {
+                split2h(v.x, v.y, s_d, h0, l0);
+                split2h(v.z, v.w, s_d, h1, l1);
+                *reinterpret_cast<u32x2 *>(sb) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2 *>(sb + BMS * SB) = u32x2{l0, l1};
+            } else {
+                split2(v.x, v.y, h0, m0, l0);
+                split2(v.z, v.w, h1, m1, l1);
+                *reinterpret_cast<u32x2 *>(sb) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2 *>(sb + BMS * SB) = u32x2{m0, m1};
+                *reinterpret_cast<u32x2 *>(sb + 2 * BMS * SB) = u32x2{l0, l1};
+            }
         }
     };
 
@@ -170,9 +199,9 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
     auto multiply = [&](int st) {
         const unsigned char *sa = smem + st * W3_STAGE + a_fofs;
         const unsigned char *sb = smem + st * W3_STAGE + b_fofs;
-        s16x8 af[3][2], bf[3][2];
+        s16x8 af[PL][2], bf[PL][2];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const s16x4 a0 = frag(sa + pl * BMS * SA + i * 64), a1 = frag(sa + pl * BMS * SA + i * 64 + 4 * SA);
@@ -180,17 +209,24 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
                 af[pl][i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                 bf[pl][i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
-        constexpr int PA[6] = {0, 0, 1, 0, 2, 1};
-        constexpr int PB[6] = {0, 1, 0, 2, 0, 1};
+        constexpr int NQ = PL == 3 ? 6 : 3;
+        constexpr int PA[6] = {0, 0, 1, 0, PL == 3 ? 2 : 0, 1};
+        constexpr int PB[6] = {0, 1, 0, PL == 3 ? 2 : 0, 0, 1};
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
-                                                                        __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
-                                                                        acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (PL == 3)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[q]][i]),
+                                                                            __builtin_bit_cast(bf16x8, bf[PB[q]][j]),
+                                                                            acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[PA[q]][i]),
+                                                                           __builtin_bit_cast(f16x8, bf[PB[q]][j]),
+                                                                           acc[i][j], 0, 0, 0);
+                }
     };
 
     // ROUND 5: the wait in front of the split + store is a FULL drain (vmcnt(0)), not "all but the newest three loads".  With the
@@ -233,10 +269,10 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
         store_lds(cur ^ 1, ready);
         // the split of the next stage in the shadows of this stage's MFMAs (one basic block: nothing here is conditional)
 #pragma unroll
-        for (int k = 0; k < 24; ++k) {
+        for (int k = 0; k < (PL == 3 ? 24 : 12); ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // 4 VALU
-            if (k % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
+            __builtin_amdgcn_sched_group_barrier(0x002, PL == 3 ? 4 : 6, 0);      // VALU
+            if (PL == 2 || k % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
         }
         __syncthreads();
     };
@@ -249,6 +285,7 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Buffer atomics with
     // 32-bit byte offsets (the image is far below 2 GB: checked by launch_wgrad3), out of range for rows past C / columns past N
+    const float u_a = split_unscale(s_a), u_d = split_unscale(s_d);      // (1 for PL = 3)
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.dWt, (short)0, 0x7fffffff, 0x00020000);
     const unsigned ldw_b = (unsigned)p.ldw * 4u;
 #pragma unroll
@@ -261,7 +298,7 @@ __global__ void __launch_bounds__(W3_NT) k_wgrad3(const WParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int kr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const unsigned o = (c0_tile + kr < p.C) ? __umul24((unsigned)(k0 + kr), ldw_b) + nb : OOB;
-                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][r], rs_w, (int)o, 0, 0);
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(PL == 2 ? acc[i][j][r] * u_a * u_d : acc[i][j][r], rs_w, (int)o, 0, 0);
             }
         }
 }
@@ -293,7 +330,14 @@ bool hpl_gc::launch_wgrad3(WParams &p, bool tap, int64_t m_len, hipStream_t s) {
     p.m_per_split = cdiv(cdiv(m_len, splits), W3_BMS) * W3_BMS;
     if (!tap) splits = cdiv(m_len, p.m_per_split);
     const dim3 grid((unsigned)tiles, (unsigned)splits);
-    if (tap) k_wgrad3<true><<<grid, W3_NT, 0, s>>>(p);
-    else k_wgrad3<false><<<grid, W3_NT, 0, s>>>(p);
+    // fp16 pairs when both largest magnitudes were given (and the mode allows), else the exact bf16 triples
+    const bool pairs = split_planes() == 2 && p.a_amax && p.dy_amax;
+    if (pairs) {
+        if (tap) k_wgrad3<true, 2><<<grid, W3_NT, 0, s>>>(p);
+        else k_wgrad3<false, 2><<<grid, W3_NT, 0, s>>>(p);
+    } else {
+        if (tap) k_wgrad3<true, 3><<<grid, W3_NT, 0, s>>>(p);
+        else k_wgrad3<false, 3><<<grid, W3_NT, 0, s>>>(p);
+    }
     return true;
 }

@@ -144,9 +144,12 @@ def tap_order(nbr):
 
 
 TILE_BM = 64        # tile height of the gather-GEMM classes that take a row order (csrc/gconv.hip: 64x128, 64x64)
-#: HPL_MATH=f32 keeps every gather-GEMM on the fp32 MFMA; default: the wide tap-group passes run on the bf16 MFMA with
-#: three-way split operands (csrc/gconv3.hip, fp32-class accuracy), whose tiles are 128 rows high
-SPLIT3 = os.environ.get('HPL_MATH', 'split3') != 'f32'
+#: HPL_MATH=f32 keeps every gather-GEMM on the fp32 MFMA; default (f16x2): the wide launches run on the fp16 MFMA with every
+#: fp32 operand carried as a scaled fp16 pair, HPL_MATH=bf16x3: on the bf16 MFMA with exact bf16 triples (csrc/gconv3.hip: both
+#: fp32-class accuracy; tiles 128 rows high)
+MATH = os.environ.get('HPL_MATH', 'f16x2')
+SPLIT3 = MATH != 'f32'
+SPLIT_PLANES = 3 if MATH == 'bf16x3' else 2
 GROUP_TILE_BM = 128 if SPLIT3 else 64
 #: weight images narrower than this stay fp32-only (the split kernel takes launches with N >= 256, C >= 32)
 SPLIT3_MIN_N, SPLIT3_MIN_C = 256, 32
@@ -259,16 +262,44 @@ def weight_relayout(W, R, Q, F, sr, sq, sf, base=0, fmap=None):
     return Wt
 
 
-def weight_split3(Wt, out=None):
-    """fp32 weight image [k_rows (multiple of 8), ldw] -> uint8 tensor [3, k_rows/8 * ldw * 16]: the image as three
-    bf16 planes hi / mid / lo (Wt == hi + mid + lo exactly) in MFMA B-fragment order (hpl_weight_split3); the operand of
-    the split-precision gather-GEMM (gconv_raw Wt3=...)."""
+class SplitW(object):
+    """Split image of a weight image: `planes` uint8 [P, k_rows/8 * ldw * 16] in MFMA B-fragment order -- P = 3: bf16 planes
+    hi / mid / lo with Wt == hi + mid + lo exactly (hpl_weight_split3); P = 2: fp16 planes hi / lo of Wt * s, s the power of
+    two that puts the image's largest magnitude `amax` (float32 [1], device) into [2^13, 2^14) (hpl_weight_split2h)."""
+    __slots__ = ('planes', 'amax', 'P')
+
+    def __init__(self, planes, amax, P):
+        self.planes, self.amax, self.P = planes, amax, P
+
+    def rows_from(self, k0, ldw):
+        """The same image from row k0 (a multiple of 8) on: k-blocks of 8 rows, 16 bytes per column."""
+        return SplitW(self.planes[:, (k0 // 8) * ldw * 16:], self.amax, self.P)
+
+
+def weight_split3(Wt, out=None, planes=None):
+    """fp32 weight image [k_rows (multiple of 8), ldw] -> SplitW: the operand of the split-operand gather-GEMM (gconv_raw
+    Wt3=...); planes = 2 / 3 (default: SPLIT_PLANES, i.e. HPL_MATH); out: a SplitW of the same image to refresh."""
     k_rows, ldw = Wt.shape
     if k_rows % 8 or not Wt.is_contiguous():
         raise _lib.HplError('weight_split3: image must be contiguous with a multiple of 8 rows, got %s' % (tuple(Wt.shape),))
+    P = out.P if out is not None else (planes or SPLIT_PLANES)
     if out is None:
-        out = torch.empty((3, k_rows // 8 * ldw * 16), dtype=torch.uint8, device=Wt.device)
-    check(_lib.load().hpl_weight_split3(ptr(Wt), k_rows, ldw, ptr(out), out.stride(0), stream()), 'hpl_weight_split3')
+        out = SplitW(torch.empty((P, k_rows // 8 * ldw * 16), dtype=torch.uint8, device=Wt.device),
+                     torch.zeros(1, dtype=torch.float32, device=Wt.device) if P == 2 else None, P)
+    if P == 2:
+        check(_lib.load().hpl_weight_split2h(ptr(Wt), k_rows, ldw, ptr(out.planes), out.planes.stride(0), ptr(out.amax), stream()),
+              'hpl_weight_split2h')
+    else:
+        check(_lib.load().hpl_weight_split3(ptr(Wt), k_rows, ldw, ptr(out.planes), out.planes.stride(0), stream()), 'hpl_weight_split3')
+    return out
+
+
+def amax(X, rows=None, cols=None):
+    """float32 [1] on the device: the largest magnitude of X[:rows, :cols] (hpl_amax; the scale of a gather-GEMM's fp16-pair
+    operands)."""
+    p_, ld, r, c = _mat(X, 'amax input')
+    out = torch.empty(1, dtype=torch.float32, device=X.device)
+    check(_lib.load().hpl_amax(p_, ld, r if rows is None else rows, c if cols is None else cols, ptr(out), stream()), 'hpl_amax')
     return out
 
 
@@ -313,7 +344,14 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
     d.w_rows = min(wsh[0], round_up(F * C, 32))     # rows past the image read as zero
     d.act, d.slope = act, slope
     if Wt3 is not None:           # weight_split3 of the image Wt is a row range of (same first row)
-        d.Wt3, d.wt3_plane_stride = ptr(Wt3), Wt3.stride(0)
+        if Wt3.P == 3:
+            d.Wt3, d.wt3_plane_stride, d.wt3_planes = ptr(Wt3.planes), Wt3.planes.stride(0), 3
+        elif C >= SPLIT3_MIN_C and N >= SPLIT3_MIN_N and M >= 1024 and F <= 15 and scat is None:
+            # fp16 pairs: the launch scales A by its largest magnitude (csrc/gconv_common.h split3_maybe: launches that cannot
+            # qualify skip the reduction and run on the fp32 MFMA)
+            a_amax = amax(A, cols=C)
+            d.Wt3, d.wt3_plane_stride, d.wt3_planes = ptr(Wt3.planes), Wt3.planes.stride(0), 2
+            d.a_amax, d.w_amax = ptr(a_amax), ptr(Wt3.amax)
     if bias is not None:
         d.bias = ptr(bias)
     if res is not None:
@@ -379,10 +417,14 @@ def wgrad_raw(A, nbr, M, C, F, dY, N, taps=None, want_bias=False, reg_stride=0):
     dWt = buf[:kp * ldw].view(kp, ldw)
     gb = buf[kp * ldw:kp * ldw + N] if want_bias else None
     tl, tr, tp = taps if (taps is not None and nbr is not None) else (None, None, None)
-    check(_lib.load().hpl_gconv_wgrad(ptr(A), _ld(A), A.shape[0], ptr(nbr), nbr.stride(0) if nbr is not None else 0,
-                                      reg_stride if nbr is None else 0, M, C, F, ptr(dY), _ld(dY), N, ptr(dWt), ldw,
-                                      ptr(tl), ptr(tr), ptr(tp),
-                                      M if tl is not None else 0, ptr(gb), stream()),
+    # wide layers (csrc/wgrad3.hip's test): fp16-pair operands need the largest magnitudes of both
+    sa = sd = None
+    if SPLIT_PLANES == 2 and SPLIT3 and N >= 256 and C >= 128 and M >= 8192 and (tl is not None or (F == 1 and nbr is None)):
+        sa, sd = amax(A, cols=C), amax(dY, rows=M, cols=N)
+    check(_lib.load().hpl_gconv_wgrad_scaled(ptr(A), _ld(A), A.shape[0], ptr(nbr), nbr.stride(0) if nbr is not None else 0,
+                                             reg_stride if nbr is None else 0, M, C, F, ptr(dY), _ld(dY), N, ptr(dWt), ldw,
+                                             ptr(tl), ptr(tr), ptr(tp),
+                                             M if tl is not None else 0, ptr(gb), ptr(sa), ptr(sd), stream()),
           'hpl_gconv_wgrad')
     return (dWt, gb) if want_bias else dWt
 
@@ -565,7 +607,7 @@ def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, r
     for i, (f0, f1, perm) in enumerate(groups):
         first, last = i == 0, i == len(groups) - 1
         # the same rows of the split image (k-blocks of 8 rows, 16 bytes per column)
-        w3 = W3[:, (f0 * C // 8) * Wt.shape[1] * 16:] if (W3 is not None and (f0 * C) % 8 == 0) else None
+        w3 = W3.rows_from(f0 * C, Wt.shape[1]) if (W3 is not None and (f0 * C) % 8 == 0) else None
         # a tap range of a regular pattern is the same pattern over the rows from f0*reg_stride on
         y = gconv_raw(A[f0 * reg_stride:] if regular else A, None if regular else nbr[f0:f1], M, C, f1 - f0,
                       Wt[f0 * C:], N, bias=bias if first else None,

@@ -457,7 +457,9 @@ class ForwardPlan(object):
                     done[id(job)] = (img, ops.weight_split3(img))
                     self._split3[i] = done[id(job)]
                 w3 = done[id(job)][1]
-                w_arr[i].Wt3, w_arr[i].wt3_plane_stride = w3.data_ptr(), w3.stride(0)
+                w_arr[i].Wt3, w_arr[i].wt3_plane_stride, w_arr[i].wt3_planes = w3.planes.data_ptr(), w3.planes.stride(0), w3.P
+                if w3.P == 2:
+                    w_arr[i].w_amax = w3.amax.data_ptr()
         self._mark_images_written()
         b_arr = (ctypes.c_void_p * max(1, len(P.biases)))(*[(b if isinstance(b, int) else b.data_ptr()) for b in P.biases])
         self.handle = L.hpl_plan_create(ops_arr, len(P.ops), bufs_arr, len(P.bufs), w_arr, len(P.weights), b_arr,

@@ -432,9 +432,12 @@ class TrainPlan(ForwardPlan):
                 continue
             arr = (Split3Job * len(items))()
             for a, (img, w3) in zip(arr, items):
-                a.Wt, a.dst, a.k_rows, a.ldw, a.plane_stride = img.data_ptr(), w3.data_ptr(), img.shape[0], img.shape[1], w3.stride(0)
+                a.Wt, a.dst, a.k_rows, a.ldw, a.plane_stride = img.data_ptr(), w3.planes.data_ptr(), img.shape[0], img.shape[1], w3.planes.stride(0)
+                a.planes = w3.P
+                if w3.P == 2:
+                    a.amax = w3.amax.data_ptr()
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.gflat.device)
-            out.append((dev, len(items), max(img.numel() for img, _ in items)))
+            out.append((dev, len(items), max(img.numel() for img, _ in items), int(any(w3.P == 2 for _, w3 in items))))
         return out
 
     def refresh_weights(self):
@@ -447,7 +450,7 @@ class TrainPlan(ForwardPlan):
 
         def split(tab):
             if tab is not None:
-                check(L.hpl_weight_split3_batch(tab[0].data_ptr(), tab[1], tab[2], stream()), 'hpl_weight_split3_batch')
+                check(L.hpl_weight_split3_batch(tab[0].data_ptr(), tab[1], tab[2], tab[3], stream()), 'hpl_weight_split3_batch')
         main = torch.cuda.current_stream()
         side = self._side if self._side is not None else main
         if side is not main:

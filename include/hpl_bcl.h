@@ -168,14 +168,23 @@ int hpl_weight_unlayout_batch(const hpl_relayout_job *jobs /* DEVICE */, int njo
  * one output column are one 16-byte MFMA B fragment), plane p at dst + p*plane_stride bytes; hi = bf16_rne(w),
  * mid = bf16_rne(w - hi), lo = bf16_rne(w - hi - mid): w == hi + mid + lo exactly.  plane_stride >= k_rows*ldw*2. */
 int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride, hplStream stream);
+/* The fp16-pair form (hpl_gconv_desc.wt3_planes == 2): *amax (DEVICE) = the image's largest magnitude, s = the power of two
+ * that puts it into [2^13, 2^14); two planes of fp16 in the same fragment order, hi = f16_rne(w s), lo = f16_rne(w s - hi). */
+int hpl_weight_split2h(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride, float *amax,
+                       hplStream stream);
 /* The same for many images in one launch (a training step re-splits every wide image after the optimiser step): jobs in DEVICE
  * memory, max_elems = the largest k_rows * ldw among them (sizes the grid). */
 typedef struct hpl_split3_job {
     const float *Wt;
     void *dst;
     int64_t k_rows, ldw, plane_stride;
+    float *amax;              /* planes == 2: DEVICE scalar the job's largest magnitude is written to */
+    int32_t planes;           /* 2: fp16 pairs (hpl_weight_split2h); 0 / 3: bf16 triples */
+    int32_t pad_;
 } hpl_split3_job;
-int hpl_weight_split3_batch(const hpl_split3_job *jobs /* DEVICE */, int njobs, int64_t max_elems, hplStream stream);
+/* any_pairs: nonzero when any job has planes == 2 (their largest magnitudes are reduced first: two more launches). */
+int hpl_weight_split3_batch(const hpl_split3_job *jobs /* DEVICE */, int njobs, int64_t max_elems, int any_pairs,
+                            hplStream stream);
 
 /* inverse scatter for weight gradients: W[base + r*sr + q*sq + f*sf] (+)= Wt[(f*R + r)*ldw + q] */
 int hpl_weight_unlayout(const float *Wt, int64_t ldw, int R, int Q, int F, float *W, int64_t base,
@@ -249,7 +258,21 @@ typedef struct hpl_gconv_desc {
      * rounding class; 16/6 of the fp32-MFMA rate).  NULL: fp32 MFMA. */
     const void *Wt3;
     int64_t wt3_plane_stride;   /* bytes between the planes */
+    /* wt3_planes == 2 (round 5): Wt3 is hpl_weight_split2h of the image -- two fp16 planes hi / lo of w * s_w -- and the
+     * launch splits A the same way: a * s_a = hi + lo (one rounding each), the three partial products hi*hi + hi*lo + lo*hi
+     * on the fp16 MFMA, fp32 accumulate, the result times 1 / (s_a s_w).  s = the power of two that puts the matrix's
+     * largest magnitude into [2^13, 2^14): a_amax / w_amax are DEVICE scalars holding those magnitudes (hpl_amax of the
+     * rows and channels of A the launch can read -- or of any superset --; the one hpl_weight_split2h wrote).  Per product
+     * the error is <= 2^-21 |a b| for every a within 2^-17 of the largest; measured against float64 the sums are as close
+     * as the fp32 MFMA's (tests/test_gpu_split3.py) at half the bf16-triple form's MFMA work.  Both scalars must be given
+     * (else the launch runs on the fp32 MFMA).  wt3_planes == 0 / 3: bf16 triples as above. */
+    int32_t wt3_planes;
+    const float *a_amax;
+    const float *w_amax;
 } hpl_gconv_desc;
+
+/* Largest magnitude of X[0 .. rows)[0 .. cols) (row stride ld) -> *slot (DEVICE; NaN if X holds one). */
+int hpl_amax(const float *X, int64_t ld, int64_t rows, int32_t cols, float *slot, hplStream stream);
 
 /* Row order for tap skipping: perm = the M vertices grouped by their F-bit tap-presence mask (bit f set iff
  * nbr[f*nbr_stride + m] >= 0; F <= 15), the groups in Gray-code order of their masks (neighbouring groups differ in
@@ -293,6 +316,14 @@ int hpl_gconv_wgrad(const float *A, int64_t lda, int64_t rows_a, const int32_t *
                     const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
                     const int32_t *tap_m, const int32_t *tap_row, const int32_t *tap_ptr,
                     int64_t tap_max, float *dbias, hplStream stream);
+/* The same with the largest magnitudes of A (the rows and channels the launch can read) and of dY (hpl_amax; DEVICE scalars):
+ * the wide layers then run with both operands as scaled fp16 pairs on the fp16 MFMA (hpl_gconv_desc.wt3_planes == 2: the same
+ * arithmetic, half the MFMA work of the bf16 triples).  Either NULL (or HPL_MATH=bf16x3): as hpl_gconv_wgrad. */
+int hpl_gconv_wgrad_scaled(const float *A, int64_t lda, int64_t rows_a, const int32_t *nbr,
+                           int64_t nbr_stride, int64_t reg_stride, int64_t M, int C, int F,
+                           const float *dY, int64_t lddy, int N, float *dWt, int64_t ldw,
+                           const int32_t *tap_m, const int32_t *tap_row, const int32_t *tap_ptr,
+                           int64_t tap_max, float *dbias, const float *a_amax, const float *dy_amax, hplStream stream);
 
 /* out[n] = sum_m X[m*ld + n]   (bias gradients) */
 int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStream stream);
@@ -482,8 +513,11 @@ typedef struct hpl_weight {   /* a re-laid weight image (hpl_weight_relayout) */
     const float *Wt;
     int64_t ldw;
     int64_t rows;
-    const void *Wt3;          /* optional: hpl_weight_split3 of the whole image (NULL: the layer stays on the fp32 MFMA) */
+    const void *Wt3;          /* optional: hpl_weight_split3 / hpl_weight_split2h of the whole image (NULL: the layer stays on the fp32 MFMA) */
     int64_t wt3_plane_stride;
+    const float *w_amax;      /* wt3_planes == 2: the scalar hpl_weight_split2h wrote */
+    int32_t wt3_planes;
+    int32_t pad_;
 } hpl_weight;
 
 typedef struct hpl_op {

@@ -1,7 +1,10 @@
-"""The split-operand gather-GEMM (csrc/gconv3.hip: every fp32 operand carried as three bf16 terms on the bf16 matrix
-pipe) against float64 and against the fp32-MFMA kernel.  The claim pinned here: its error against the exact result is
-of the fp32 rounding class -- not larger than the fp32 kernel's own -- on dense and gathered launches, with and without
-row orders / tile tables, including the tails (partial tiles, partial slices, absent rows, taps straddling slices)."""
+"""The split-operand gather-GEMM (csrc/gconv3.hip) against float64 and against the fp32-MFMA kernel, in both of its forms:
+every fp32 operand as an exact bf16 triple on the bf16 matrix pipe (HPL_MATH=bf16x3: 6 partial products), and as a scaled
+fp16 pair on the fp16 pipe (the default since round 5: 3 partial products, operands good to 2^-22).  The claim pinned here:
+the error against the exact result is of the fp32 rounding class -- triples: not larger than the fp32 kernel's own; pairs:
+largest error not larger than the fp32 kernel's, mean error within 1.4 x of it (a sequential fp32 dot product measures
+1.4 x) -- on dense and gathered launches, with and without row orders / tile tables, including the tails (partial tiles,
+partial slices, absent rows, taps straddling slices)."""
 import numpy as np
 import pytest
 import torch
@@ -46,7 +49,8 @@ def _table(M, rows_a, F, density, seed):
     (9433, 388, 15, 256, 0.8, 'splitk'),      # bcn3_: 74 row tiles -> split over K into 3 shares, partial tiles + fixed-order sum
     (8200, 132, 15, 256, 0.6, 'splitk'),      # 62 slices over 3 shares: a last share that is longer; C % 8 = 4
 ])
-def test_split3_matches_float64_like_the_fp32_kernel(M, C, F, N, density, order):
+@pytest.mark.parametrize('planes', [2, 3])
+def test_split3_matches_float64_like_the_fp32_kernel(M, C, F, N, density, order, planes):
     from hplflownet_amd import ops
     torch.manual_seed(M + C)
     rows_a = M if F == 1 else M + 37
@@ -61,10 +65,19 @@ def test_split3_matches_float64_like_the_fp32_kernel(M, C, F, N, density, order)
         perm = ops.tap_order(nbr)
         if order == 'tiles':
             tiles = ops.tile_index(nbr, perm, BM=128)
-    W3 = ops.weight_split3(Wt)
-    # the planes are an exact decomposition of the image
-    pl = W3.view(torch.bfloat16).view(3, k_rows // 8, Wt.shape[1], 8).float()
-    assert torch.equal(pl.sum(0).permute(0, 2, 1).reshape(k_rows, Wt.shape[1]), Wt)
+    W3 = ops.weight_split3(Wt, planes=planes)
+    if planes == 3:         # the planes are an exact decomposition of the image
+        pl = W3.planes.view(torch.bfloat16).view(3, k_rows // 8, Wt.shape[1], 8).float()
+        assert torch.equal(pl.sum(0).permute(0, 2, 1).reshape(k_rows, Wt.shape[1]), Wt)
+    else:                   # hi + lo = w * s up to 2^-22 |w s| (lo below fp16's normal range: 2^-25 absolute), s = 2^k, amax * s in [2^13, 2^14)
+        amax = float(W3.amax)
+        assert amax == float(Wt.abs().max())
+        sc = 2.0 ** (13 - int(np.floor(np.log2(amax))))
+        pl = W3.planes.view(torch.float16).view(2, k_rows // 8, Wt.shape[1], 8).double()
+        back = pl.sum(0).permute(0, 2, 1).reshape(k_rows, Wt.shape[1])
+        ws = Wt.double() * sc
+        assert float(pl[0].abs().max()) < 2.0 ** 14 + 8
+        assert bool(((back - ws).abs() <= ws.abs() * 2.0 ** -22 + 2.0 ** -25).all())
     kw = dict(bias=bias, act=ops.ACT_LEAKY, row_perm=perm, tiles=tiles, split_k=order == 'splitk')
     y3 = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3, **kw)
     y1 = ops.gconv_raw(A, nbr, M, C, F, Wt, N, **kw)
@@ -81,7 +94,7 @@ def test_split3_matches_float64_like_the_fp32_kernel(M, C, F, N, density, order)
     # fp32 rounding class in absolute terms (a few 2^-24 of the magnitude sum; an fp32 fma chain of K terms measures
     # 3e-7 .. 7e-7 here), and not worse than the fp32-MFMA kernel on the same launch: measured 0.6x (max) / 0.85x (mean)
     assert r3[0] < 1.5e-6 and r3[1] < 5e-8
-    assert r3[1] <= 1.1 * r1[1] + 1e-10 and r3[0] <= 1.25 * r1[0] + 1e-9
+    assert r3[1] <= (1.1 if planes == 3 else 1.4) * r1[1] + 1e-10 and r3[0] <= 1.25 * r1[0] + 1e-9
     assert e3 <= 1.5 * e1 + 3e-7 * scale       # (the largest single error of a launch: K = 108 measures 7.0e-5 vs 3.5e-5 at scale 132)
 
 
@@ -94,6 +107,7 @@ def test_split3_is_deterministic_and_order_independent():
     Wt = torch.randn(ops.round_up(F * C, 32), N, device=DEV)
     Wt[F * C:] = 0
     W3 = ops.weight_split3(Wt)
+    assert W3.P == ops.SPLIT_PLANES
     nbr = _table(M, M, F, 0.6, 11)
     perm = ops.tap_order(nbr)
     a = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3, row_perm=perm, tiles=ops.tile_index(nbr, perm, BM=128), split_k=False)

@@ -40,8 +40,7 @@ for name, lvl, C, O, f0, f1 in cases:
         tb = lat.levels[lvl].blur[0]
         nbr = tb.t[f0:f1]
         M = nbr.shape[1]
-        keys = tb.keys
-        perm = ops.tap_order(nbr, keys)
+        perm = ops.tap_order(nbr)
         t64 = ops.tile_index(nbr, perm, BM=64)
         t128 = ops.tile_index(nbr, perm, BM=128)
         valid = float((nbr >= 0).float().mean())

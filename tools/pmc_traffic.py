@@ -10,7 +10,7 @@ import sys
 import os
 import re
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-DOMINANT = re.compile(r'k_gconv3w<8, 4>' if os.environ.get('HPL_MATH', 'split3') != 'f32' else r'k_gconv<64, 128, 2, 4, true, (8|15)\b')
+DOMINANT = re.compile(r'k_gconv3w<8, 4, \d>' if os.environ.get('HPL_MATH', 'f16x2') != 'f32' else r'k_gconv<64, 128, 2, 4, true, (8|15)\b')
 
 
 def per_launch(db, ctr):
@@ -37,7 +37,7 @@ def main():
     hist.setdefault('round_3_split_kernel_one_barrier_form', 1110000000)
     d = {'_comment': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `python bench.py '
                      '--steps 3 --warmup 1 --no-cpu-baseline --no-overlap` (tools/pmc_traffic.py). Per launch of '
-                     'the dominant stencil instance (k_gconv3w<8,4>; HPL_MATH=f32: k_gconv<64,128,2,4,true,...>), averaged over its four launches per step. Counter unit KiB; FETCH_SIZE '
+                     'the dominant stencil instance (k_gconv3w<8,4,planes>; HPL_MATH=f32: k_gconv<64,128,2,4,true,...>), averaged over its four launches per step. Counter unit KiB; FETCH_SIZE '
                      'doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane reads), WRITE_SIZE as is.',
          'fetch_size_kib_per_launch_raw': fetch_kib, 'write_size_kib_per_launch': write_kib, 'launches_fetch_pass': f[fk][0],
          'k_gconv_64x128_bytes_per_launch': total, 'dominant_bytes_per_launch': total, 'dominant_kernel': fk,
