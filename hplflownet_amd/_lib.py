@@ -44,7 +44,7 @@ class GConvDesc(ctypes.Structure):
                 ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64),
                 ('tile_idx', c_vp), ('tile_mask', c_vp), ('tile_bm', c_i32), ('clock_probe', c_vp),
                 ('Y2', c_vp), ('ldy2', c_i64), ('rows2', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64),
-                ('wt3_planes', c_i32), ('a_amax', c_vp), ('w_amax', c_vp)]
+                ('wt3_planes', c_i32), ('a_amax', c_vp), ('w_amax', c_vp), ('y_amax', c_vp)]
 
 
 class Ref(ctypes.Structure):
@@ -137,6 +137,7 @@ _SIGNATURES = {
     'hpl_tap_lists': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'hpl_colsum': (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     'hpl_leaky_bwd': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_i64, ctypes.c_int, c_vp]),
+    'hpl_leaky_bwd_amax': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_vp]),
     'hpl_transpose': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     'hpl_table_symmetric': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, c_vp]),
     'hpl_lattice_keys': (ctypes.c_int, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),

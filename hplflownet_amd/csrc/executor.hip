@@ -157,6 +157,7 @@ struct Runner {
     bool side_busy = false;                 // side-stream work the main stream has not waited for yet
     float *amax_base = nullptr;             // AMAX_SLOTS scalars in the workspace (cleared when a run starts at op 0)
     const float *cur_a_amax = nullptr, *cur_b_amax = nullptr;      // of the op being issued (prepare_amax)
+    float *cur_y_amax = nullptr;            // where the op being issued leaves the largest magnitude of what it writes (or null)
 
     // the largest magnitude of columns [0, cols) of a view, reduced on the MAIN stream unless this run already has it
     int amax_of(const hpl_ref &r, const View &v, int64_t rows, int cols, const float *&slot) {
@@ -171,24 +172,43 @@ struct Runner {
         slot = dst;
         return HPL_OK;
     }
-    void amax_forget(int buf) {
-        if (buf < 0) return;
-        for (size_t i = 0; i < pl.amax.size();)
-            if (pl.amax[i].buf == buf) { pl.amax[i] = pl.amax.back(); pl.amax.pop_back(); } else ++i;
+    // an op writes columns [col_off, col_off + cols) of a matrix: reductions over any of them are stale
+    void amax_forget(const hpl_ref &r) {
+        if (r.buf < 0) return;
+        for (size_t i = 0; i < pl.amax.size();) {
+            const auto &e = pl.amax[i];
+            if (e.buf == r.buf && e.col_off < r.col_off + r.cols && r.col_off < e.col_off + e.cols) { pl.amax[i] = pl.amax.back(); pl.amax.pop_back(); }
+            else ++i;
+        }
     }
+    // the op just issued left the largest magnitude of rows [off, off + rows) x its N columns of `out` in cur_y_amax
+    void amax_produced(const hpl_op &op) {
+        if (!cur_y_amax || op.out.buf < 0) return;
+        pl.amax.push_back({op.out.buf, symv(sym, op.out.row_off_sym), symv(sym, op.m_sym), op.out.col_off, op.N, cur_y_amax});
+        cur_y_amax = nullptr;
+    }
+    float *amax_slot() { return pl.amax_used < AMAX_SLOTS ? amax_base + pl.amax_used++ : nullptr; }
     // wide launches in the fp16-pair mode scale their operands by their largest magnitudes: reduce them (main stream, before a
     // side-stream op is fenced) for the ops that can qualify (gconv_common.h split3_maybe / wgrad3.hip's test)
-    int prepare_amax(const hpl_op &op) {
+    int prepare_amax(const hpl_op &op, bool side) {
         cur_a_amax = cur_b_amax = nullptr;
+        cur_y_amax = nullptr;
         if (hpl_gc::split_planes() != 2) return HPL_OK;
         View A, B;
         int rc;
+        if (op.kind == HPL_OP_LEAKY_BWD) {          // its result usually feeds a wide data / weight gradient: reduce it on the way
+            if (!side && op.out.buf >= 0 && op.N >= 128 && symv(sym, op.m_sym) >= 1024) cur_y_amax = amax_slot();
+            return HPL_OK;
+        }
         if (op.kind == HPL_OP_GCONV) {
             if (op.weight < 0 || op.weight >= (int)pl.weights.size() || pl.weights[op.weight].wt3_planes != 2 || !pl.weights[op.weight].Wt3) return HPL_OK;
             const int64_t M = symv(sym, op.m_sym);
             if ((op.flags & HPL_FLAG_SCATTER) || !hpl_gc::split3_maybe(M, op.C, op.F > 15 ? 15 : op.F, op.N)) return HPL_OK;
             if ((rc = view(op.a, A, "gconv input"))) return rc;
-            return amax_of(op.a, A, A.rows, op.C, cur_a_amax);
+            if ((rc = amax_of(op.a, A, A.rows, op.C, cur_a_amax))) return rc;
+            // a wide launch's result usually feeds the next wide launch (the 1x1 convs behind a blur conv): its epilogue reduces it
+            if (!side && op.out.buf >= 0 && op.N >= 128) cur_y_amax = amax_slot();
+            return HPL_OK;
         }
         if (op.kind == HPL_OP_WGRAD) {
             const int64_t M = symv(sym, op.m_sym);
@@ -347,6 +367,7 @@ struct Runner {
             }
             d.Y = Y.p; d.ldy = Y.ld;
             if (last && has_out2) { d.Y2 = Y2.p; d.ldy2 = Y2.ld; d.rows2 = rows2; }
+            if (last && cur_y_amax && !scatter) d.y_amax = cur_y_amax;
             d.row_perm = row_perm;
             if (row_perm && ti && tm) { d.tile_idx = ti; d.tile_mask = tm; d.tile_bm = ngroups >= 2 ? t.group_tile_bm : t.tile_bm; }
             // split-operand image of the same rows (csrc/gconv3.hip takes the launch if it qualifies): k-blocks of 8 rows
@@ -484,7 +505,7 @@ struct Runner {
             if ((rc = view(op.a, A, "leaky_bwd dY")) || (rc = view(op.b, B, "leaky_bwd Y")) || (rc = view(op.out, Y, "leaky_bwd dX"))) return rc;
             const int64_t M = symv(sym, op.m_sym);
             HPL_REQUIRE(A.rows >= M && B.rows >= M && Y.rows >= M && A.cols >= op.N && B.cols >= op.N && Y.cols >= op.N, "hpl_plan_run: leaky_bwd shapes");
-            return hpl_leaky_bwd(A.p, A.ld, B.p, B.ld, op.slope, Y.p, Y.ld, M, op.N, hs);
+            return hpl_leaky_bwd_amax(A.p, A.ld, B.p, B.ld, op.slope, Y.p, Y.ld, M, op.N, cur_y_amax, hs);
         }
         case HPL_OP_COLSUM: {
             if ((rc = view(op.a, A, "colsum input"))) return rc;
@@ -786,14 +807,15 @@ extern "C" int hpl_plan_run_range(hpl_plan *plan, const hpl_level_tables *levels
         if ((rc = active(op, run))) return rc;
         if (!run) continue;
         const bool side = r.side_s && (op.flags & HPL_FLAG_SIDE);
-        if ((rc = r.prepare_amax(op))) return rc;
-        r.amax_forget(op.out.buf);
-        r.amax_forget(op.out2.buf);
+        if ((rc = r.prepare_amax(op, side))) return rc;
+        r.amax_forget(op.out);
+        r.amax_forget(op.out2);
         if (side) { if ((rc = r.to_side())) return rc; }
         else if (op.kind == HPL_OP_UNLAYOUT && (rc = r.join())) return rc;       // (it reads what the side-stream wgrads wrote)
         rc = r.run_op(op);
         if (side) r.to_main();
         if (rc) return rc;
+        r.amax_produced(op);
     }
     if (!join) return HPL_OK;
     r.side_busy = r.side_s != nullptr;         // (earlier ranges of the same step may have left work there)

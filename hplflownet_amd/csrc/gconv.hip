@@ -578,6 +578,8 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     p.planes = d->wt3_planes == 2 ? 2 : 3; p.a_amax = d->a_amax; p.w_amax = d->w_amax;
     HPL_REQUIRE(!d->Wt3 || d->wt3_planes == 0 || d->wt3_planes == 2 || d->wt3_planes == 3, "%s: wt3_planes = %d", who, d->wt3_planes);
     if (p.planes == 2 && !(p.a_amax && p.w_amax)) p.Wt3 = nullptr;      // fp16 pairs need both scales: the launch stays on the fp32 MFMA
+    p.y_amax = d->y_amax; p.y_amax_done = 0;
+    HPL_REQUIRE(!(d->y_amax && d->scat), "%s: y_amax with a scatter epilogue", who);
     p.col_share = 0; p.col_rows = 0;
     p.tiles_m = p.tiles_n = 0;
     p.a_bytes = ((d->rows_a - 1) * d->lda + d->C) * 4;
@@ -683,6 +685,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
             k_gconv_finish<<<g, 256, 0, s>>>(p);
         }
         HPL_CHECK_LAUNCH("hpl_gconv_forward");
+        if (p.y_amax && !p.y_amax_done) return amax_launch(p.Y, p.ldy, p.M, p.N, p.y_amax, s);
         return HPL_OK;
     }
     // Tile selection.
@@ -707,6 +710,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
         k_gconv_finish<<<g, 256, 0, s>>>(p);
     }
     HPL_CHECK_LAUNCH("hpl_gconv_forward");
+    if (p.y_amax) return amax_launch(p.Y, p.ldy, p.M, p.N, p.y_amax, s);
     return HPL_OK;
 }
 

@@ -65,7 +65,7 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned
 }
 
 // PL = 2 (round 5): (x0, x1) * s -> packed fp16 pairs hi / lo, hi = rne(x s), lo = rne(x s - hi): x s = hi + lo up to 2^-22 |x s|
-// (s: the power of two that puts the matrix's largest magnitude into [2^13, 2^14), gconv_common.h split_scale; the residual
+// (s: the power of two that puts the matrix's largest magnitude into [2^14, 2^15), gconv_common.h split_scale; the residual
 // x s - hi is exact in fp32, so lo is ONE rounding).  Three partial products hi*hi + hi*lo + lo*hi on the fp16 MFMA.
 __device__ __forceinline__ void split2h(float x0, float x1, float s, unsigned &h, unsigned &l) {
     const float2_t v = {x0 * s, x1 * s};
@@ -94,7 +94,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     constexpr int A_STAGE = PL * 2 * BM * 16;       // bytes: [plane][kb 0..1][row][8 x 16 bit]
     constexpr int B_STAGE = PL * 2 * BN * 16;       //        [plane][kb 0..1][n][8 x 16 bit]
     constexpr int NA = 3;                            // stages of the gathered-row ring
-    constexpr int ASETS = NB - 1;                    // register sets of gathered rows in flight
+    static_assert(NB >= 3 && NB <= 5, "weight ring of 3 .. 5 stages");
+    constexpr int ASETS = NB >= 4 ? 3 : NB - 1;     // register sets of gathered rows in flight
     constexpr int B_BASE = NA * A_STAGE;             // LDS: A ring | B ring | indices
     constexpr int B_CHUNKS_PER_WAVE = PL;           // 2 * PL * WGN chunks of 1 KiB per half-step over 2 * WGN waves
     constexpr int KLIST = 1024;
@@ -434,6 +435,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                         af[pl][i] = *reinterpret_cast<const u32x4 *>(sa + a_rofs[i] + pl * 2 * BM * 16);
                         bf[pl][i] = *reinterpret_cast<const u32x4 *>(sb + b_rofs + pl * 2 * BN * 16 + i * 32 * 16);
                     }
+                // (PL = 2, round 5: split + store moved up here, where the wave waits for the barrier anyway: 411 -> 434 us on bcn1_'s
+                // first pass, 273 -> 291 us on bcn2_'s -- it stays in the compute phase)
                 // the loads of the compute phase before last have landed (in flight: the last compute phase's); fragments here,
                 // the LDS stores of the last compute phase done
                 wait_vm_lgkm0(inflight_tag);
@@ -549,8 +552,17 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             const int k1 = kt_at(sl + 1), kl = ks_at(sl + ASETS);
             if constexpr (PP) {
                 // (the wait closes the memory phase: in flight = what the compute phase of the half-step before issued)
-                halfstep(e, 0, T{}, k1, 1, T{}, SW{}, T{}, SL{}, ks_at(sl + ASETS + 1), std::integral_constant<int, NLB>{});
-                halfstep(e, 1, T{}, kt_at(sl + 2), 0, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB + NLA>{});
+                if constexpr (NB == 5) {
+                    // (round 5, fp16 pairs: half the MFMAs per half-step = half the time a load has to land.  Five weight stages, four
+                    // half-steps ahead, and the wait leaves the loads of the last TWO compute phases in flight: a load has five barrier
+                    // intervals instead of three.  A register set is stored four half-steps after its loads: covered by the same wait.)
+                    const int k2 = kt_at(sl + 2);
+                    halfstep(e, 0, T{}, k2, 0, T{}, SW{}, T{}, SL{}, ks_at(sl + ASETS + 1), std::integral_constant<int, 2 * NLB + NLA>{});
+                    halfstep(e, 1, T{}, k2, 1, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, 2 * NLB + NLA>{});
+                } else {
+                    halfstep(e, 0, T{}, k1, 1, T{}, SW{}, T{}, SL{}, ks_at(sl + ASETS + 1), std::integral_constant<int, NLB>{});
+                    halfstep(e, 1, T{}, kt_at(sl + 2), 0, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB + NLA>{});
+                }
             } else
             if constexpr (NB == 3) {
                 halfstep(e, 0, T{}, k1, 0, T{}, SW{}, T{}, SL{}, kl, std::integral_constant<int, NLB + NLA>{});
@@ -633,6 +645,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             p.Y2 ? (void *)p.Y2 : (void *)p.Y, (short)0, (p.Y2 && p.splits <= 1) ? 0x7fffffff : 0, 0x00020000);   // (split-K partials never go to Y2: k_gconv_finish writes it)
         const unsigned ldy_b = (unsigned)(p.splits > 1 ? p.N : p.ldy) * 4u, ldr_b = (unsigned)p.ldres * 4u, ldy2_b = (unsigned)p.ldy2 * 4u;
         const bool plain = p.splits <= 1;
+        unsigned ymax = 0;                                   // largest |y| this lane stores (p.y_amax)
         const bool res_wrap = p.res && p.res_mod < p.M;      // (uniform)
         const float res_inv = res_wrap ? 1.0f / (float)p.res_mod : 0.f;
 #pragma unroll
@@ -670,11 +683,17 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                         if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
                     }
                     const unsigned yo = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldy_b) + nb : OOB;
+                    ymax = max(ymax, (mrow[r] >= 0 && n < p.N) ? (__builtin_bit_cast(unsigned, v) & 0x7fffffffu) : 0u);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (int)yo, 0, 0);
                     const unsigned y2o = (mrow[r] >= 0 && mrow[r] < (int)p.rows2) ? __umul24((unsigned)mrow[r], ldy2_b) + nb : OOB;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y2, (int)y2o, 0, 0);
                 }
             }
+        if (p.y_amax && plain) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ymax = max(ymax, (unsigned)__shfl_xor((int)ymax, o));
+            if (lane == 0 && ymax) atomicMax(reinterpret_cast<unsigned *>(p.y_amax), ymax);
+        }
     } else
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -977,13 +996,17 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
         static const int epi = getenv("HPL_SPLIT3_EPILOGUE") ? atoi(getenv("HPL_SPLIT3_EPILOGUE")) : 1;
         if (!epi) p.epi_fast = 0;
     }
+    p.y_amax_done = (p.y_amax && p.epi_fast && p.splits <= 1) ? 1 : 0;      // (else hpl_gconv_forward reduces Y afterwards)
     // instances by the taps whose indices a tile stages in LDS: 1 (dense GEMMs), <= 8 (tap-group passes), <= 15
     // (a three-stage weight ring for the 256-wide tile was A/B'd in round 3 and lost: four stages stay)
+#ifndef HPL_PP2_NB
+#define HPL_PP2_NB 4
+#endif
     if (p.planes == 2) {
         if (bn256) {
-            if (p.F == 1) k_gconv3w<1, 4, 2><<<grid, 512, 0, s>>>(p);
-            else if (p.F <= 8) k_gconv3w<8, 4, 2><<<grid, 512, 0, s>>>(p);
-            else k_gconv3w<15, 4, 2><<<grid, 512, 0, s>>>(p);
+            if (p.F == 1) k_gconv3w<1, HPL_PP2_NB, 2><<<grid, 512, 0, s>>>(p);
+            else if (p.F <= 8) k_gconv3w<8, HPL_PP2_NB, 2><<<grid, 512, 0, s>>>(p);
+            else k_gconv3w<15, HPL_PP2_NB, 2><<<grid, 512, 0, s>>>(p);
         } else {
             if (p.F == 1) k_gconv3<2, 1, 2><<<grid, 256, 0, s>>>(p);
             else if (p.F <= 8) k_gconv3<2, 8, 2><<<grid, 256, 0, s>>>(p);

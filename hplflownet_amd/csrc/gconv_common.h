@@ -28,14 +28,14 @@ __device__ __forceinline__ int32x4_t make_rsrc(const void *base, int bytes) {
 }
 
 // fp16-pair operands (round 5): a matrix is multiplied by the power of two s that puts its largest magnitude `amax` into
-// [2^13, 2^14) before it is split into fp16 hi + lo (hi cannot overflow -- fp16 reaches 65 504 --, lo of every element within
-// 2^-17 of the largest is a normal fp16 number, smaller ones keep an absolute error of 2^-39 amax); the product is multiplied by
+// [2^14, 2^15) before it is split into fp16 hi + lo (hi cannot overflow -- fp16 reaches 65 504 --, lo of every element within
+// 2^-18 of the largest is a normal fp16 number, smaller ones keep an absolute error of 2^-40 amax); the product is multiplied by
 // 1 / s afterwards.  amax == 0 or denormal: s = 1.  NaN / inf in amax: the products are NaN / inf as in fp32.
 __host__ __device__ __forceinline__ float split_scale(float amax) {
     unsigned bits;
     __builtin_memcpy(&bits, &amax, 4);
     const int e = (int)((bits >> 23) & 0xffu);
-    int sb = 267 - e;                        // biased exponent of 2^(13 - (e - 127))
+    int sb = 268 - e;                        // biased exponent of 2^(14 - (e - 127))
     sb = sb < 2 ? 2 : (sb > 252 ? 252 : sb);
     const unsigned sbits = e == 0 ? 0x3f800000u : ((unsigned)sb << 23);
     float s;
@@ -78,6 +78,7 @@ struct GParams {
     const void *Wt3; int64_t w3_plane_stride;      // split weight image (hpl_weight_split3 / hpl_weight_split2h) or nullptr
     int planes;                         // 3: bf16 triples; 2: fp16 pairs, with the largest magnitudes of A / of the weight image:
     const float *a_amax; const float *w_amax;      //   DEVICE scalars (hpl_amax; hpl_weight_split2h)
+    float *y_amax; int y_amax_done;     // optional: largest |Y| stored -> *y_amax (done = 1: the kernel's epilogue did it)
     int epi_fast;                       // 32-bit buffer addressing in the epilogue (set by the launch functions)
 };
 

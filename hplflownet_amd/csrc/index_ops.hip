@@ -2,6 +2,7 @@
 // table narrowing, corr-table permutation, the splat CSR build, transpose, column sums,
 // LeakyReLU backward.  All HBM-bound; written for 64-wide waves, 256-thread groups.
 #include "common.h"
+#include "gconv_common.h"
 
 #include <string.h>
 
@@ -362,13 +363,51 @@ __global__ void k_leaky_bwd(const float *__restrict__ dY, int64_t lddy, const fl
     }
 }
 
+// four columns per thread (N % 4 == 0, 16-byte aligned rows); amax (optional): *amax = max(*amax, largest |dX|) -- the scale the
+// wide data / weight gradients that read dX need (hpl_gconv_desc.a_amax), from the values while they are in registers
+__global__ void __launch_bounds__(256) k_leaky_bwd4(const float *__restrict__ dY, int64_t lddy, const float *__restrict__ Y, int64_t ldy,
+                                                    float slope, float *__restrict__ dX, int64_t lddx, int64_t M, int N4,
+                                                    unsigned *__restrict__ amax) {
+    const int64_t total = M * N4;
+    unsigned vmax = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / N4;
+        const int n = (int)(i - m * N4) * 4;
+        const float4 y = *reinterpret_cast<const float4 *>(Y + m * ldy + n);
+        float4 g = *reinterpret_cast<const float4 *>(dY + m * lddy + n);
+        g.x *= y.x > 0.f ? 1.0f : slope;
+        g.y *= y.y > 0.f ? 1.0f : slope;
+        g.z *= y.z > 0.f ? 1.0f : slope;
+        g.w *= y.w > 0.f ? 1.0f : slope;
+        *reinterpret_cast<float4 *>(dX + m * lddx + n) = g;
+        vmax = max(max(vmax, __float_as_uint(g.x) & 0x7fffffffu), max(max(__float_as_uint(g.y) & 0x7fffffffu, __float_as_uint(g.z) & 0x7fffffffu), __float_as_uint(g.w) & 0x7fffffffu));
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, o));
+        if ((threadIdx.x & 63) == 0 && vmax) atomicMax(amax, vmax);
+    }
+}
+
 extern "C" int hpl_leaky_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, float slope,
                              float *dX, int64_t lddx, int64_t M, int N, hplStream stream) {
+    return hpl_leaky_bwd_amax(dY, lddy, Y, ldy, slope, dX, lddx, M, N, nullptr, stream);
+}
+
+extern "C" int hpl_leaky_bwd_amax(const float *dY, int64_t lddy, const float *Y, int64_t ldy, float slope,
+                                  float *dX, int64_t lddx, int64_t M, int N, float *amax, hplStream stream) {
     HPL_REQUIRE(dY && Y && dX && M >= 0 && N > 0, "hpl_leaky_bwd: bad arguments");
     if (M == 0) return HPL_OK;
+    if (N % 4 == 0 && lddy % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0 && aligned16(dY) && aligned16(Y) && aligned16(dX)) {
+        const int grid = (int)imin(cdiv(M * (N / 4), 256), 4096);
+        k_leaky_bwd4<<<grid, 256, 0, to_stream(stream)>>>(dY, lddy, Y, ldy, slope, dX, lddx, M, N / 4, reinterpret_cast<unsigned *>(amax));
+        HPL_CHECK_LAUNCH("hpl_leaky_bwd");
+        return HPL_OK;
+    }
     int grid = (int)imin(cdiv(M * N, 256), 4096);
     k_leaky_bwd<<<grid, 256, 0, to_stream(stream)>>>(dY, lddy, Y, ldy, slope, dX, lddx, M, N);
     HPL_CHECK_LAUNCH("hpl_leaky_bwd");
+    if (amax) return hpl_gc::amax_launch(dX, lddx, M, N, amax, to_stream(stream));
     return HPL_OK;
 }
 

@@ -265,7 +265,7 @@ def weight_relayout(W, R, Q, F, sr, sq, sf, base=0, fmap=None):
 class SplitW(object):
     """Split image of a weight image: `planes` uint8 [P, k_rows/8 * ldw * 16] in MFMA B-fragment order -- P = 3: bf16 planes
     hi / mid / lo with Wt == hi + mid + lo exactly (hpl_weight_split3); P = 2: fp16 planes hi / lo of Wt * s, s the power of
-    two that puts the image's largest magnitude `amax` (float32 [1], device) into [2^13, 2^14) (hpl_weight_split2h)."""
+    two that puts the image's largest magnitude `amax` (float32 [1], device) into [2^14, 2^15) (hpl_weight_split2h)."""
     __slots__ = ('planes', 'amax', 'P')
 
     def __init__(self, planes, amax, P):
@@ -315,12 +315,13 @@ def _mat(x, what):
 
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
               scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True, reg_stride=0, tiles=None,
-              out2=None, rows2=0, Wt3=None):
+              out2=None, rows2=0, Wt3=None, y_amax=None):
     """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
     row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged.
     nbr None and reg_stride > 0: tap f of row m reads row f*reg_stride + m (no table: the displacement
     filter of the correlation layer, whose taps are the F blocks of H1 virtual vertices).
-    out2 / rows2: rows m < rows2 of the result are also stored to the matrix (view) `out2`."""
+    out2 / rows2: rows m < rows2 of the result are also stored to the matrix (view) `out2`.
+    y_amax (float32 [1], device, cleared by the caller): max(y_amax, largest |Y|) is left there."""
     d = GConvDesc()
     d.A, d.lda, d.rows_a, a_cols = _mat(A, 'activation')
     if nbr is not None:
@@ -369,6 +370,8 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
         if scat is not None or rows2 > r2 or c2 < N:
             raise _lib.HplError('second destination: %d rows x %d columns for rows2=%d N=%d' % (r2, c2, rows2, N))
         d.rows2 = rows2
+    if y_amax is not None:
+        d.y_amax = ptr(y_amax)
     if row_perm is not None:
         if row_perm.dtype is not torch.int32 or row_perm.numel() != M or not row_perm.is_contiguous():
             raise _lib.HplError('row_perm must be a contiguous int32 tensor of M=%d entries' % M)
@@ -436,11 +439,12 @@ def colsum(X):
     return out
 
 
-def leaky_bwd(dY, Y, slope=LEAKY_RATE):
+def leaky_bwd(dY, Y, slope=LEAKY_RATE, amax=None):
+    """dX = dY * (Y > 0 ? 1 : slope); amax (float32 [1], cleared by the caller): max(amax, largest |dX|) is left there."""
     dY, Y = _cl(dY, 'dY'), _cl(Y, 'Y')
     dX = torch.empty(tuple(Y.shape), dtype=torch.float32, device=Y.device)
-    check(_lib.load().hpl_leaky_bwd(ptr(dY), _ld(dY), ptr(Y), _ld(Y), slope, ptr(dX), _ld(dX), Y.shape[0],
-                                    Y.shape[1], stream()), 'hpl_leaky_bwd')
+    check(_lib.load().hpl_leaky_bwd_amax(ptr(dY), _ld(dY), ptr(Y), _ld(Y), slope, ptr(dX), _ld(dX), Y.shape[0],
+                                         Y.shape[1], ptr(amax), stream()), 'hpl_leaky_bwd')
     return dX
 
 

@@ -169,7 +169,7 @@ int hpl_weight_unlayout_batch(const hpl_relayout_job *jobs /* DEVICE */, int njo
  * mid = bf16_rne(w - hi), lo = bf16_rne(w - hi - mid): w == hi + mid + lo exactly.  plane_stride >= k_rows*ldw*2. */
 int hpl_weight_split3(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride, hplStream stream);
 /* The fp16-pair form (hpl_gconv_desc.wt3_planes == 2): *amax (DEVICE) = the image's largest magnitude, s = the power of two
- * that puts it into [2^13, 2^14); two planes of fp16 in the same fragment order, hi = f16_rne(w s), lo = f16_rne(w s - hi). */
+ * that puts it into [2^14, 2^15); two planes of fp16 in the same fragment order, hi = f16_rne(w s), lo = f16_rne(w s - hi). */
 int hpl_weight_split2h(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride, float *amax,
                        hplStream stream);
 /* The same for many images in one launch (a training step re-splits every wide image after the optimiser step): jobs in DEVICE
@@ -261,14 +261,17 @@ typedef struct hpl_gconv_desc {
     /* wt3_planes == 2 (round 5): Wt3 is hpl_weight_split2h of the image -- two fp16 planes hi / lo of w * s_w -- and the
      * launch splits A the same way: a * s_a = hi + lo (one rounding each), the three partial products hi*hi + hi*lo + lo*hi
      * on the fp16 MFMA, fp32 accumulate, the result times 1 / (s_a s_w).  s = the power of two that puts the matrix's
-     * largest magnitude into [2^13, 2^14): a_amax / w_amax are DEVICE scalars holding those magnitudes (hpl_amax of the
+     * largest magnitude into [2^14, 2^15): a_amax / w_amax are DEVICE scalars holding those magnitudes (hpl_amax of the
      * rows and channels of A the launch can read -- or of any superset --; the one hpl_weight_split2h wrote).  Per product
-     * the error is <= 2^-21 |a b| for every a within 2^-17 of the largest; measured against float64 the sums are as close
+     * the error is <= 2^-21 |a b| for every a within 2^-18 of the largest; measured against float64 the sums are as close
      * as the fp32 MFMA's (tests/test_gpu_split3.py) at half the bf16-triple form's MFMA work.  Both scalars must be given
      * (else the launch runs on the fp32 MFMA).  wt3_planes == 0 / 3: bf16 triples as above. */
     int32_t wt3_planes;
     const float *a_amax;
     const float *w_amax;
+    /* optional (DEVICE, cleared by the caller; not with scat): *y_amax = max(*y_amax, largest |Y[m][n]| this call stores) -- the
+     * a_amax of a wide launch that reads Y next, from the epilogue's registers where the launch allows, else by one more pass. */
+    float *y_amax;
 } hpl_gconv_desc;
 
 /* Largest magnitude of X[0 .. rows)[0 .. cols) (row stride ld) -> *slot (DEVICE; NaN if X holds one). */
@@ -330,6 +333,10 @@ int hpl_colsum(const float *X, int64_t ld, int64_t M, int N, float *out, hplStre
 /* dX = dY * (Y > 0 ? 1 : slope)   element-wise on [M][N] views (LeakyReLU backward) */
 int hpl_leaky_bwd(const float *dY, int64_t lddy, const float *Y, int64_t ldy, float slope,
                   float *dX, int64_t lddx, int64_t M, int N, hplStream stream);
+/* The same; amax (optional, DEVICE): *amax = max(*amax, largest |dX|) -- the operand scale of the wide gradient launches that
+ * read dX (hpl_gconv_desc.a_amax), taken while the values are in registers.  The caller clears *amax. */
+int hpl_leaky_bwd_amax(const float *dY, int64_t lddy, const float *Y, int64_t ldy, float slope,
+                       float *dX, int64_t lddx, int64_t M, int N, float *amax, hplStream stream);
 /* out[h, n] (+)= sum_j X[(j*mod + h)*ldx + n], j < rows / mod: the gradient of a residual that was broadcast over the
  * rows / mod blocks of a result (the f-independent pc1 half of the patch correlation, models/bnn_flow.py:192). */
 int hpl_psum(const float *X, int64_t ldx, int64_t rows, int64_t mod, int N, float *out, int64_t ldo, int accumulate,

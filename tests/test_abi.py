@@ -34,7 +34,7 @@ def test_gconv_desc_layout_matches_header():
     assert fields == [f[0] for f in _lib.GConvDesc._fields_]
     assert ctypes.sizeof(_lib.GConvDesc) == (8 * 3 + 8 * 3 + 8 + 4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8
                                              + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8
-                                                 + 8 + 8 + 8)      # wt3_planes (+ padding), a_amax, w_amax
+                                                 + 8 + 8 + 8 + 8)      # wt3_planes (+ padding), a_amax, w_amax, y_amax
 
 
 def test_relayout_job_layout_matches_header():

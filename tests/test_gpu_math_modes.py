@@ -1,8 +1,9 @@
-"""GPU: the suite runs with the default arithmetic (wide layers on the bf16 MFMA with exact three-way split operands,
-csrc/gconv3.hip).  HPL_MATH=f32 keeps every launch on the fp32 MFMA -- the A/B switch of the bench numbers and the path
-of the wide fp32 kernel instances (the 64 x 128 tap-group class) that the default no longer reaches.  The switch is
-read once per process, so the fp32 mode gets its own interpreter: benchmark-size parity (configs 3 / 5: reference
-fixture + oracle), the native executor against the Python path, and the backward kernels, all with HPL_MATH=f32."""
+"""GPU: the suite runs with the default arithmetic (wide layers on the fp16 MFMA with scaled fp16-pair operands,
+csrc/gconv3.hip).  HPL_MATH=bf16x3 selects the exact bf16 triples of rounds 3-4 (twice the MFMA work), HPL_MATH=f32 keeps
+every launch on the fp32 MFMA -- the A/B switches of the bench numbers and the paths of the kernel instances the default no
+longer reaches.  The switch is read once per process, so each mode gets its own interpreter: benchmark-size parity
+(configs 3 / 5: reference fixture + oracle), the native executor against the Python path, the backward kernels and the
+native training step."""
 import os
 import subprocess
 import sys
@@ -13,13 +14,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_fp32_mfma_mode_passes_the_benchmark_size_parity_tests():
-    env = dict(os.environ, HPL_MATH='f32')
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
+def test_other_math_modes_pass_the_benchmark_size_parity_tests(mode):
+    env = dict(os.environ, HPL_MATH=mode)
     cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu',
            'tests/test_gpu_bench_size.py::test_config3_full_n8192_vs_reference_and_oracle',
            'tests/test_gpu_bench_size.py::test_weight_gradient_and_mirrored_data_gradient_at_bench_size_vs_float64',
            'tests/test_gpu_plan.py::test_native_plan_equals_python_path',
            'tests/test_gpu_split3.py::test_split3_is_deterministic_and_order_independent']
+    if mode == 'bf16x3':
+        cmd += ['tests/test_gpu_wgrad3.py', 'tests/test_gpu_train_plan.py::test_native_step_matches_autograd']
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
     assert ' passed' in p.stdout and 'failed' not in p.stdout.splitlines()[-1]

@@ -69,14 +69,14 @@ def test_split3_matches_float64_like_the_fp32_kernel(M, C, F, N, density, order,
     if planes == 3:         # the planes are an exact decomposition of the image
         pl = W3.planes.view(torch.bfloat16).view(3, k_rows // 8, Wt.shape[1], 8).float()
         assert torch.equal(pl.sum(0).permute(0, 2, 1).reshape(k_rows, Wt.shape[1]), Wt)
-    else:                   # hi + lo = w * s up to 2^-22 |w s| (lo below fp16's normal range: 2^-25 absolute), s = 2^k, amax * s in [2^13, 2^14)
+    else:                   # hi + lo = w * s up to 2^-22 |w s| (lo below fp16's normal range: 2^-25 absolute), s = 2^k, amax * s in [2^14, 2^15)
         amax = float(W3.amax)
         assert amax == float(Wt.abs().max())
-        sc = 2.0 ** (13 - int(np.floor(np.log2(amax))))
+        sc = 2.0 ** (14 - int(np.floor(np.log2(amax))))
         pl = W3.planes.view(torch.float16).view(2, k_rows // 8, Wt.shape[1], 8).double()
         back = pl.sum(0).permute(0, 2, 1).reshape(k_rows, Wt.shape[1])
         ws = Wt.double() * sc
-        assert float(pl[0].abs().max()) < 2.0 ** 14 + 8
+        assert float(pl[0].abs().max()) < 2.0 ** 15 + 16
         assert bool(((back - ws).abs() <= ws.abs() * 2.0 ** -22 + 2.0 ** -25).all())
     kw = dict(bias=bias, act=ops.ACT_LEAKY, row_perm=perm, tiles=tiles, split_k=order == 'splitk')
     y3 = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3, **kw)
@@ -153,3 +153,83 @@ def test_split3_generic_epilogue_is_bit_identical():
             outs.append(torch.load(f))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert float(outs[0][1].abs().max()) > 0 and torch.equal(outs[0][0][:9000], outs[0][1])
+
+
+def test_amax_is_the_largest_magnitude():
+    """hpl_amax (the scale of the fp16-pair operands) against torch: aligned and ragged views, zero and NaN matrices."""
+    from hplflownet_amd import ops
+    torch.manual_seed(1)
+    X = torch.randn(5000, 132, device=DEV) * torch.exp(2 * torch.randn(5000, 1, device=DEV))
+    for rows, cols, view in [(5000, 132, X), (4999, 131, X), (777, 64, X[11:, 4:]), (1, 1, X[3:, 7:]), (3000, 3, X[:, 1:])]:
+        got = float(ops.amax(view, rows=rows, cols=cols))
+        assert got == float(view[:rows, :cols].abs().max()), (rows, cols)
+    assert float(ops.amax(torch.zeros(100, 8, device=DEV))) == 0.0
+    Xn = X.clone()
+    Xn[4321, 77] = float('nan')
+    assert np.isnan(float(ops.amax(Xn)))
+    assert float(ops.amax(Xn, cols=64)) == float(X[:, :64].abs().max())
+
+
+@pytest.mark.parametrize('sa,sw', [(1.0, 1.0), (1e-25, 1e-8), (1e18, 1e-12), (3e4, 40.0), (1e-3, 1e-3)])
+def test_fp16_pairs_follow_the_scale_of_their_operands(sa, sw):
+    """The pair form scales both operands by powers of two taken from their largest magnitudes: activations of 1e-25 or 1e18
+    (far outside fp16's range) give the same relative accuracy as activations of 1."""
+    from hplflownet_amd import ops
+    torch.manual_seed(7)
+    M, C, F, N = 8192, 160, 1, 256
+    A = torch.randn(M, C, device=DEV) * sa
+    Wt = torch.randn(C, N, device=DEV) * (sw / C ** 0.5)
+    y = ops.gconv_raw(A, None, M, C, F, Wt, N, Wt3=ops.weight_split3(Wt, planes=2), split_k=False)
+    y1 = ops.gconv_raw(A, None, M, C, F, Wt, N, split_k=False)
+    ref = A.double() @ Wt.double()
+    mag = A.abs().double() @ Wt.abs().double()
+    r, r1 = float(((y.double() - ref).abs() / mag).max()), float(((y1.double() - ref).abs() / mag).max())
+    print('scales %g %g: err / sum|a||w| pairs %.3g fp32 %.3g' % (sa, sw, r, r1))
+    assert not torch.equal(y, y1) and torch.isfinite(y).all()
+    assert r < 1.25 * r1 + 1e-9 and r < 6e-7
+
+
+@pytest.mark.parametrize('outlier', [1e3, 1e5, 1e8])
+def test_fp16_pairs_with_an_outlier_in_the_matrix(outlier):
+    """ONE scale per matrix: an element `outlier` times larger than the rest pushes the small elements' lo halves towards fp16's
+    subnormals.  Up to 2^18 x nothing is lost; beyond that every element keeps an ABSOLUTE error of 2^-40 of the largest magnitude
+    (per product 2^-40 amax |w|) -- the bound include/hpl_bcl.h states -- instead of a relative one.  Zeros stay zeros."""
+    from hplflownet_amd import ops
+    torch.manual_seed(8)
+    M, C, F, N = 8192, 128, 1, 256
+    A = torch.randn(M, C, device=DEV)
+    A[5, 9] = outlier
+    A[100:200] = 0
+    Wt = torch.randn(C, N, device=DEV) / C ** 0.5
+    y = ops.gconv_raw(A, None, M, C, F, Wt, N, Wt3=ops.weight_split3(Wt, planes=2), split_k=False)
+    ref = A.double() @ Wt.double()
+    mag = A.abs().double() @ Wt.abs().double()
+    err = (y.double() - ref).abs()
+    bound = 6e-7 * mag + C * 2.0 ** -39 * outlier * float(Wt.abs().max())
+    assert bool((err <= bound).all()), float((err / bound).max())
+    assert float(y[100:200].abs().max()) == 0.0
+    if outlier <= 2.0 ** 17:
+        assert float((err / mag.clamp(min=1e-30)).max()) < 6e-7
+
+
+@pytest.mark.parametrize('M,C,F,N,splitk', [(16500, 64, 1, 512, False), (16400, 96, 8, 320, False), (9433, 388, 15, 256, True), (3000, 40, 1, 48, False)])
+def test_a_launch_can_leave_the_largest_magnitude_of_its_result(M, C, F, N, splitk):
+    """hpl_gconv_desc.y_amax: the scale of the NEXT wide launch from this launch's epilogue (fast split epilogue: in registers;
+    split-K, generic or fp32-MFMA launches: one more pass) -- always the exact largest |Y| after bias, residual and LeakyReLU."""
+    from hplflownet_amd import ops
+    torch.manual_seed(M)
+    A = torch.randn(M + 5, C, device=DEV)
+    Wt = torch.zeros(ops.round_up(F * C, 32), ops.round_up(N, 4), device=DEV)
+    Wt[:F * C, :N] = torch.randn(F * C, N, device=DEV) / (F * C) ** 0.5
+    nbr = _table(M, M + 5, F, 0.7, 2) if F > 1 else None
+    perm = ops.tap_order(nbr) if F > 1 else None
+    res = torch.randn(M, N, device=DEV) * 3
+    slot = torch.zeros(1, device=DEV)
+    W3 = ops.weight_split3(Wt) if N >= 256 else None
+    y = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3, bias=torch.randn(N, device=DEV), act=ops.ACT_LEAKY, res=res, row_perm=perm,
+                      split_k=splitk, y_amax=slot)
+    assert float(slot) == float(y.abs().max())
+    g = torch.randn(M, N, device=DEV)
+    slot.zero_()
+    dx = ops.leaky_bwd(g, y, amax=slot)
+    assert torch.equal(dx, g * torch.where(y > 0, 1.0, ops.LEAKY_RATE)) and float(slot) == float(dx.abs().max())
