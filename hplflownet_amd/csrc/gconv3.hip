@@ -94,8 +94,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     constexpr int A_STAGE = PL * 2 * BM * 16;       // bytes: [plane][kb 0..1][row][8 x 16 bit]
     constexpr int B_STAGE = PL * 2 * BN * 16;       //        [plane][kb 0..1][n][8 x 16 bit]
     constexpr int NA = 3;                            // stages of the gathered-row ring
-    static_assert(NB >= 3 && NB <= 5, "weight ring of 3 .. 5 stages");
-    constexpr int ASETS = NB >= 4 ? 3 : NB - 1;     // register sets of gathered rows in flight
+    static_assert(NB == 3 || NB == 4, "weight ring of 3 or 4 stages");
+    constexpr int ASETS = NB - 1;                    // register sets of gathered rows in flight
     constexpr int B_BASE = NA * A_STAGE;             // LDS: A ring | B ring | indices
     constexpr int B_CHUNKS_PER_WAVE = PL;           // 2 * PL * WGN chunks of 1 KiB per half-step over 2 * WGN waves
     constexpr int KLIST = 1024;
@@ -552,17 +552,11 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
             const int k1 = kt_at(sl + 1), kl = ks_at(sl + ASETS);
             if constexpr (PP) {
                 // (the wait closes the memory phase: in flight = what the compute phase of the half-step before issued)
-                if constexpr (NB == 5) {
-                    // (round 5, fp16 pairs: half the MFMAs per half-step = half the time a load has to land.  Five weight stages, four
-                    // half-steps ahead, and the wait leaves the loads of the last TWO compute phases in flight: a load has five barrier
-                    // intervals instead of three.  A register set is stored four half-steps after its loads: covered by the same wait.)
-                    const int k2 = kt_at(sl + 2);
-                    halfstep(e, 0, T{}, k2, 0, T{}, SW{}, T{}, SL{}, ks_at(sl + ASETS + 1), std::integral_constant<int, 2 * NLB + NLA>{});
-                    halfstep(e, 1, T{}, k2, 1, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, 2 * NLB + NLA>{});
-                } else {
-                    halfstep(e, 0, T{}, k1, 1, T{}, SW{}, T{}, SL{}, ks_at(sl + ASETS + 1), std::integral_constant<int, NLB>{});
-                    halfstep(e, 1, T{}, kt_at(sl + 2), 0, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB + NLA>{});
-                }
+                // (round 5, fp16 pairs: half the MFMAs per half-step = half the time a load has to land.  Measured: a weight ring of FIVE
+                // stages, four half-steps ahead, with the wait leaving the loads of the last two compute phases in flight -- five barrier
+                // intervals per load instead of three: 387 vs 388 us on bcn1_'s first pass.  Load latency is not what the pair form waits for.)
+                halfstep(e, 0, T{}, k1, 1, T{}, SW{}, T{}, SL{}, ks_at(sl + ASETS + 1), std::integral_constant<int, NLB>{});
+                halfstep(e, 1, T{}, kt_at(sl + 2), 0, T{}, SW{}, Fl{}, SL{}, 0, std::integral_constant<int, NLB + NLA>{});
             } else
             if constexpr (NB == 3) {
                 halfstep(e, 0, T{}, k1, 0, T{}, SW{}, T{}, SL{}, kl, std::integral_constant<int, NLB + NLA>{});
@@ -999,14 +993,11 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     p.y_amax_done = (p.y_amax && p.epi_fast && p.splits <= 1) ? 1 : 0;      // (else hpl_gconv_forward reduces Y afterwards)
     // instances by the taps whose indices a tile stages in LDS: 1 (dense GEMMs), <= 8 (tap-group passes), <= 15
     // (a three-stage weight ring for the 256-wide tile was A/B'd in round 3 and lost: four stages stay)
-#ifndef HPL_PP2_NB
-#define HPL_PP2_NB 4
-#endif
     if (p.planes == 2) {
         if (bn256) {
-            if (p.F == 1) k_gconv3w<1, HPL_PP2_NB, 2><<<grid, 512, 0, s>>>(p);
-            else if (p.F <= 8) k_gconv3w<8, HPL_PP2_NB, 2><<<grid, 512, 0, s>>>(p);
-            else k_gconv3w<15, HPL_PP2_NB, 2><<<grid, 512, 0, s>>>(p);
+            if (p.F == 1) k_gconv3w<1, 4, 2><<<grid, 512, 0, s>>>(p);
+            else if (p.F <= 8) k_gconv3w<8, 4, 2><<<grid, 512, 0, s>>>(p);
+            else k_gconv3w<15, 4, 2><<<grid, 512, 0, s>>>(p);
         } else {
             if (p.F == 1) k_gconv3<2, 1, 2><<<grid, 256, 0, s>>>(p);
             else if (p.F <= 8) k_gconv3<2, 8, 2><<<grid, 256, 0, s>>>(p);
