@@ -17,7 +17,7 @@ gen = H.GenerateDataUnsymmetric(a, device=dev, wide_up=model.lattice_hint())
 pc1, pc2, sf = synthetic_pair(N, 0)
 t1, t2, tsf = [torch.from_numpy(x.T.copy()).to(dev) for x in (pc1, pc2, sf)]
 lat = gen.build_native(t1, t2).device_lattice().prepare(True)
-opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=bool(os.environ.get('PROBE_FUSED_ADAM')))
+opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=not os.environ.get('PROBE_UNFUSED_ADAM'))      # (engine.Trainer and bench.py use the fused optimizer)
 
 def timed(fn, n=10, warm=3):
     for _ in range(warm): fn()
