@@ -18,7 +18,10 @@ Printed JSON (rank 0, one line): the contract fields plus
                 HBM roofline with the algorithmic bytes of SURVEY.md §8 d2);
   train         BASELINE config 4 on this GPU: 8 training steps on the same pairs (fwd + bwd + all-reduce + Adam);
   cpu_baseline  the CPU oracle ("port": C lattice + the faster of the numpy/BLAS and torch-CPU layer ports) timed on this
-                host on a bounded sample of the same workload (rank 0, N=1 only); it doubles as the EPE3D parity check.
+                host on a bounded sample of the same workload (rank 0, N=1 only); it doubles as the EPE3D parity check;
+  exact_bf16x3  (default run, N=1) the same workload with the exact operand form of rounds 3-4 -- bf16 triples, six partial
+                products instead of the three of the scaled fp16 pairs `value` is measured with -- from a subprocess with
+                HPL_MATH=bf16x3 after this run's timed regions: both arithmetics in one line.
 """
 import argparse
 import json
@@ -1045,6 +1048,25 @@ def main():
                              'max_abs_flow_diff': float(np.abs(flow_gpu - flow_cpu).max()),
                              'note': 'random-init weights: parity number, not accuracy'}
             line['speedup_vs_cpu_baseline'] = line['value'] / base['value']
+        if (world == 1 and full and not a.train and not a.no_cpu_baseline and ops.SPLIT_PLANES == 2 and ops.SPLIT3
+                and not os.environ.get('HPL_BENCH_SUBRUN') and a.points == 8192 and a.data == 'frustum'):
+            # The same workload with the EXACT operand form of rounds 3-4 (bf16 triples, six partial products), in a process of its own
+            # (the mode is read once per process), on the now idle GPU: the headline's arithmetic is the scaled fp16 pair (operands to
+            # 2^-22, sums measured closer to float64 than the fp32 MFMA's) -- a reader who wants fp32 operands carried exactly finds
+            # that number here, from the same run.
+            try:
+                torch.cuda.synchronize()
+                env = dict(os.environ, HPL_MATH='bf16x3', HPL_BENCH_SUBRUN='1', HPL_BENCH_NO_POWER='1')
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', '100', '--warmup', '10', '--no-train-probe'],
+                                     env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=420).stdout
+                sub = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+                line['exact_bf16x3'] = {'value': sub['value'], 'unit': sub['unit'], 'steps': sub['steps'], 'ms_per_step': sub['ms_per_step'],
+                                        'steady': (sub.get('steady') or {}).get('value'), 'dtype': sub['dtype'],
+                                        'epe3d_abs_delta_vs_cpu_oracle': (sub.get('epe3d') or {}).get('abs_delta'),
+                                        'roofline_frac': sub['roofline'].get('frac'), 'roofline_avg_launch_us': sub['roofline'].get('avg_launch_us'),
+                                        'note': 'python bench.py --steps 100 with HPL_MATH=bf16x3 in a subprocess after the timed regions of this run'}
+            except Exception as e_:
+                line['exact_bf16x3'] = {'error': repr(e_)[:200]}
         if line['ranks']['ranks_seen'] != line['n_gpus'] or line['n_gpus'] != a.gpus:
             raise SystemExit('bench.py: %d of %d ranks reported (--gpus %d): not printing a line for a job of another size'
                              % (line['ranks']['ranks_seen'], line['n_gpus'], a.gpus))

@@ -960,7 +960,7 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     constexpr int wide = 256;
     // any N: columns past N are neither loaded (the image's row length bounds the loads) nor stored; the wider tile unless
     // its padding costs more than it gains (N = 580, the data gradient of bcn1_: 3 x 256 = 768 vs 5 x 128 = 640 columns)
-    constexpr int pct = 108;
+    constexpr int pct = 108;      // (round 5, fp16 pairs: 135 -- the 256-wide tile for the data gradients too -- 539 -> 600 us, 332 -> 380 us)
     const bool bn256 = splitk > 1 || (wide == 256 && cdiv(p.N, 256) * 256 * 100 <= cdiv(p.N, 128) * 128 * pct);
     const int BN = bn256 ? 256 : 128;
     p.tiles_n = (int)cdiv(p.N, BN);

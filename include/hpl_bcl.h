@@ -263,8 +263,10 @@ typedef struct hpl_gconv_desc {
      * on the fp16 MFMA, fp32 accumulate, the result times 1 / (s_a s_w).  s = the power of two that puts the matrix's
      * largest magnitude into [2^14, 2^15): a_amax / w_amax are DEVICE scalars holding those magnitudes (hpl_amax of the
      * rows and channels of A the launch can read -- or of any superset --; the one hpl_weight_split2h wrote).  Per product
-     * the error is <= 2^-21 |a b| for every a within 2^-18 of the largest; measured against float64 the sums are as close
-     * as the fp32 MFMA's (tests/test_gpu_split3.py) at half the bf16-triple form's MFMA work.  Both scalars must be given
+     * the error is <= 2^-21 |a b| for every a within 2^-18 of the largest (smaller ones: 2^-40 of the largest, absolute), per
+     * output <= (2^-21 + (3K/16) 2^-24) sum|a||w| -- below the (K - 1) 2^-24 sum|a||w| of an fp32 dot product of length K >= 12
+     * in any order; measured against float64 the sums are closer than the fp32 MFMA's and the triples'
+     * (tests/test_gpu_split3.py) at half the bf16-triple form's MFMA work.  Both scalars must be given
      * (else the launch runs on the fp32 MFMA).  wt3_planes == 0 / 3: bf16 triples as above. */
     int32_t wt3_planes;
     const float *a_amax;
