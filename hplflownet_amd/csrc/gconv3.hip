@@ -453,6 +453,10 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 // to the 815-835 of the bare MFMAs: an instruction beside the MFMAs costs 5-10 cycles of issue, nothing is free.
                 // With all three groups in the memory phase instead: 1190 / 790 (before the instruction trims); with the gathered
                 // loads and the stores there 617 us against 597 us for the launch: this split is the fastest of the four tried.
+                // Round 5, pair form, timing-only builds without one group each (bcn1_'s first pass, 403 us): no weight loads 378, no
+                // index reads + gathered loads 375, no split + store 366, none of the three 320 us -- against 131 us of matrix-pipe time.
+                // The staging is a fifth of the launch; the rest is the tile structure itself (rounds of unequal tiles, wave rows
+                // without a tap of the slice, prologue / epilogue, the phases' barriers).
                 auto others = [&]() {
                     if constexpr (B) load_b(kt_b, hb_b, stb2);
                     // (the row indices of these loads were read from LDS one slice ago -- no wait on the LDS queue, which the
