@@ -772,17 +772,31 @@ __device__ __forceinline__ void amax_reduce(unsigned v, unsigned *slot) {
     }
 }
 
+// a block covers 256 >> tpr_log rows at a time, 2^tpr_log lanes across a row's columns (V = float4 / float): no division in the loops
 template <typename V>
-__global__ void __launch_bounds__(256) k_amax(const float *__restrict__ X, int64_t ld, int64_t rows, int colsv, unsigned *__restrict__ slot) {
+__global__ void __launch_bounds__(256) k_amax(const float *__restrict__ X, int64_t ld, int64_t rows, int colsv, int tpr_log, unsigned *__restrict__ slot) {
     constexpr int VW = sizeof(V) / 4;
-    const int64_t total = rows * colsv;
+    const int tpr = 1 << tpr_log, c0 = threadIdx.x & (tpr - 1), rpb = 256 >> tpr_log;
     unsigned v = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / colsv;
-        const V x = *reinterpret_cast<const V *>(X + r * ld + (i - r * colsv) * VW);
+    auto fold = [&](const V &x) {
         const unsigned *e = reinterpret_cast<const unsigned *>(&x);
 #pragma unroll
         for (int u = 0; u < VW; ++u) v = max(v, e[u] & 0x7fffffffu);
+    };
+    const int64_t rstep = (int64_t)gridDim.x * rpb;
+    int64_t r = (int64_t)blockIdx.x * rpb + (threadIdx.x >> tpr_log);
+    // four rows in flight per lane (the matrix is read once: latency, not bandwidth, sets the pace of a plain loop)
+    for (; r + 3 * rstep < rows; r += 4 * rstep) {
+        const float *p0 = X + r * ld, *p1 = p0 + rstep * ld, *p2 = p1 + rstep * ld, *p3 = p2 + rstep * ld;
+        for (int c = c0; c < colsv; c += tpr) {
+            const V a = *reinterpret_cast<const V *>(p0 + (int64_t)c * VW), b = *reinterpret_cast<const V *>(p1 + (int64_t)c * VW);
+            const V d = *reinterpret_cast<const V *>(p2 + (int64_t)c * VW), f = *reinterpret_cast<const V *>(p3 + (int64_t)c * VW);
+            fold(a); fold(b); fold(d); fold(f);
+        }
+    }
+    for (; r < rows; r += rstep) {
+        const float *p0 = X + r * ld;
+        for (int c = c0; c < colsv; c += tpr) fold(*reinterpret_cast<const V *>(p0 + (int64_t)c * VW));
     }
     amax_reduce(v, slot);
 }
@@ -877,10 +891,20 @@ extern "C" int hpl_weight_split3_batch(const hpl_split3_job *jobs, int njobs, in
 int hpl_gc::amax_launch(const float *X, int64_t ld, int64_t rows, int cols, float *slot, hipStream_t s) {
     if (rows <= 0) return HPL_OK;
     const bool vec = cols % 4 == 0 && ld % 4 == 0 && aligned16(X);
-    const int cv = vec ? cols / 4 : cols;
-    const int grid = (int)imax(1, imin(cdiv(rows * cv, 256 * 4), 2048));
-    if (vec) k_amax<float4><<<grid, 256, 0, s>>>(X, ld, rows, cv, reinterpret_cast<unsigned *>(slot));
-    else k_amax<float><<<grid, 256, 0, s>>>(X, ld, rows, cv, reinterpret_cast<unsigned *>(slot));
+    int cv = vec ? cols / 4 : cols;
+    int64_t nrows = rows;
+    if (ld == cols && (int64_t)rows * cv >= 256) {          // contiguous: any row length will do -- 256 lanes across a "row"
+        const int64_t total = rows * cv;
+        int w = 256;
+        while (total % w) w >>= 1;
+        if (w >= 64) { cv = w; nrows = total / w; ld = (int64_t)w * (vec ? 4 : 1); }
+    }
+    int tpr_log = 0;
+    while ((1 << tpr_log) < cv && tpr_log < 8) ++tpr_log;
+    const int rpb = 256 >> tpr_log;
+    const int grid = (int)imax(1, imin(cdiv(nrows, (int64_t)rpb * 4), 1024));      // (one atomic per workgroup: few, long-running workgroups)
+    if (vec) k_amax<float4><<<grid, 256, 0, s>>>(X, ld, nrows, cv, tpr_log, reinterpret_cast<unsigned *>(slot));
+    else k_amax<float><<<grid, 256, 0, s>>>(X, ld, nrows, cv, tpr_log, reinterpret_cast<unsigned *>(slot));
     HPL_CHECK_LAUNCH("hpl_amax");
     return HPL_OK;
 }
