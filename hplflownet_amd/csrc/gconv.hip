@@ -1414,7 +1414,7 @@ extern "C" int hpl_gconv_wgrad_scaled(const float *A, int64_t lda, int64_t rows_
     int64_t splits = 1;
     {
         const int64_t len = tap ? imax(1, m_len / 2) : m_len;
-        const int64_t smax = imax(1, imin(64, cdiv(len, 256)));
+        const int64_t smax = imax(1, imin(256, cdiv(len, 64)));      // (round 5: was 64 slabs of >= 256 vertices -- the 1x1 layers of levels 0-1, ONE tile, ran as 63 workgroups of 13 dependent steps)
         int64_t best = INT64_MAX;
         for (int64_t sp = 1; sp <= smax; ++sp) {
             const int64_t cost = cdiv((int64_t)tiles * sp, 512) * (cdiv(cdiv(len, sp), 32) * 32 + 256);

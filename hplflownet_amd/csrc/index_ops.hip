@@ -308,9 +308,41 @@ extern "C" int hpl_transpose(const float *src, int64_t lds, float *dst, int64_t 
 }
 
 // ---------------------------------------------------------------- column sums
-// out[n] = sum_m X[m*ld + n].  A 256-thread group covers 64 columns (one 256-byte row segment per
-// wave) x a slab of rows: 4 row lanes per column, LDS combine, one atomicAdd per (group, column).
-// `out` is zeroed by the launcher.
+// out[n] += sum_m X[m*ld + n].  Vector form (N % 4 == 0, 16-byte aligned rows): a 256-thread group covers 256 columns (64 lanes x
+// float4) x a slab of rows, 4 row lanes per column group with two rows in flight each, LDS combine, one atomicAdd per (group, column).
+// Scalar form: 64 columns per group.  `out` is zeroed by the caller.
+__global__ void __launch_bounds__(256) k_colsum4(const float *__restrict__ X, int64_t ld, int64_t M, int N,
+                                                 int64_t rows_per_block, float *__restrict__ out) {
+    __shared__ float4 part[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int n = (blockIdx.y * 64 + cx) * 4;
+    const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t m1 = imin(M, m0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t = s;
+    if (n < N) {
+        int64_t m = m0 + ry;
+        for (; m + 4 < m1; m += 8) {
+            const float4 a = *reinterpret_cast<const float4 *>(X + m * ld + n), b = *reinterpret_cast<const float4 *>(X + (m + 4) * ld + n);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+        }
+        if (m < m1) {
+            const float4 a = *reinterpret_cast<const float4 *>(X + m * ld + n);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    part[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && n < N) {
+        const float4 a = part[0][cx], b = part[1][cx], c = part[2][cx], d = part[3][cx];
+        atomicAdd(&out[n + 0], (a.x + b.x) + (c.x + d.x));
+        atomicAdd(&out[n + 1], (a.y + b.y) + (c.y + d.y));
+        atomicAdd(&out[n + 2], (a.z + b.z) + (c.z + d.z));
+        atomicAdd(&out[n + 3], (a.w + b.w) + (c.w + d.w));
+    }
+}
+
 __global__ void __launch_bounds__(256) k_colsum(const float *__restrict__ X, int64_t ld, int64_t M, int N,
                                                 int64_t rows_per_block, float *__restrict__ out) {
     __shared__ float part[4][64];
@@ -334,6 +366,13 @@ __global__ void k_zero_f32(float *p, int64_t n) {
 namespace hpl {
 void colsum_accumulate(const float *X, int64_t ld, int64_t M, int N, float *out, hipStream_t s) {
     if (M <= 0) return;
+    if (N % 4 == 0 && ld % 4 == 0 && aligned16(X)) {
+        // slabs of >= 64 rows, ~2 048 workgroups over the matrix (few atomics per column, enough workgroups to hide the loads)
+        const int64_t cg = cdiv(N, 256);
+        const int64_t rpb = imax(64, cdiv(cdiv(M, imax(1, 2048 / cg)), 8) * 8);
+        k_colsum4<<<dim3((unsigned)cdiv(M, rpb), (unsigned)cg), 256, 0, s>>>(X, ld, M, N, rpb, out);
+        return;
+    }
     const int64_t rpb = 256;
     k_colsum<<<dim3((unsigned)cdiv(M, rpb), (unsigned)cdiv(N, 64)), 256, 0, s>>>(X, ld, M, N, rpb, out);
 }
@@ -363,29 +402,46 @@ __global__ void k_leaky_bwd(const float *__restrict__ dY, int64_t lddy, const fl
     }
 }
 
-// four columns per thread (N % 4 == 0, 16-byte aligned rows); amax (optional): *amax = max(*amax, largest |dX|) -- the scale the
-// wide data / weight gradients that read dX need (hpl_gconv_desc.a_amax), from the values while they are in registers
+// four columns per thread (N % 4 == 0, 16-byte aligned rows): 2^tpr_log lanes across a row, 256 >> tpr_log rows per workgroup and
+// round, two rows in flight per lane, no division; amax (optional): *amax = max(*amax, largest |dX|) -- the scale the wide data /
+// weight gradients that read dX need (hpl_gconv_desc.a_amax), from the values while they are in registers: ONE atomic per workgroup
 __global__ void __launch_bounds__(256) k_leaky_bwd4(const float *__restrict__ dY, int64_t lddy, const float *__restrict__ Y, int64_t ldy,
-                                                    float slope, float *__restrict__ dX, int64_t lddx, int64_t M, int N4,
+                                                    float slope, float *__restrict__ dX, int64_t lddx, int64_t M, int N4, int tpr_log,
                                                     unsigned *__restrict__ amax) {
-    const int64_t total = M * N4;
+    const int tpr = 1 << tpr_log, c0 = threadIdx.x & (tpr - 1), rpb = 256 >> tpr_log;
+    const int64_t rstep = (int64_t)gridDim.x * rpb;
     unsigned vmax = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t m = i / N4;
-        const int n = (int)(i - m * N4) * 4;
-        const float4 y = *reinterpret_cast<const float4 *>(Y + m * ldy + n);
-        float4 g = *reinterpret_cast<const float4 *>(dY + m * lddy + n);
+    auto one = [&](float4 g, const float4 y, float *dst) {
         g.x *= y.x > 0.f ? 1.0f : slope;
         g.y *= y.y > 0.f ? 1.0f : slope;
         g.z *= y.z > 0.f ? 1.0f : slope;
         g.w *= y.w > 0.f ? 1.0f : slope;
-        *reinterpret_cast<float4 *>(dX + m * lddx + n) = g;
+        *reinterpret_cast<float4 *>(dst) = g;
         vmax = max(max(vmax, __float_as_uint(g.x) & 0x7fffffffu), max(max(__float_as_uint(g.y) & 0x7fffffffu, __float_as_uint(g.z) & 0x7fffffffu), __float_as_uint(g.w) & 0x7fffffffu));
+    };
+    int64_t m = (int64_t)blockIdx.x * rpb + (threadIdx.x >> tpr_log);
+    for (; m + rstep < M; m += 2 * rstep) {
+        const int64_t m2 = m + rstep;
+        for (int c = c0; c < N4; c += tpr) {
+            const float4 y0 = *reinterpret_cast<const float4 *>(Y + m * ldy + c * 4), g0 = *reinterpret_cast<const float4 *>(dY + m * lddy + c * 4);
+            const float4 y1 = *reinterpret_cast<const float4 *>(Y + m2 * ldy + c * 4), g1 = *reinterpret_cast<const float4 *>(dY + m2 * lddy + c * 4);
+            one(g0, y0, dX + m * lddx + c * 4);
+            one(g1, y1, dX + m2 * lddx + c * 4);
+        }
     }
+    if (m < M)
+        for (int c = c0; c < N4; c += tpr)
+            one(*reinterpret_cast<const float4 *>(dY + m * lddy + c * 4), *reinterpret_cast<const float4 *>(Y + m * ldy + c * 4), dX + m * lddx + c * 4);
     if (amax) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, o));
-        if ((threadIdx.x & 63) == 0 && vmax) atomicMax(amax, vmax);
+        __shared__ unsigned part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            vmax = max(max(part[0], part[1]), max(part[2], part[3]));
+            if (vmax) atomicMax(amax, vmax);
+        }
     }
 }
 
@@ -399,8 +455,10 @@ extern "C" int hpl_leaky_bwd_amax(const float *dY, int64_t lddy, const float *Y,
     HPL_REQUIRE(dY && Y && dX && M >= 0 && N > 0, "hpl_leaky_bwd: bad arguments");
     if (M == 0) return HPL_OK;
     if (N % 4 == 0 && lddy % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0 && aligned16(dY) && aligned16(Y) && aligned16(dX)) {
-        const int grid = (int)imin(cdiv(M * (N / 4), 256), 4096);
-        k_leaky_bwd4<<<grid, 256, 0, to_stream(stream)>>>(dY, lddy, Y, ldy, slope, dX, lddx, M, N / 4, reinterpret_cast<unsigned *>(amax));
+        int tpr_log = 0;
+        while ((1 << tpr_log) < N / 4 && tpr_log < 8) ++tpr_log;
+        const int grid = (int)imax(1, imin(cdiv(M, (int64_t)(256 >> tpr_log) * 2), 2048));
+        k_leaky_bwd4<<<grid, 256, 0, to_stream(stream)>>>(dY, lddy, Y, ldy, slope, dX, lddx, M, N / 4, tpr_log, reinterpret_cast<unsigned *>(amax));
         HPL_CHECK_LAUNCH("hpl_leaky_bwd");
         return HPL_OK;
     }
