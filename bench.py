@@ -635,7 +635,12 @@ def main():
             return model(p1[None], p2[None], lat)
 
     overlap = not (a.no_lattice or a.no_overlap)
-    prio = 'lattice'          # the lattice stream gets the high hardware-queue priority (swept in round 2: forward / none are slower)
+    # Which streams get the high-priority hardware queues.  Rounds 2-4: the lattice stream (a build is a chain of 34 short launches:
+    # behind 700-us tiles it starved).  Round 5, fp16 pairs: the forwards of the full model -- their wide launches are short enough
+    # for the lattice chain to slip through, and the forward streams no longer share the four normal-priority queues: N = 8 192
+    # 442-447 -> 458-462 pairs/s (steady 443 -> 466), N = 2 048 867 -> 878; no priorities at all: 355.  The shallow model is bound by
+    # its lattice builds (forward alone 1 740 pairs/s) and keeps the lattice stream in front: 1 176 vs 1 130.
+    prio = 'forward' if (full and not a.train) else 'lattice'
     side = [torch.cuda.Stream(device=dev, priority=-1 if prio == 'lattice' else 0) for _ in range(max(1, a.lattice_streams))] \
         if overlap else None
     # forwards of consecutive pairs alternate over a.streams HIP streams: the launch-bound deep levels of
@@ -1011,7 +1016,7 @@ def main():
                 'config': {'workload': ('full HPLFlowNet %s (7 levels, 19.3M params, random init), ' if full else 'HPLFlowNetShallow %s (5 levels, random init), ') % ('training step (fwd+bwd+grad all-reduce+Adam)' if a.train else 'inference') +
                                        ('FT3D-like synthetic pair' if a.data == 'frustum' else 'synthetic pair of surface patches') + ', N=%d, bs=1 per GPU' % a.points,
                            'num_points': a.points, 'step_includes_lattice_build': not a.no_lattice,
-                           'lattice_overlapped_on_second_stream': bool(overlap),
+                           'lattice_overlapped_on_second_stream': bool(overlap), 'high_priority_streams': prio if overlap else None,
                            'lattices_under_construction': a.lattice_depth if overlap else 1,
                            'forward_streams': n_fwd if overlap else 1,
                            'forward_issue': 'one native hpl_plan_run per pair' if native else 'python, launch by launch',
