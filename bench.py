@@ -640,7 +640,7 @@ def main():
     # for the lattice chain to slip through, and the forward streams no longer share the four normal-priority queues: N = 8 192
     # 442-447 -> 458-462 pairs/s (steady 443 -> 466), N = 2 048 867 -> 878; no priorities at all: 355.  The shallow model is bound by
     # its lattice builds (forward alone 1 740 pairs/s) and keeps the lattice stream in front: 1 176 vs 1 130.
-    prio = 'forward' if (full and not a.train) else 'lattice'
+    prio = 'forward' if (full and not a.train) else 'lattice'       # (all streams high: 450 / 443; 4 forward streams: forward alone 528, with the lattice 316)
     side = [torch.cuda.Stream(device=dev, priority=-1 if prio == 'lattice' else 0) for _ in range(max(1, a.lattice_streams))] \
         if overlap else None
     # forwards of consecutive pairs alternate over a.streams HIP streams: the launch-bound deep levels of
