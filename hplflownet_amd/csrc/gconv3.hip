@@ -966,6 +966,8 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // two wide Up convs are 51 x 4 and 68 x 2 tiles -- on the fp32 kernel they were 1.18 + 0.59 ms of a 3.7 ms forward)
     constexpr int fill_tiles = 128;
     constexpr int floor_rows = 1024;
+    // (round 5: the narrow 15-tap stencils of levels 0-2 on the 128 x 128 tile of the pair form, N = 64: 52 -> 59, 79 -> 67, 34 -> 43 us
+    // with their reduction -- no gain; N = 128, C = 132: 183 -> 100 us at level 1, a shape the model does not have)
     if (p.N < 256 || p.M < floor_rows) return false;
     const int64_t tiles256 = cdiv(p.M, BM3) * cdiv(p.N, 256);
     const bool fills = tiles256 >= fill_tiles;
