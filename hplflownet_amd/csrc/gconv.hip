@@ -510,6 +510,39 @@ __global__ void k_gconv_finish(const GParams p) {
     }
 }
 
+// the same, four columns per thread, 32-bit index arithmetic (N % 4 == 0, every row 16-byte aligned, M * N < 2^31): the additions in
+// the same order, so the same bits
+__global__ void __launch_bounds__(256) k_gconv_finish4(const GParams p) {
+    const unsigned N4 = (unsigned)p.N / 4u, total4 = (unsigned)p.M * N4;
+    const int64_t total = p.M * p.N;
+    const unsigned res_mod = (unsigned)p.res_mod;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+        const unsigned m = i / N4, n = (i - m * N4) * 4u;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sidx = 0; sidx < p.splits; ++sidx) {
+            const float4 v = *reinterpret_cast<const float4 *>(p.partial + (int64_t)sidx * total + (int64_t)i * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
+            acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+        }
+        if (p.res) {
+            const unsigned mr = m < res_mod ? m : m % res_mod;
+            const float4 r = *reinterpret_cast<const float4 *>(p.res + (int64_t)mr * p.ldres + n);
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
+        if (p.act == HPL_ACT_LEAKY) {
+            acc.x = acc.x > 0.f ? acc.x : p.slope * acc.x;
+            acc.y = acc.y > 0.f ? acc.y : p.slope * acc.y;
+            acc.z = acc.z > 0.f ? acc.z : p.slope * acc.z;
+            acc.w = acc.w > 0.f ? acc.w : p.slope * acc.w;
+        }
+        *reinterpret_cast<float4 *>(p.Y + (int64_t)m * p.ldy + n) = acc;
+        if (p.Y2 && m < (unsigned)p.rows2) *reinterpret_cast<float4 *>(p.Y2 + (int64_t)m * p.ldy2 + n) = acc;
+    }
+}
+
 // one thread per output element; sequential fmaf chain in k order (what one MFMA lane does)
 __global__ void k_gconv_naive(const GParams p) {
     const int64_t total = p.M * p.N;
@@ -672,6 +705,21 @@ void launch_cfg(GParams &p, bool avec, hipStream_t s) {
 
 }  // namespace
 
+namespace {
+void launch_finish(const GParams &p, hipStream_t s) {
+    const bool vec = p.N % 4 == 0 && p.ldy % 4 == 0 && aligned16(p.Y) && aligned16(p.partial) && (!p.bias || aligned16(p.bias)) &&
+                     (!p.res || (p.ldres % 4 == 0 && aligned16(p.res))) && (!p.Y2 || (p.ldy2 % 4 == 0 && aligned16(p.Y2))) &&
+                     p.M * p.N < (int64_t)0x7fffffff && p.res_mod < (int64_t)0x7fffffff;
+    if (vec) {
+        const int g = (int)imin(cdiv(p.M * (p.N / 4), 256), 2048);
+        k_gconv_finish4<<<g, 256, 0, s>>>(p);
+    } else {
+        const int g = (int)imin(cdiv(p.M * p.N, 256), 2048);
+        k_gconv_finish<<<g, 256, 0, s>>>(p);
+    }
+}
+}  // namespace
+
 extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     GParams p;
     int rc = fill_params(d, p, "hpl_gconv_forward");
@@ -680,10 +728,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     hipStream_t s = to_stream(stream);
     const bool avec = (p.C % 4 == 0) && (p.lda % 4 == 0) && aligned16(p.A);
     if (avec && p.Wt3 && launch_split3(p, s)) {
-        if (p.splits > 1) {       // (mid-size stencils: partial tiles over slice ranges, summed in fixed order)
-            const int g = (int)imin(cdiv(p.M * p.N, 256), 2048);
-            k_gconv_finish<<<g, 256, 0, s>>>(p);
-        }
+        if (p.splits > 1) launch_finish(p, s);       // (mid-size stencils: partial tiles over slice ranges, summed in fixed order)
         HPL_CHECK_LAUNCH("hpl_gconv_forward");
         if (p.y_amax && !p.y_amax_done) return amax_launch(p.Y, p.ldy, p.M, p.N, p.y_amax, s);
         return HPL_OK;
@@ -705,10 +750,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
         if (t128 >= 512) launch_cfg<128, 32, 4, 1>(p, avec, s);
         else launch_cfg<64, 32, 2, 1>(p, avec, s);
     }
-    if (p.splits > 1) {
-        const int g = (int)imin(cdiv(p.M * p.N, 256), 2048);
-        k_gconv_finish<<<g, 256, 0, s>>>(p);
-    }
+    if (p.splits > 1) launch_finish(p, s);
     HPL_CHECK_LAUNCH("hpl_gconv_forward");
     if (p.y_amax) return amax_launch(p.Y, p.ldy, p.M, p.N, p.y_amax, s);
     return HPL_OK;
