@@ -135,9 +135,11 @@ def test_cols_images_and_batched_unlayout_round_trip():
     assert torch.equal(gW2, W2)
 
 
-def test_inference_plan_on_a_poisoned_workspace():
+@pytest.mark.parametrize('fill', [float('nan'), 1e30])
+def test_inference_plan_on_a_poisoned_workspace(fill):
     """The executor lays the activation matrices out by their lifetimes (matrices that are never alive together share memory): a
-    forward must not read a cell before the program has written it -- NaN-filled workspaces, two different pairs in turn, same flows
+    forward must not read a cell before the program has written it -- NaN-filled workspaces (1e30-filled: a stale cell inside an
+    operand-scale reduction would not make a NaN, it would silently shrink the scale), two different pairs in turn, same flows
     as the launch-by-launch Python path."""
     import hplflownet_amd as H
     from hplflownet_amd.synthetic import SCALES_FILTER_MAP, fill_module_, synthetic_pair
@@ -154,7 +156,7 @@ def test_inference_plan_on_a_poisoned_workspace():
             t1, t2 = [torch.from_numpy(np.ascontiguousarray(x.T)).to(DEV) for x in (pc1, pc2)]
             lat = gen.build(t1, t2)
             for ws in plan._ws.values():
-                ws.view(torch.float32)[:ws.numel() // 4].fill_(float('nan'))
+                ws.view(torch.float32)[:ws.numel() // 4].fill_(fill)
             y = model(t1[None], t2[None], lat)
             model.native_forward = False
             ref = model(t1[None], t2[None], lat)

@@ -87,3 +87,34 @@ def test_trainer_takes_the_native_step_and_matches_the_autograd_loop():
     for k in runs[True][1]:
         d = float((runs[True][1][k] - runs[False][1][k]).abs().max())
         assert d <= 6.1e-4, (k, d)                       # (Adam moves an entry by <= lr per step whatever the gradient's size)
+
+
+@pytest.mark.parametrize('fill', [float('nan'), 1e30])
+def test_native_step_does_not_see_what_the_workspace_held(fill):
+    """The training program lays its matrices out by lifetime and scales the wide launches' operands by the largest magnitude
+    of what they read: neither may touch a cell this step has not written.  A workspace full of NaN -- or of 1e30, which a
+    reduction over a stale cell would pick up as the scale and silently lose the small operands' low bits -- gives the flow, the
+    loss and the forward-determined quantities of a clean one, bit for bit; gradients as close as two clean runs are (their slab
+    sums are atomic)."""
+    from hplflownet_amd.train_plan import TrainPlan
+    model, gen, t = _setup('HPLFlowNet', 4096)
+    lat = gen.build_native(t[0], t[1]).device_lattice().prepare(True)
+    plan = TrainPlan(model, side_stream=True)
+
+    def run(value):
+        ws = plan._ws.get('train')
+        if ws is not None and value is not None:
+            torch.cuda.synchronize()
+            ws[:ws.numel() // 16 * 16].view(torch.float32).fill_(value)
+        flow, loss = plan.step(t[0], t[1], t[2], lat)
+        plan.finish()
+        torch.cuda.synchronize()
+        return flow.clone(), float(loss), plan.gflat.clone()
+
+    run(None)                                   # (allocates the workspace)
+    f0, l0, g0 = run(0.0)
+    f1, l1, g1 = run(fill)
+    f2, l2, g2 = run(0.0)
+    assert torch.equal(f0, f1) and l0 == l1 and bool(torch.isfinite(g1).all())
+    scale = float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) <= max(2.0 * float((g2 - g0).abs().max()), 1e-6 * scale)
