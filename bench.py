@@ -1077,7 +1077,10 @@ def main():
             # that number here, from the same run.
             try:
                 torch.cuda.synchronize()
-                env = dict(os.environ, HPL_MATH='bf16x3', HPL_BENCH_SUBRUN='1', HPL_BENCH_NO_POWER='1')
+                env = {k: v for k, v in os.environ.items()
+                       if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                    'TORCHELASTIC_RUN_ID', 'TORCHELASTIC_RESTART_COUNT', 'TORCHELASTIC_MAX_RESTARTS')}      # (a plain single process)
+                env.update(HPL_MATH='bf16x3', HPL_BENCH_SUBRUN='1', HPL_BENCH_NO_POWER='1')
                 out = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', '100', '--warmup', '10', '--no-train-probe'],
                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=420).stdout
                 sub = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
