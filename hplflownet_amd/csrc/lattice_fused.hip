@@ -83,20 +83,6 @@ __device__ __forceinline__ int block_scan_excl(int v, int *scr, int *total) {
     return base + inc - v;
 }
 
-// counter[idx] += 1 for every lane with `valid`; lanes of the wave that name the same counter are combined into ONE atomic
-// (most rows of a chunk carry the same key -- all 15 neighbours present -- and a per-lane atomicAdd would queue thousands of
-// operations on one address).  Must be reached by the whole wave.
-__device__ __forceinline__ void wave_count(int32_t *counter, int idx, bool valid) {
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lead_idx = __shfl(idx, leader, 64);
-        const unsigned long long same = __ballot(valid && idx == lead_idx);
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&counter[lead_idx], (int)__popcll(same));
-        todo &= ~same;
-    }
-}
-
 __device__ __forceinline__ int block_sum(int v, int *scr) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -297,7 +283,7 @@ __device__ __forceinline__ uint32_t gray_rank(uint32_t m) {        // position o
 
 // blur table of the pair [15][H0 + H1] (cloud 2's vertices numbered behind cloud 1's; transforms.py:209-221), one lane
 // per vertex: its 15 probes give the tap-presence mask, hence the sort keys of the row orders and their first digit counts
-__device__ void task_blur(const Level &L, int b, int nblk, const Off15 &o) {
+__device__ void task_blur(const Level &L, int b, int nblk, const Off15 &o, int *hist) {
     const int H0 = L.dims[D_H0], H1 = L.dims[D_H1], Hp = H0 + H1;
     const int n0 = npts(L, 0), n1 = npts(L, 1);
     const int32_t *mm = L.dims + D_MM;
@@ -305,10 +291,17 @@ __device__ void task_blur(const Level &L, int b, int nblk, const Off15 &o) {
 #pragma unroll
     for (int q = 0; q < MAX_JOBS; ++q) rows[q] = q < L.n_jobs ? job_rows(L, L.job[q]) : 0;
     const int nth = nblk * 256;
-    for (int h0 = b * 256; h0 < Hp; h0 += nth) {            // wave-uniform trip count (wave_count below)
+    for (int h0 = b * 256; h0 < Hp; h0 += nth) {            // workgroup-uniform trip count (the barriers below)
         const int h = h0 + threadIdx.x;
         const bool valid = h < Hp;
         uint32_t bits = 0;
+        // the digit counts of the row orders: the workgroup's 256 rows lie in ONE 2048-row chunk, so they are counted in LDS and
+        // flushed with one atomic per digit that occurs (round 5; a loop over the distinct keys of every wave with one global
+        // atomic each -- tap masks differ from row to row on the fine levels -- was 17-19 us of this task's 55 at levels 0 and 1)
+#pragma unroll
+        for (int q = 0; q < MAX_JOBS; ++q)
+            if (rows[q]) hist[q * 256 + threadIdx.x] = 0;
+        __syncthreads();
         if (valid) {
             const int c = h >= H0 ? 1 : 0;
             const int hh = c ? h - H0 : h;
@@ -365,9 +358,20 @@ __device__ void task_blur(const Level &L, int b, int nblk, const Off15 &o) {
             const SortJob &J = L.job[q];
             const bool mine = valid && h < rows[q];
             const uint32_t key = gray_rank((bits >> J.f0) & ((1u << J.F) - 1u));
-            if (mine) J.key[h] = key;
-            wave_count(J.hist1, (h / SORT_CHUNK) * 256 + (int)(key & 255u), mine);
+            if (mine) {
+                J.key[h] = key;
+                atomicAdd(&hist[q * 256 + (int)(key & 255u)], 1);
+            }
         }
+        __syncthreads();
+        static_assert(SORT_CHUNK % 256 == 0, "a workgroup's rows in one chunk");
+#pragma unroll
+        for (int q = 0; q < MAX_JOBS; ++q) {
+            if (rows[q] == 0) continue;
+            const int c = hist[q * 256 + threadIdx.x];
+            if (c) atomicAdd(&L.job[q].hist1[(h0 / SORT_CHUNK) * 256 + (int)threadIdx.x], c);
+        }
+        __syncthreads();                                   // (the next round clears the counters)
     }
 }
 
@@ -708,7 +712,7 @@ __global__ void __launch_bounds__(256) k_lattice_fused(const Level *__restrict__
     case T_FLAGS: task_flags(L, b, t.nblk, ism); break;
     case T_IDS: task_ids(L, b, t.nblk, ism); break;
     case T_OFF: task_off(L, b, t.nblk); break;
-    case T_BLUR: task_blur(L, b, t.nblk, o); break;
+    case T_BLUR: task_blur(L, b, t.nblk, o, ism); break;
     case T_CORR2: task_corr2(L, b, t.nblk, o); break;
     case T_CSR_SUMS: task_csr_sums(L, b, t.nblk, ism); break;
     case T_SORT1: task_sort(L, L.job[t.job], 1, b, t.nblk, smem); break;
@@ -886,7 +890,7 @@ int enqueue(Plan &plan, Level *lv_stage, int32_t *dims_host, hipEvent_t counts_e
         bool dropped = false;
         auto add = [&](int kind, int level, int job, int64_t nblk) {
             if (l.n >= MAX_TASKS) { dropped = true; return; }
-            nblk = imin(nblk, max_blocks);
+            nblk = imin(nblk, max_blocks);          // (round 5: 1 024 for the CSR ranking alone, eleven rounds -> four at levels 0-1: no gain)
             Task &k = l.t[l.n++];
             k.kind = kind; k.level = level; k.job = job; k.blk0 = blk; k.nblk = (int)nblk;
             blk += (int)nblk;

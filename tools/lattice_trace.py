@@ -15,9 +15,10 @@ def run(n):
     import torch
     import hplflownet_amd as H
     from hplflownet_amd.synthetic import SCALES_FILTER_MAP, synthetic_pair
-    args = types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP, evaluate=True, use_leaky=True, bcn_use_bias=True,
-                                 bcn_use_norm=True, last_relu=False, DEVICE='cuda')
-    m = H.HPLFlowNet(args)
+    shallow = bool(os.environ.get('LT_SHALLOW'))        # the 5-level model (BASELINE config 2)
+    args = types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP[:5] if shallow else SCALES_FILTER_MAP, evaluate=True, use_leaky=True,
+                                 bcn_use_bias=True, bcn_use_norm=True, last_relu=False, DEVICE='cuda')
+    m = (H.HPLFlowNetShallow if shallow else H.HPLFlowNet)(args)
     gen = H.GenerateDataUnsymmetric(args, device='cuda', wide_up=m.lattice_hint())
     pc1, pc2, _ = synthetic_pair(n, 0)
     t1, t2 = torch.from_numpy(pc1.T.copy()).cuda(), torch.from_numpy(pc2.T.copy()).cuda()
