@@ -209,6 +209,9 @@ def load_diag():
         lib.hpl_mfma_probe.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp]
         lib.hpl_mfma_probe_data.restype = ctypes.c_int
         lib.hpl_mfma_probe_data.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp]
+        lib.hpl_diag_splat_atomic.restype = ctypes.c_int
+        lib.hpl_diag_splat_atomic.argtypes = [c_vp, ctypes.c_int64, ctypes.c_int, c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp,
+                                              ctypes.c_int64, ctypes.c_int, c_vp]
         _diag = lib
     return _diag
 

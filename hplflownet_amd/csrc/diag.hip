@@ -128,3 +128,107 @@ extern "C" int hpl_mfma_probe(float *out, int blocks, int iters, void *stream) {
     HPL_CHECK_LAUNCH("hpl_mfma_probe");
     return HPL_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// A/B of the splat as SCATTER-ADDS (what models/bilateralNN.py:24-29 `sparse_sum` means literally, and the form BASELINE.json's
+// north star names: "LDS-staged ... wavefront-reduced atomicAdd") against the product's CSR segmented reduction (splat_slice.hip
+// k_splat: deterministic, no atomics).  Measurement only -- tools/bench_splat_slice.py --atomic; the sums of these kernels depend on
+// the order the atomics land in.  out[v, :] += bary[r, n] * norm[v] * feat[n, :] for v = off[r, n]; out is cleared by the call.
+//   mode 0: one lane per (point n, remainder r, float4 column), four global_atomic_add_f32 each;
+//   mode 1: a workgroup stages its 24 points' <= 96 vertex rows in an LDS open-address table (ds_add_f32), then flushes every
+//           occupied slot with one global atomic per element -- entries of the block that share a vertex are combined in LDS.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) k_splat_atomic(const float *__restrict__ feat, int64_t ldf, int CV, const float *__restrict__ bary,
+                                                      const int32_t *__restrict__ off, int64_t N, const float *__restrict__ norm,
+                                                      float *__restrict__ out, int64_t ldo) {
+    const int64_t total = 4 * N * CV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i / CV;
+        const int cq = (int)(i - e * CV);
+        const int64_t n = e >> 2;
+        const int r = (int)(e & 3);
+        const int32_t v = off[(int64_t)r * N + n];
+        if (v < 0) continue;
+        const float w = bary[(int64_t)r * N + n] * (norm ? norm[v] : 1.0f);
+        const float4 x = *reinterpret_cast<const float4 *>(feat + n * ldf + (int64_t)cq * 4);
+        float *dst = out + (int64_t)v * ldo + (int64_t)cq * 4;
+        atomicAdd(dst + 0, w * x.x); atomicAdd(dst + 1, w * x.y); atomicAdd(dst + 2, w * x.z); atomicAdd(dst + 3, w * x.w);
+    }
+}
+
+constexpr int SA_PTS = 24, SA_SLOTS = 128;
+__global__ void __launch_bounds__(256) k_splat_atomic_lds(const float *__restrict__ feat, int64_t ldf, int CV, const float *__restrict__ bary,
+                                                          const int32_t *__restrict__ off, int64_t N, const float *__restrict__ norm,
+                                                          float *__restrict__ out, int64_t ldo) {
+    extern __shared__ float sm[];
+    int *keys = reinterpret_cast<int *>(sm);                 // [SA_SLOTS] vertex of a slot, -1 = free
+    int *eslot = keys + SA_SLOTS;                            // [4 * SA_PTS] slot of every entry of the block
+    float *rows = sm + SA_SLOTS + 4 * SA_PTS;                // [SA_SLOTS][4 * CV]
+    const int C = 4 * CV;
+    for (int64_t p0 = (int64_t)blockIdx.x * SA_PTS; p0 < N; p0 += (int64_t)gridDim.x * SA_PTS) {
+        for (int i = threadIdx.x; i < SA_SLOTS; i += 256) keys[i] = -1;
+        for (int i = threadIdx.x; i < SA_SLOTS * C; i += 256) rows[i] = 0.f;
+        __syncthreads();
+        if (threadIdx.x < 4 * SA_PTS) {
+            const int64_t n = p0 + (threadIdx.x >> 2);
+            const int r = threadIdx.x & 3;
+            int slot = -1;
+            if (n < N) {
+                const int v = off[(int64_t)r * N + n];
+                if (v >= 0) {
+                    unsigned h = ((unsigned)v * 2654435761u) >> 25;          // 7 bits
+                    while (true) {
+                        const int prev = atomicCAS(&keys[h], -1, v);
+                        if (prev == -1 || prev == v) break;
+                        h = (h + 1) & (SA_SLOTS - 1);
+                    }
+                    slot = (int)h;
+                }
+            }
+            eslot[threadIdx.x] = slot;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * SA_PTS * CV; i += 256) {
+            const int e = i / CV, cq = i - e * CV;
+            const int slot = eslot[e];
+            if (slot < 0) continue;
+            const int64_t n = p0 + (e >> 2);
+            const int r = e & 3;
+            const int v = keys[slot];
+            const float w = bary[(int64_t)r * N + n] * (norm ? norm[v] : 1.0f);
+            const float4 x = *reinterpret_cast<const float4 *>(feat + n * ldf + (int64_t)cq * 4);
+            float *dst = rows + slot * C + cq * 4;
+            atomicAdd(dst + 0, w * x.x); atomicAdd(dst + 1, w * x.y); atomicAdd(dst + 2, w * x.z); atomicAdd(dst + 3, w * x.w);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < SA_SLOTS * C; i += 256) {
+            const int slot = i / C, c = i - slot * C;
+            const int v = keys[slot];
+            if (v >= 0) atomicAdd(out + (int64_t)v * ldo + c, rows[i]);
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+extern "C" int hpl_diag_splat_atomic(const float *feat, int64_t ldf, int C, const float *bary, const int32_t *off, int64_t N,
+                                     const float *norm, int64_t H, float *out, int64_t ldo, int mode, void *stream) {
+    HPL_REQUIRE(feat && bary && off && out && C > 0 && C % 4 == 0 && ldf % 4 == 0 && ldo >= C && N >= 0 && H >= 0 && (mode == 0 || mode == 1),
+                "hpl_diag_splat_atomic: bad arguments");
+    if (N == 0 || H == 0) return HPL_OK;
+    hipStream_t s = to_stream(stream);
+    if (hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)C * 4, (size_t)H, s) != hipSuccess) return -2;
+    const int CV = C / 4;
+    if (mode == 0) {
+        const int64_t blocks = (4 * N * CV + 255) / 256;
+        k_splat_atomic<<<(int)(blocks < (1 << 20) ? blocks : (1 << 20)), 256, 0, s>>>(feat, ldf, CV, bary, off, N, norm, out, ldo);
+    } else {
+        const size_t lds = (size_t)(SA_SLOTS + 4 * SA_PTS + SA_SLOTS * C) * 4;
+        HPL_REQUIRE(lds <= 64 * 1024, "hpl_diag_splat_atomic: C too large for the LDS table");
+        const int64_t blocks = (N + SA_PTS - 1) / SA_PTS;
+        k_splat_atomic_lds<<<(int)(blocks < (1 << 16) ? blocks : (1 << 16)), 256, lds, s>>>(feat, ldf, CV, bary, off, N, norm, out, ldo);
+    }
+    HPL_CHECK_LAUNCH("hpl_diag_splat_atomic");
+    return HPL_OK;
+}

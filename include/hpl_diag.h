@@ -4,6 +4,7 @@
  */
 #ifndef HPL_DIAG_H
 #define HPL_DIAG_H
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -19,6 +20,14 @@ int hpl_mfma_probe(float *out, int blocks, int iters, void *stream);
  * lowers the sustained clock below what hpl_mfma_probe's constant operands reach.  clk (DEVICE, optional):
  * clk[0] = shader cycles, clk[1] = 100 MHz wall ticks spent by workgroup 0 in the MFMA loop. */
 int hpl_mfma_probe_data(float *out, int blocks, int iters, int mode, long long *clk, void *stream);
+
+/* A/B of the splat as scatter-adds (reference: models/bilateralNN.py:24-29 sparse_sum; BASELINE.json north star: "LDS-staged ...
+ * wavefront-reduced atomicAdd") against the product's CSR segmented reduction (hpl_splat).  out[off[r][n], :] += bary[r][n] *
+ * norm[off[r][n]] * feat[n, :]; out [H][ldo] is cleared by the call (counted in its time).  mode 0: global atomics per element;
+ * mode 1: per-workgroup LDS open-address table of the block's vertices, one global atomic per element of an occupied slot.
+ * C % 4 == 0.  The sums depend on the order the atomics land in: a measurement, not a product path. */
+int hpl_diag_splat_atomic(const float *feat, int64_t ldf, int C, const float *bary, const int32_t *off, int64_t N,
+                          const float *norm, int64_t H, float *out, int64_t ldo, int mode, void *stream);
 
 #ifdef __cplusplus
 }

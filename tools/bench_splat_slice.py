@@ -15,7 +15,7 @@ from types import SimpleNamespace
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from hplflownet_amd import ops, synthetic                                # noqa: E402
+from hplflownet_amd import _lib, ops, synthetic                                # noqa: E402
 from hplflownet_amd.lattice import GenerateDataUnsymmetric               # noqa: E402
 
 HBM_PEAK = 8.0e12
@@ -50,6 +50,9 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--reps', type=int, default=30)
     ap.add_argument('--json', default=None)
+    ap.add_argument('--atomic', action='store_true',
+                    help='also time the splat as scatter-adds (libhplbcl_diag.so hpl_diag_splat_atomic: global atomics / LDS-staged), '
+                         'the A/B of the product CSR reduction')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     pc1, pc2, _ = synthetic.synthetic_pair(a.points, 0)
@@ -72,6 +75,22 @@ def main():
             by = 4.0 * C * N + 32.0 * N + 4.0 * (C + 1) * (H + 1)
             rows.append(dict(kernel='splat', level=L, batch=B, C=C, N=N, H=H, us=t * 1e6, MB=by / 1e6,
                              GBps=by / t / 1e9, frac=by / t / HBM_PEAK))
+            if a.atomic:
+                diag = _lib.load_diag()
+                norm = csr[3]
+                ref = out.clone()
+                for mode, nm in ((0, 'splat_atomic'), (1, 'splat_atomic_lds')):
+                    o3 = torch.empty(H, C, device=dev)
+
+                    def run():
+                        rc = diag.hpl_diag_splat_atomic(feat.data_ptr(), C, C, cl.bary.data_ptr(), cl.off.data_ptr(), N, norm.data_ptr(), H,
+                                                        o3.data_ptr(), C, mode, _lib.stream())
+                        assert rc == 0, rc
+                    t = timed(run, a.reps)
+                    err = float((o3 - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+                    assert err < 1e-4, (nm, L, B, err)
+                    rows.append(dict(kernel=nm, level=L, batch=B, C=C, N=N, H=H, us=t * 1e6, MB=by / 1e6,
+                                     GBps=by / t / 1e9, frac=by / t / HBM_PEAK, max_rel_diff_vs_csr=err))
             # Up BCL slice
             C = up_c[L]
             Y = torch.randn(H, C, device=dev)
@@ -82,10 +101,10 @@ def main():
             rows.append(dict(kernel='slice', level=L, batch=B, C=C, N=N, H=H, us=t * 1e6, MB=by / 1e6,
                              GBps=by / t / 1e9, frac=by / t / HBM_PEAK))
             del feat, out, Y, o2
-    print('%-6s %3s %5s %5s %9s %9s %9s %8s %9s %6s' % ('kernel', 'lvl', 'batch', 'C', 'N', 'H', 'us', 'MB', 'GB/s',
+    print('%-16s %3s %5s %5s %9s %9s %9s %8s %9s %6s' % ('kernel', 'lvl', 'batch', 'C', 'N', 'H', 'us', 'MB', 'GB/s',
                                                        'frac'))
     for r in rows:
-        print('%-6s %3d %5d %5d %9d %9d %9.1f %8.1f %9.0f %6.3f' % (r['kernel'], r['level'], r['batch'], r['C'],
+        print('%-16s %3d %5d %5d %9d %9d %9.1f %8.1f %9.0f %6.3f' % (r['kernel'], r['level'], r['batch'], r['C'],
                                                                     r['N'], r['H'], r['us'], r['MB'], r['GBps'],
                                                                     r['frac']))
     if a.json:
