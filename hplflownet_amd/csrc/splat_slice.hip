@@ -66,42 +66,86 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t chunk) {
 // vertex's contributor list in CSR order (deterministic, no shuffles, no idle lanes when CV is not
 // a power of two -- the Down layers have CV = 17).  Lanes of one vertex read the same csr words
 // (one L1 broadcast); the feature rows are read as CV consecutive 16-byte words.
+// One round of the contributor loop: entries [j, min(j + R, e)) of a vertex, all predicated -- the index / weight words of a round are
+// independent loads, then its (up to) R row words are: three dependent loads deep for segments of up to R contributors.  (A scalar tail
+// loop over the last 1-3 contributors was two more dependent loads per contributor: the common case on the fine levels, ~3 contributors
+// per vertex.)  Absent slots add w = 0 times 0: the sum and its order are those of the plain loop.
+template <typename V, int R>
+__device__ __forceinline__ void splat_round(V &acc, const float *__restrict__ col, int64_t ldf, const int32_t *__restrict__ csr_pt,
+                                            const float *__restrict__ csr_w, int32_t j, int32_t e) {
+    using ops = vec_ops<V>;
+    int32_t pt[R];
+    float w[R];
+    V x[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const bool ok = j + u < e;
+        pt[u] = ok ? csr_pt[j + u] : -1;
+        w[u] = ok ? csr_w[j + u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) x[u] = pt[u] >= 0 ? *reinterpret_cast<const V *>(col + (int64_t)pt[u] * ldf) : ops::zero();
+#pragma unroll
+    for (int u = 0; u < R; ++u) ops::fma(acc, w[u], x[u]);
+}
+
+// V = float4 (vector path) or float (scalar path); CV = number of V columns per row.
+// Sparse segments (fine levels: 1.3-3 contributors per vertex): one lane per (vertex, V column) -- a wave covers 64/CV consecutive
+// vertices, every lane walks its vertex's contributor list in CSR order (no shuffles, no idle lanes when CV is not a power of two --
+// the Down layers have CV = 17).  Lanes of one vertex read the same csr words (one L1 broadcast); the feature rows are read as CV
+// consecutive 16-byte words.
+// Long segments (level 2 on: 10-21 contributors per vertex, csr_ptr[H] >= 6 H -- decided on the device, the host does not know the
+// entry count): G lane groups per vertex (G * CV lanes, 256 / (G * CV) vertices per workgroup pass) take the rounds of R entries in
+// turn, group g the rounds g, g + G, ...; the partial sums of groups 1 .. G-1 meet in LDS and are added in group order.  Deterministic
+// (a fixed order per vertex, the same as the plain loop for segments of up to R entries); three times the lanes in flight on the
+// levels where a lane's chain of dependent rounds set the time (level 2 of one N = 8 192 cloud: 12.9 -> 10.0 us; launches of
+// 2^20 lanes or more keep one group: splat_launch).
 template <typename V, int R>
 __global__ void __launch_bounds__(256) k_splat(const float *__restrict__ feat, int64_t ldf, uint32_t CV,
                                                const int32_t *__restrict__ csr_ptr,
                                                const int32_t *__restrict__ csr_pt,
                                                const float *__restrict__ csr_w,
                                                const float *__restrict__ norm, uint32_t total,
-                                               float *__restrict__ out, int64_t ldo, int xcd, int accumulate) {
+                                               float *__restrict__ out, int64_t ldo, int xcd, int accumulate, uint32_t H, uint32_t G) {
     using ops = vec_ops<V>;
     constexpr int VW = sizeof(V) / 4;
-    const uint32_t stride = gridDim.x * 256u;
+    __shared__ V part[256];
     const uint32_t lb = xcd_block(blockIdx.x, (uint32_t)xcd);
+    const bool grouped = G > 1 && (uint32_t)csr_ptr[H] >= 6u * H;        // (uniform)
+    if (grouped) {
+        const uint32_t unit = CV * G, VB = 256u / unit;
+        const uint32_t vb = threadIdx.x / unit, rem = threadIdx.x - vb * unit;
+        const uint32_t g = rem / CV, cq = rem - g * CV;
+        const uint32_t batches = (H + VB - 1) / VB;
+        const float *col = feat + (int64_t)cq * VW;
+        for (uint32_t bt = lb; bt < batches; bt += gridDim.x) {
+            const uint32_t v = bt * VB + vb;
+            const bool valid = vb < VB && v < H;
+            V acc = ops::zero();
+            if (valid) {
+                const int32_t b = csr_ptr[v], e = csr_ptr[v + 1];
+                for (int32_t j = b + (int32_t)g * R; j < e; j += (int32_t)G * R) splat_round<V, R>(acc, col, ldf, csr_pt, csr_w, j, e);
+                if (g > 0) part[(vb * (G - 1) + g - 1) * CV + cq] = acc;
+            }
+            __syncthreads();
+            if (valid && g == 0) {
+                for (uint32_t gg = 1; gg < G; ++gg) acc = ops::add(acc, part[(vb * (G - 1) + gg - 1) * CV + cq]);
+                acc = ops::scale(acc, norm ? norm[v] : 1.0f);
+                V *dst = reinterpret_cast<V *>(out + (int64_t)v * ldo + (int64_t)cq * VW);
+                *dst = accumulate ? ops::add(*dst, acc) : acc;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const uint32_t stride = gridDim.x * 256u;
     for (uint32_t idx = lb * 256u + threadIdx.x; idx < total; idx += stride) {
         const uint32_t v = idx / CV, cq = idx - v * CV;
         const int32_t b = csr_ptr[v], e = csr_ptr[v + 1];
         const float sc = norm ? norm[v] : 1.0f;
         const float *col = feat + (int64_t)cq * VW;
         V acc = ops::zero();
-        // R contributors per round, all predicated: the index / weight words of a round are independent loads, then its (up to)
-        // R row words are -- three dependent loads deep for segments of up to R contributors.  (A scalar tail loop over the last 1-3
-        // contributors was two more dependent loads per contributor: the common case on the fine levels, ~3 contributors per vertex.)
-        // Absent slots add w = 0 times 0: the sum and its order are those of the plain loop.
-        for (int32_t j = b; j < e; j += R) {
-            int32_t pt[R];
-            float w[R];
-            V x[R];
-#pragma unroll
-            for (int u = 0; u < R; ++u) {
-                const bool ok = j + u < e;
-                pt[u] = ok ? csr_pt[j + u] : -1;
-                w[u] = ok ? csr_w[j + u] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < R; ++u) x[u] = pt[u] >= 0 ? *reinterpret_cast<const V *>(col + (int64_t)pt[u] * ldf) : ops::zero();
-#pragma unroll
-            for (int u = 0; u < R; ++u) ops::fma(acc, w[u], x[u]);
-        }
+        for (int32_t j = b; j < e; j += R) splat_round<V, R>(acc, col, ldf, csr_pt, csr_w, j, e);
         V *dst = reinterpret_cast<V *>(out + (int64_t)v * ldo + (int64_t)cq * VW);
         acc = ops::scale(acc, sc);
         *dst = accumulate ? ops::add(*dst, acc) : acc;
@@ -233,8 +277,17 @@ int splat_launch(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr, 
     const uint32_t total = (uint32_t)(H * cv);
     int chunk;
     const int grid = xcd_grid(imin(cdiv((int64_t)total, 256), 256 * 32), &chunk);
-    if (vec) k_splat<float4, 8><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate);
-    else k_splat<float, 8><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate);
+    // lane groups per vertex for long segments: the G <= 4 that fills most of the 256 lanes (CV = 17: G = 3, five vertices per pass)
+    uint32_t G = 1;
+    for (uint32_t g = 2, best = 0; g <= 4; ++g) {
+        const uint32_t used = (256u / ((uint32_t)cv * g)) * (uint32_t)cv * g;
+        if ((uint32_t)cv * g <= 256u && used >= best) { best = used; G = g; }
+    }
+    // (measured, tools/bench_splat_slice.py: level 2 of one N = 8 192 cloud 12.9 -> 10.0 us; sixteen such clouds in one launch, 2.5 M lanes,
+    // 76 -> 80 us -- a launch that fills the GPU several times over gains nothing from more lanes and pays the two barriers)
+    if (total >= (1u << 20)) G = 1;
+    if (vec) k_splat<float4, 8><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate, (uint32_t)H, G);
+    else k_splat<float, 8><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate, (uint32_t)H, G);
     HPL_CHECK_LAUNCH("hpl_splat");
     return HPL_OK;
 }

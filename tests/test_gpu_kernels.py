@@ -553,3 +553,36 @@ def test_results_do_not_depend_on_what_runs_beside_them(kind):
             assert float((out - ref).abs().max()) < 1e-5 * float(ref.abs().max())
         else:
             assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('C,H', [(68, 97), (68, 700), (64, 300), (5, 50), (33, 211), (12, 1), (1024, 64)])
+def test_splat_long_segments(ops, C, H):
+    """Vertices with many contributors (csr_ptr[H] >= 6 H: the coarse levels) take the lane-group form of k_splat -- several
+    lane groups per vertex, partial sums added in group order: same sums as the float64 restatement of
+    models/bilateralNN.py:151-186, deterministic, and the accumulating variant adds the same numbers."""
+    rng = np.random.RandomState(C * 1000 + H)
+    N = 4096
+    off = rng.randint(0, H, size=(4, N)).astype(np.int64)
+    off[:, :8] = (H - 1)                                   # one vertex with a long list of its own
+    bary = rng.rand(4, N).astype(np.float32)
+    feat = rng.randn(N, C).astype(np.float32)
+    ct = ops.CloudTables(dev(bary), dev(off), H)
+    assert int(ct.csr()[0][-1]) == 4 * N >= 6 * H
+    for use_norm in (True, False):
+        S = ops.splat_raw(dev(feat), ct.csr(), H, use_norm)
+        want = np.zeros((H, C))
+        np.add.at(want, off.ravel(), (bary.ravel()[:, None].astype(np.float64) * np.tile(feat.astype(np.float64), (4, 1))))
+        if use_norm:
+            w = np.zeros(H)
+            np.add.at(w, off.ravel(), bary.ravel().astype(np.float64))
+            assert rel_err(ct.csr()[3].cpu().numpy(), 1.0 / (w + 1e-5)) < 1e-5
+            want = want * ct.csr()[3].cpu().numpy()[:, None].astype(np.float64)
+        assert rel_err(S.cpu().numpy(), want) < 1e-5, (C, H, use_norm)
+        assert torch.equal(S, ops.splat_raw(dev(feat), ct.csr(), H, use_norm))
+    from hplflownet_amd import _lib
+    cp, cpt, cw, cn = ct.csr()
+    acc = torch.ones(H, C, device='cuda')
+    x = dev(feat)
+    _lib.check(_lib.load().hpl_splat_add(_lib.ptr(x), C, C, _lib.ptr(cp), _lib.ptr(cpt), _lib.ptr(cw), _lib.ptr(cn), H, _lib.ptr(acc), C,
+                                         _lib.stream()), 'hpl_splat_add')
+    assert torch.equal(acc, 1.0 + ops.splat_raw(x, ct.csr(), H, True))
