@@ -398,7 +398,8 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
         r = tplan.step(p1, p2, sfs[i % len(pairs)], lat) if native else None
         if r is not None:
             tplan.finish()
-            opt.step()
+            if not tplan.adam_step(opt):
+                opt.step()
             ls = r[1]
         else:
             if native:
@@ -409,7 +410,8 @@ def train_probe(H, arch, margs, state, pairs, sfs, gen, steps=8, warmup=3):
                 opt.zero_grad(set_to_none=True)
             ls.backward()
             reducer()
-            opt.step()
+            if not (native and tplan.adam_step(opt)):
+                opt.step()
         fin = torch.cuda.Event()
         fin.record(main)
         keep.append((lat, fin))                # side-stream allocations stay alive until the step that used them has RUN
@@ -652,7 +654,8 @@ def main():
             r = tplan.step(p1, p2, sfs[i % a.pool], lat) if native_train else None
             if r is not None:
                 tplan.finish()
-                opt.step()
+                if not tplan.adam_step(opt):
+                    opt.step()
                 return r[0]
             if native_train:
                 tplan.gflat.zero_()
@@ -662,7 +665,8 @@ def main():
                 opt.zero_grad(set_to_none=True)
             loss.backward()
             reducer()
-            opt.step()
+            if not (native_train and tplan.adam_step(opt)):
+                opt.step()
             return flow
 
         def step(i):                                           # noqa: F811

@@ -113,6 +113,8 @@ _SIGNATURES = {
     'hpl_psum': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, ctypes.c_int, c_vp, c_i64, ctypes.c_int, c_vp]),
     'hpl_regroup': (ctypes.c_int, [c_vp, c_i64, c_i64, ctypes.c_int, ctypes.c_int, c_vp, c_i64, ctypes.c_int, c_vp]),
     'hpl_epe3d': (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'hpl_adam_flat': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     c_i64, c_vp]),
     'hpl_gather_sum': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_i64, c_i64,
                                       ctypes.c_int, c_f32, c_vp, c_i64, c_vp]),
     'hpl_table_invert': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, ctypes.c_int, c_i64, c_vp, c_vp]),

@@ -95,9 +95,9 @@ __device__ __forceinline__ void splat_round(V &acc, const float *__restrict__ co
 // the Down layers have CV = 17).  Lanes of one vertex read the same csr words (one L1 broadcast); the feature rows are read as CV
 // consecutive 16-byte words.
 // Long segments (level 2 on: 10-21 contributors per vertex, csr_ptr[H] >= 6 H -- decided on the device, the host does not know the
-// entry count): G lane groups per vertex (G * CV lanes, 256 / (G * CV) vertices per workgroup pass) take the rounds of R entries in
+// entry count): G lane groups per vertex (G * CV lanes, 256 / (G * CV) vertices per workgroup pass) take rounds of R / 2 entries in
 // turn, group g the rounds g, g + G, ...; the partial sums of groups 1 .. G-1 meet in LDS and are added in group order.  Deterministic
-// (a fixed order per vertex, the same as the plain loop for segments of up to R entries); three times the lanes in flight on the
+// (a fixed order per vertex, the same as the plain loop for segments of up to R / 2 entries); three times the lanes in flight on the
 // levels where a lane's chain of dependent rounds set the time (level 2 of one N = 8 192 cloud: 12.9 -> 10.0 us; launches of
 // 2^20 lanes or more keep one group: splat_launch).
 template <typename V, int R>
@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(256) k_splat(const float *__restrict__ feat, i
                                                float *__restrict__ out, int64_t ldo, int xcd, int accumulate, uint32_t H, uint32_t G) {
     using ops = vec_ops<V>;
     constexpr int VW = sizeof(V) / 4;
+    constexpr int RG = R / 2;
     __shared__ V part[256];
     const uint32_t lb = xcd_block(blockIdx.x, (uint32_t)xcd);
     const bool grouped = G > 1 && (uint32_t)csr_ptr[H] >= 6u * H;        // (uniform)
@@ -124,7 +125,9 @@ __global__ void __launch_bounds__(256) k_splat(const float *__restrict__ feat, i
             V acc = ops::zero();
             if (valid) {
                 const int32_t b = csr_ptr[v], e = csr_ptr[v + 1];
-                for (int32_t j = b + (int32_t)g * R; j < e; j += (int32_t)G * R) splat_round<V, R>(acc, col, ldf, csr_pt, csr_w, j, e);
+                // (rounds of RG = R / 2 entries: the lane groups multiply the loads in flight, and this path's extra indices must not
+                // cost the sparse path -- the register count of the kernel is that of its larger branch -- its eighth wave per SIMD)
+                for (int32_t j = b + (int32_t)g * RG; j < e; j += (int32_t)G * RG) splat_round<V, RG>(acc, col, ldf, csr_pt, csr_w, j, e);
                 if (g > 0) part[(vb * (G - 1) + g - 1) * CV + cq] = acc;
             }
             __syncthreads();

@@ -4,6 +4,7 @@
 // Reference: autograd over models/bnn_flow.py:189-208 (expand + cat of the pc1 half, Conv2d((15,1)) displacement filter),
 // models/epe3d_loss.py:9-10, main.py:213-214.  All of them move each byte once; none is worth more than full lines.
 #include "common.h"
+#include <math.h>
 
 using namespace hpl;
 
@@ -154,6 +155,53 @@ int vcopy(const float *src, float *dst, int n, hipStream_t s) {
 }
 
 }  // namespace hpl
+
+namespace {
+// Adam (torch.optim.Adam, weight_decay = 0, amsgrad off: main.py:138-140) over flat fp32 arrays: one pass, 16 B per element read
+// and 12 written.  The arithmetic follows torch's fused kernel (ATen fused_adam_utils.cuh adam_math) operation by operation; the bias
+// corrections and 1 - beta are computed on the host in double (as torch does) and arrive rounded once: step_size = lr / (1 - beta1^t),
+// bc2_sqrt = sqrt(1 - beta2^t), w1 = 1 - beta1, w2 = 1 - beta2.
+struct AdamK { float step_size, w1, b2, w2, eps, bc2_sqrt; };
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, const AdamK &k) {
+    const float step_size = k.step_size, eps = k.eps, bc2_sqrt = k.bc2_sqrt;
+    m = m + k.w1 * (g - m);                             // lerp(m, g, 1 - beta1)
+    v = k.b2 * v + k.w2 * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * m / denom;
+}
+__global__ void __launch_bounds__(256) k_adam_flat(float *__restrict__ P, const float *__restrict__ G, float *__restrict__ M, float *__restrict__ V,
+                                                   int64_t n, const AdamK k) {
+    const int64_t n4 = n / 4, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 p = reinterpret_cast<float4 *>(P)[i], m = reinterpret_cast<float4 *>(M)[i], v = reinterpret_cast<float4 *>(V)[i];
+        const float4 g = reinterpret_cast<const float4 *>(G)[i];
+        adam1(p.x, g.x, m.x, v.x, k);
+        adam1(p.y, g.y, m.y, v.y, k);
+        adam1(p.z, g.z, m.z, v.z, k);
+        adam1(p.w, g.w, m.w, v.w, k);
+        reinterpret_cast<float4 *>(P)[i] = p;
+        reinterpret_cast<float4 *>(M)[i] = m;
+        reinterpret_cast<float4 *>(V)[i] = v;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) adam1(P[i], G[i], M[i], V[i], k);
+}
+}  // namespace
+
+extern "C" int hpl_adam_flat(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1, double beta2, double eps,
+                             int64_t step, hplStream stream) {
+    HPL_REQUIRE(p && g && m && v && n >= 0 && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && step >= 1 && beta1 >= 0.0 &&
+                    beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0,
+                "hpl_adam_flat: null / unaligned pointer or bad arguments (n=%lld step=%lld)", (long long)n, (long long)step);
+    if (n == 0) return HPL_OK;
+    AdamK k;
+    k.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    k.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    k.w1 = (float)(1.0 - beta1); k.b2 = (float)beta2; k.w2 = (float)(1.0 - beta2); k.eps = (float)eps;
+    const int grid = (int)imin(cdiv(cdiv(n, 4), 256), 256 * 16);
+    k_adam_flat<<<grid, 256, 0, to_stream(stream)>>>(p, g, m, v, n, k);
+    HPL_CHECK_LAUNCH("hpl_adam_flat");
+    return HPL_OK;
+}
 
 extern "C" int hpl_psum(const float *X, int64_t ldx, int64_t rows, int64_t mod, int N, float *out, int64_t ldo, int accumulate,
                         hplStream stream) {

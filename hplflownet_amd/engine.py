@@ -157,7 +157,8 @@ class Trainer(object):
             r = self.tplan.step(pc1, pc2, sf, lat)
             if r is not None:
                 self.tplan.finish()
-                self.opt.step()
+                if not self.tplan.adam_step(self.opt):         # one launch over the flat arrays (hpl_adam_flat)
+                    self.opt.step()
                 self.native_steps += 1
                 return r[1][0].clone()
             self.tplan.gflat.zero_()                 # a lattice the native backward refuses: autograd adds into the same arena
@@ -168,7 +169,8 @@ class Trainer(object):
         loss.backward()
         if self.reducer is not None:
             self.reducer()
-        self.opt.step()
+        if self.tplan is None or not self.tplan.adam_step(self.opt):
+            self.opt.step()
         return loss.detach()
 
     # ------------------------------------------------------------------ lattice pipeline
@@ -226,9 +228,13 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ checkpoints
     def state(self):
-        sd = collections.OrderedDict(('module.' + k, v) for k, v in self.model.state_dict().items())
+        # (the native training step keeps parameters and Adam moments as views of flat arrays -- train_plan.TrainPlan --: a
+        # checkpoint holds tensors of their own, as the reference's does)
+        sd = collections.OrderedDict(('module.' + k, v.detach().clone()) for k, v in self.model.state_dict().items())
+        osd = self.opt.state_dict()
+        osd['state'] = {i: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in osd['state'].items()}
         return {'epoch': self.epoch, 'arch': self.arch, 'state_dict': sd, 'min_loss': self.min_loss,
-                'optimizer': self.opt.state_dict()}
+                'optimizer': osd}
 
     def save_checkpoint(self, ckpt_dir, is_best, filename='checkpoint.pth.tar'):
         os.makedirs(ckpt_dir, exist_ok=True)

@@ -291,7 +291,9 @@ class TrainPlan(ForwardPlan):
         # flat gradient arena in bucket order; .grad = views
         order = [p for b in self.reducer.buckets for p in b]
         assert len(order) == len(self.params)
-        self.gflat = torch.zeros(sum(p.numel() for p in order), dtype=torch.float32, device=dev)
+        # (every vector starts on a 16-byte boundary: the parameters live in an array of the same layout -- below -- and the kernels
+        # read biases and weights as 16-byte words; the <= 3 padding floats behind a vector stay zero in every array)
+        self.gflat = torch.zeros(sum((p.numel() + 3) // 4 * 4 for p in order), dtype=torch.float32, device=dev)
         self._goff, self._bucket_of, o = {}, {}, 0
         self.bucket_range = []
         for bi, b in enumerate(self.reducer.buckets):
@@ -300,9 +302,23 @@ class TrainPlan(ForwardPlan):
                 self._goff[id(p)] = o
                 self._bucket_of[id(p)] = bi
                 p.grad = self.gflat[o:o + p.numel()].view(p.shape)
-                o += p.numel()
+                o += (p.numel() + 3) // 4 * 4
             self.bucket_range.append((o0, o))
         self.reducer.adopt_flat(self.gflat, self.bucket_range)
+        # The parameters themselves move into ONE flat array of the same order (their .data become views of it, values kept; done
+        # before the program below takes any pointer): with the moments of the optimiser laid out likewise, an Adam step is one
+        # launch over four flat arrays (adam_step) instead of torch's four multi-tensor launches at a quarter of the bandwidth.
+        self.pflat = torch.zeros_like(self.gflat)
+        with torch.no_grad():
+            for p in order:
+                o = self._goff[id(p)]
+                v = self.pflat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+        ops.invalidate_weight_cache()          # (images cached for the old storage)
+        # the weight images are (re)made on other streams: the copies above must have landed before any of them reads a parameter
+        torch.cuda.current_stream(dev).synchronize()
+        self._adam = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         # The side stream is a HIGH-priority stream: HIP maps the normal-priority streams of a process round robin onto 4 hardware
         # queues, and a process that has made a few (bench.py: three forward streams) gets a side stream that SHARES the queue of
@@ -526,3 +542,55 @@ class TrainPlan(ForwardPlan):
     def finish(self):
         """Wait for the all-reduces (several ranks) and divide: after this the .grad views hold the step's gradients."""
         self.reducer.finish_flat()
+
+    def adam_step(self, opt):
+        """optimizer.step() (main.py:216) for a torch.optim.Adam over exactly this plan's parameters (one group, weight_decay 0, no
+        amsgrad / maximize: main.py:138-140) as ONE launch (hpl_adam_flat) over the flat parameter / gradient arrays and two flat
+        moment arrays.  `opt` stays the owner of the state: its per-parameter 'exp_avg' / 'exp_avg_sq' become views of the flat
+        moments (values adopted if it was loaded from a checkpoint), 'step' one shared device scalar -- opt.state_dict() keeps the
+        reference's checkpoint format (main.py:183-189).  Do not mix with opt.step() (the shared scalar would be bumped per
+        parameter).  Returns False, having done nothing, for an optimiser it does not cover."""
+        if isinstance(self._adam, list):
+            st = opt.state.get(self.params[0])
+            if not st or st.get('step') is not self._adam[2]:      # opt.load_state_dict() since: adopt the loaded state
+                self._adam = None
+        if self._adam is None:
+            g = opt.param_groups
+            ok = (isinstance(opt, torch.optim.Adam) and not isinstance(opt, torch.optim.AdamW) and len(g) == 1 and
+                  len(g[0]['params']) == len(self.params) and all(a is b for a, b in zip(g[0]['params'], self.params)) and
+                  g[0].get('weight_decay', 0) == 0 and not g[0].get('amsgrad') and not g[0].get('maximize') and
+                  not isinstance(g[0]['lr'], torch.Tensor))
+            if not ok:
+                self._adam = False
+            else:
+                m, v = torch.zeros_like(self.pflat), torch.zeros_like(self.pflat)
+                t = 0
+                for p in self.params:
+                    st = opt.state.get(p)
+                    o = self._goff[id(p)]
+                    if st:                                    # loaded from a checkpoint (or stepped before): adopt
+                        m[o:o + p.numel()].copy_(st['exp_avg'].reshape(-1))
+                        v[o:o + p.numel()].copy_(st['exp_avg_sq'].reshape(-1))
+                        t = max(t, int(float(st['step'])))
+                step_t = torch.full((), float(t), dtype=torch.float32, device=self.pflat.device)
+                for p in self.params:
+                    o = self._goff[id(p)]
+                    opt.state[p] = {'step': step_t, 'exp_avg': m[o:o + p.numel()].view(p.shape),
+                                    'exp_avg_sq': v[o:o + p.numel()].view(p.shape)}
+                self._adam = [m, v, step_t, t, getattr(torch._C._autograd, '_unsafe_set_version_counter', None)]
+        if self._adam is False:
+            return False
+        m, v, step_t, t, bump = self._adam
+        g = opt.param_groups[0]
+        t += 1
+        self._adam[3] = t
+        b1, b2 = g['betas']
+        check(_lib.load().hpl_adam_flat(self.pflat.data_ptr(), self.gflat.data_ptr(), m.data_ptr(), v.data_ptr(), self.pflat.numel(),
+                                        float(g['lr']), b1, b2, g['eps'], t, stream()), 'hpl_adam_flat')
+        step_t.add_(1.0)
+        # the launch wrote the parameters behind autograd's back: their version counters are what every weight-image cache keys on
+        if bump is not None:
+            bump(tuple(self.params), tuple(p._version + 1 for p in self.params))
+        else:
+            ops.invalidate_weight_cache()
+        return True

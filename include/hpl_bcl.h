@@ -351,6 +351,14 @@ int hpl_regroup(const float *G, int64_t ldg, int64_t M, int F, int C, float *out
  * flow hpl_plan_run writes), sf (3, N); *loss = mean_n ||pred_n - sf_n||_2 (one workgroup, fixed-order sum:
  * deterministic), grad[n][c] = (pred - sf) / (N * ||.||) (0 where the norm is 0). */
 int hpl_epe3d(const float *pred, const float *sf, int64_t N, float *grad, float *loss, hplStream stream);
+/* optimizer.step() of main.py:216 for the Adam of main.py:138-140 (lr 1e-4, weight_decay 0, no amsgrad) over FLAT fp32 arrays,
+ * step >= 1 counting this one: m = lerp(m, g, 1 - beta1); v = beta2 v + (1 - beta2) g^2;
+ * p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps) -- torch's fused Adam operation by operation, the
+ * scalars computed in double and rounded once as there.  The training plan keeps parameters, gradients and both moments of a
+ * model in four arrays of one layout, so a step is ONE launch over 19.3 M elements instead of four multi-tensor launches.
+ * All pointers 16-byte aligned. */
+int hpl_adam_flat(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1, double beta2, double eps,
+                  int64_t step, hplStream stream);
 
 /* Per-tap lists of present vertices: list_m[tap_ptr[f] .. tap_ptr[f+1]) = { m : nbr[f][m] >= 0 }
  * ascending, list_row = their source rows nbr[f][m]; both hold up to F*M entries, tap_ptr F+1

@@ -89,6 +89,76 @@ def test_trainer_takes_the_native_step_and_matches_the_autograd_loop():
         assert d <= 6.1e-4, (k, d)                       # (Adam moves an entry by <= lr per step whatever the gradient's size)
 
 
+def test_adam_flat_is_torch_adam():
+    """hpl_adam_flat against torch.optim.Adam (main.py:138-140: lr 1e-4, weight_decay 0) on the same gradients, five steps, an odd
+    length (scalar tail) and gradients over twelve decades."""
+    from hplflownet_amd import _lib
+    torch.manual_seed(3)
+    n = 100003
+    p0 = torch.randn(n, device=DEV)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-4)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, 1e-4
+    scale = torch.pow(10.0, torch.randint(-8, 4, (n,), device=DEV).float())       # (per entry, the same in every step)
+    for t in range(1, 6):
+        g = torch.randn(n, device=DEV) * scale
+        g[::97] = 0.0
+        ref.grad = g.clone()
+        opt.step()
+        _lib.check(_lib.load().hpl_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, b1, b2, eps, t, _lib.stream()),
+                   'hpl_adam_flat')
+        st = opt.state[ref]
+        # (a step moves an entry by <= lr = 1e-4; one rounding of a parameter of size 4 is 4.8e-7)
+        assert float((p - ref.detach()).abs().max()) <= 1e-6
+        # (torch's unfused step rounds (1 - beta2) g g in another order; the lerp may cancel: the bar is in units of the entry's gradients)
+        ratio = (m - st['exp_avg']).abs() / scale
+        assert float(ratio.max()) <= 2e-6, (t, float(ratio.max()))
+        assert torch.allclose(v, st['exp_avg_sq'], rtol=1e-5, atol=0)
+
+
+def test_plan_adam_step_keeps_the_optimizer_state_and_follows_a_loaded_checkpoint():
+    """TrainPlan.adam_step: the parameters are views of one flat array, the optimiser's moments views of two more, 'step' counts;
+    opt.state_dict() keeps torch's format, and a state loaded with opt.load_state_dict() is adopted at the next step.  Two trainers,
+    one stepping through the plan and one through torch's Adam on the same gradients, stay together."""
+    from hplflownet_amd import engine
+    pc1, pc2, sf = synthetic_pair(512, 0)
+    data = [tuple(torch.from_numpy(np.ascontiguousarray(a.T)).to(DEV) for a in (pc1, pc2, sf))]
+    tr = engine.Trainer('HPLFlowNetShallow', DEV, lr=1e-4, init='hash', native_step=True)
+    tr.train_epoch(data)
+    tr.train_epoch(data)
+    plan = tr.tplan
+    assert plan is not None and isinstance(plan._adam, list)
+    params = list(tr.model.parameters())
+    lo, hi = plan.pflat.data_ptr(), plan.pflat.data_ptr() + 4 * plan.pflat.numel()
+    assert all(lo <= p.data_ptr() < hi for p in params)
+    sd = tr.opt.state_dict()
+    assert len(sd['state']) == len(params) and all(float(st['step']) == 2.0 for st in sd['state'].values())
+    assert all(st['exp_avg'].shape == p.shape and st['exp_avg_sq'].shape == p.shape for st, p in zip(sd['state'].values(), params))
+    # a checkpoint round trip: the loaded moments are adopted, the step count goes on from 2
+    ck = tr.state()
+    assert all(v.data_ptr() < lo or v.data_ptr() >= hi for v in ck['state_dict'].values() if v.is_cuda)      # tensors of their own
+    tr2 = engine.Trainer('HPLFlowNetShallow', DEV, lr=1e-4, init='hash', native_step=True)
+    tr2.model.load_state_dict({k[len('module.'):]: v for k, v in ck['state_dict'].items()})
+    tr2.opt.load_state_dict(ck['optimizer'])
+    l3a, l3b = tr.train_epoch(data), tr2.train_epoch(data)
+    assert abs(l3a - l3b) < 1e-4 * abs(l3a)
+    assert float(next(iter(tr2.opt.state_dict()['state'].values()))['step']) == 3.0
+    for a, b in zip(tr.model.parameters(), tr2.model.parameters()):
+        assert float((a - b).abs().max()) <= 2e-6          # (same state, same gradients up to the atomics of the weight gradients)
+    # the inference path sees the stepped weights (version counters bumped behind the launch)
+    with torch.no_grad():
+        lat = tr.gen.build(data[0][0], data[0][1])
+        tr.model.eval()
+        f1 = tr.model(data[0][0][None], data[0][1][None], lat).clone()
+        tr.model.train()
+    tr.train_epoch(data)
+    with torch.no_grad():
+        tr.model.eval()
+        f2 = tr.model(data[0][0][None], data[0][1][None], lat)
+    assert float((f1 - f2).abs().max()) > 0.0
+
+
 @pytest.mark.parametrize('fill', [float('nan'), 1e30])
 def test_native_step_does_not_see_what_the_workspace_held(fill):
     """The training program lays its matrices out by lifetime and scales the wide launches' operands by the largest magnitude
