@@ -98,8 +98,8 @@ __device__ __forceinline__ void splat_round(V &acc, const float *__restrict__ co
 // entry count): G lane groups per vertex (G * CV lanes, 256 / (G * CV) vertices per workgroup pass) take rounds of R / 2 entries in
 // turn, group g the rounds g, g + G, ...; the partial sums of groups 1 .. G-1 meet in LDS and are added in group order.  Deterministic
 // (a fixed order per vertex, the same as the plain loop for segments of up to R / 2 entries); three times the lanes in flight on the
-// levels where a lane's chain of dependent rounds set the time (level 2 of one N = 8 192 cloud: 12.9 -> 10.0 us; launches of
-// 2^20 lanes or more keep one group: splat_launch).
+// levels where a lane's chain of dependent rounds set the time (level 2 of one N = 8 192 cloud: 12.9 -> 10.0 us; in a forward the eight
+// splats of levels 3-6 7-12 -> 5-9 us each; launches of 2^19 lanes or more keep one group: splat_launch).
 template <typename V, int R>
 __global__ void __launch_bounds__(256) k_splat(const float *__restrict__ feat, int64_t ldf, uint32_t CV,
                                                const int32_t *__restrict__ csr_ptr,
@@ -278,8 +278,6 @@ int splat_launch(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr, 
     const int cv = vec ? C / 4 : C;
     HPL_REQUIRE((int64_t)H * cv < (int64_t)1 << 31, "hpl_splat: H*C too large (%lld x %d)", (long long)H, C);
     const uint32_t total = (uint32_t)(H * cv);
-    int chunk;
-    const int grid = xcd_grid(imin(cdiv((int64_t)total, 256), 256 * 32), &chunk);
     // lane groups per vertex for long segments: the G <= 4 that fills most of the 256 lanes (CV = 17: G = 3, five vertices per pass)
     uint32_t G = 1;
     for (uint32_t g = 2, best = 0; g <= 4; ++g) {
@@ -288,7 +286,15 @@ int splat_launch(const float *feat, int64_t ldf, int C, const int32_t *csr_ptr, 
     }
     // (measured, tools/bench_splat_slice.py: level 2 of one N = 8 192 cloud 12.9 -> 10.0 us; sixteen such clouds in one launch, 2.5 M lanes,
     // 76 -> 80 us -- a launch that fills the GPU several times over gains nothing from more lanes and pays the two barriers)
-    if (total >= (1u << 20)) G = 1;
+    if (total >= (1u << 19)) G = 1;
+    // The grid covers the form with MORE workgroups (the host does not know which one the device will take): one pass of 256 / (G CV)
+    // vertices per workgroup in the grouped form -- with the plain form's grid every workgroup ran G passes one after the other, G times
+    // the chain of dependent loads, and the coarse levels' splats took 17 us instead of 11 --; in the plain form the surplus
+    // workgroups find idx >= total and leave.
+    int64_t blocks = cdiv((int64_t)total, 256);
+    if (G > 1) blocks = imax(blocks, cdiv(H, (int64_t)(256u / ((uint32_t)cv * G))));
+    int chunk;
+    const int grid = xcd_grid(imin(blocks, 256 * 32), &chunk);
     if (vec) k_splat<float4, 8><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate, (uint32_t)H, G);
     else k_splat<float, 8><<<grid, 256, 0, s>>>(feat, ldf, (uint32_t)cv, csr_ptr, csr_pt, csr_w, norm, total, out, ldo, chunk, accumulate, (uint32_t)H, G);
     HPL_CHECK_LAUNCH("hpl_splat");
