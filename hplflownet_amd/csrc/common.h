@@ -45,4 +45,14 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
         }                                   \
     } while (0)
 
+
+// *slot = max(*slot, v) for magnitudes kept as bit patterns (they order like unsigned integers, NaN on top).  Hundreds to thousands of
+// workgroups publishing into ONE word serialise on it: look first -- a relaxed device-scope load does not serialise -- and only a
+// workgroup that would raise the value pays the atomic.  A stale (smaller) look costs an atomic that changes nothing; the result is
+// the same maximum.  (Single forward at N = 8 192: 3.19-3.28 -> 3.07-3.11 ms over the boxes of round 5.)
+__device__ __forceinline__ void amax_publish(unsigned *slot, unsigned v) {
+    if (v == 0u) return;
+    if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return;
+    atomicMax(slot, v);
+}
 }  // namespace hpl

@@ -690,7 +690,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         if (p.y_amax && plain) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ymax = max(ymax, (unsigned)__shfl_xor((int)ymax, o));
-            if (lane == 0 && ymax) atomicMax(reinterpret_cast<unsigned *>(p.y_amax), ymax);
+            if (lane == 0) amax_publish(reinterpret_cast<unsigned *>(p.y_amax), ymax);
         }
     } else
 #pragma unroll
@@ -768,7 +768,7 @@ __device__ __forceinline__ void amax_reduce(unsigned v, unsigned *slot) {
     __syncthreads();
     if (threadIdx.x == 0) {
         v = max(max(part[0], part[1]), max(part[2], part[3]));
-        if (v) atomicMax(slot, v);
+        amax_publish(slot, v);
     }
 }
 

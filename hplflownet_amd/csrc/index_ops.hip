@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(256) k_leaky_bwd4(const float *__restrict__ dY
         __syncthreads();
         if (threadIdx.x == 0) {
             vmax = max(max(part[0], part[1]), max(part[2], part[3]));
-            if (vmax) atomicMax(amax, vmax);
+            amax_publish(amax, vmax);
         }
     }
 }
