@@ -43,7 +43,9 @@ ops.enable_weight_bank(False)
 for side in ((True,) if ONLY == 'native' else (False, True)):
     plan = TrainPlan(model, side_stream=side)
     def nat():
-        plan.step(t1, t2, tsf, lat); plan.finish(); opt.step()
+        plan.step(t1, t2, tsf, lat); plan.finish()
+        if not plan.adam_step(opt):              # one launch over the flat arrays, as engine.Trainer does
+            opt.step()
     ms, host = timed(nat)
     if side:
         hi = torch.cuda.Stream(priority=-1)
@@ -56,7 +58,7 @@ for side in ((True,) if ONLY == 'native' else (False, True)):
     print('native step (side stream %s): %.2f ms (host enqueue %.2f ms); program: %d forward + %d backward ops, %d un-layout buckets'
           % (side, ms, host, nfwd, len(plan.prog.ops) - nfwd, len(plan.cuts)))
     torch.cuda.synchronize()
-    h0 = time.perf_counter(); plan.step(t1, t2, tsf, lat); h1 = time.perf_counter(); plan.finish(); opt.step(); h2 = time.perf_counter()
+    h0 = time.perf_counter(); plan.step(t1, t2, tsf, lat); h1 = time.perf_counter(); plan.finish(); plan.adam_step(opt) or opt.step(); h2 = time.perf_counter()
     torch.cuda.synchronize()
     print('   host time of one step issued to an idle GPU: program %.2f ms, Adam %.2f ms' % ((h1 - h0) * 1e3, (h2 - h1) * 1e3))
     def fwd_only():
