@@ -418,7 +418,7 @@ class NativeLattice(object):
                    self._t(t.csr_w, torch.float32, (4 * Np,)), self._t(t.csr_norm, torch.float32, (Hp,)))
             lv.pair._csr = csr
             c0._csr = (csr[0][:H0 + 1], csr[1][:4 * n0], csr[2][:4 * n0], csr[3][:H0])
-            c1._csr_src = (lv.pair, n0, H0)
+            c1._csr_src = (csr, n0, H0)
             if t.blur:
                 F = 15
                 blur_p = self._t(t.blur, torch.int32, (F, Hp))

@@ -68,8 +68,8 @@ class CloudTables(object):
 
     def csr(self):
         if self._csr is None and getattr(self, '_csr_src', None) is not None:
-            pair, n0, h0 = self._csr_src
-            p_ptr, p_pt, p_w, p_norm = pair.csr()
+            pair_csr, n0, h0 = self._csr_src           # (the pair's ARRAYS, not the pair: no reference cycle cloud <-> pair)
+            p_ptr, p_pt, p_w, p_norm = pair_csr
             self._csr = (p_ptr[h0:] - 4 * n0, p_pt[4 * n0:] - n0, p_w[4 * n0:], p_norm[h0:])
         if self._csr is None:
             dev = self.bary.device
@@ -118,7 +118,7 @@ class PairTables(object):
             if c0._csr is None:
                 c0._csr = (csr_ptr[:c0.H + 1], csr_pt[:4 * c0.N], csr_w[:4 * c0.N], norm[:c0.H])
             if c1._csr is None:
-                c1._csr_src = (self, c0.N, c0.H)
+                c1._csr_src = (self._csr, c0.N, c0.H)
         return self._csr
 
     def slice_back(self, g, use_norm):
