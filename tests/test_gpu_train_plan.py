@@ -159,6 +159,28 @@ def test_plan_adam_step_keeps_the_optimizer_state_and_follows_a_loaded_checkpoin
     assert float((f1 - f2).abs().max()) > 0.0
 
 
+def test_training_lattices_die_with_their_last_reference():
+    """A training lattice (device tables + tap lists) pins a 130-MB arena at N = 8 192: it must be freed by reference counting when
+    the step that used it is over, not wait for Python's cycle collector (round 5: the second cloud's tables held the pair, the pair the
+    cloud -- `bench.py --train` grew by 60-90 MB per step).  With the collector switched off an epoch leaves nothing behind."""
+    import gc
+    from hplflownet_amd import engine
+    mk = lambda s: tuple(torch.from_numpy(np.ascontiguousarray(a.T)).to(DEV) for a in synthetic_pair(2048, s))
+    data = [mk(s) for s in range(3)] * 4
+    tr = engine.Trainer('HPLFlowNetShallow', DEV, lr=1e-4, init='hash')
+    tr.train_epoch(data[:3])
+    gc.collect()
+    gc.disable()
+    try:
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        tr.train_epoch(data)
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() <= base + (1 << 20), (torch.cuda.memory_allocated() - base) / 2 ** 20
+    finally:
+        gc.enable()
+
+
 @pytest.mark.parametrize('fill', [float('nan'), 1e30])
 def test_native_step_does_not_see_what_the_workspace_held(fill):
     """The training program lays its matrices out by lifetime and scales the wide launches' operands by the largest magnitude
