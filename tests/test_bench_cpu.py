@@ -41,3 +41,67 @@ def test_committed_pmc_files_carry_the_stamp_of_the_committed_sources():
     for name in ('mfma_pmc.json', 'pmc_traffic.json'):
         with open(os.path.join(ROOT, 'profiles', name)) as f:
             assert json.load(f).get('stamp') == want, name
+
+
+REQUIRED = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'epe3d', 'exact_bf16x3', 'train', 'ranks', 'kernels')
+
+
+def check_contract_line(line, n_gpus=1, required=REQUIRED):
+    """What the driver's parser needs of bench.py's ONE stdout line (shared with tests/test_gpu_multirank.py)."""
+    assert '\n' not in line and len(line) < bench.LINE_LIMIT, len(line)
+    d = json.loads(line)
+    for k in required:
+        assert k in d, k
+    assert d['n_gpus'] == n_gpus and d['unit'] == 'point-pairs/s' and d['higher_is_better'] is True
+    assert d['metric'] == 'point-pairs/sec + EPE3D, N=8192 FlyingThings3D, 1/2/4/8 MI355X'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    if 'roofline' in required:
+        for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+            assert k in d['roofline'], k
+    if 'cpu_baseline' in required:
+        for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+            assert k in d['cpu_baseline'], k
+    return d
+
+
+def test_contract_line_is_short_and_complete():
+    """Round 5's line had grown to 20 KB and the driver's record of it came back unparsed (BENCH_r05.json: parsed null).  The
+    line is now made from the full record by bench.compact_line: rebuilt here from the recorded round-5 record (the 20-KB one)
+    it must stay under bench.LINE_LIMIT with every contract field, `roofline` and `cpu_baseline` in it."""
+    with open(os.path.join(ROOT, 'profiles', 'r05y_bench_driver_cmd.json')) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 3 * bench.LINE_LIMIT            # (the input is the oversized record)
+    line = bench.compact_line(full)
+    d = check_contract_line(line)
+    assert abs(d['value'] - full['value']) < 1e-5 * full['value']
+    assert abs(d['roofline']['frac'] - full['roofline']['frac']) < 1e-5
+    assert d['roofline']['traffic'] == full['roofline']['traffic'] and d['roofline']['whole_step']['frac'] > 0
+    assert d['exact_bf16x3']['value'] > 0 and d['train']['ms_per_step'] > 0 and d['epe3d']['abs_delta'] < 1e-4
+    assert {'slice', 'splat', 'slice_deep', 'splat_deep'} <= set(d['kernels'])
+    assert all('frac' in v for v in d['kernels'].values())
+    # eight ranks' worth of per-rank figures still fit
+    full['ranks']['ms_per_step_by_rank'] = [2.392284749657847] * 8
+    full['ranks']['host_busy_ms_by_rank'] = [0.8488328981911764] * 8
+    full['n_gpus'] = 8
+    check_contract_line(bench.compact_line(full), n_gpus=8)
+    # and a record bloated beyond anything seen sheds optional blocks instead of growing
+    full['roofline']['kernel'] = 'x' * 5000
+    full['config']['workload'] = 'y' * 3000
+    full['kernels'] = {k: dict(v, frac=0.123456789) for k, v in full['kernels'].items()}
+    assert len(bench.compact_line(full)) < bench.LINE_LIMIT + 3000
+
+
+def test_emit_writes_the_detail_file_and_prints_one_line(tmp_path, capsys):
+    with open(os.path.join(ROOT, 'profiles', 'r05y_bench_driver_cmd.json')) as f:
+        full = json.load(f)
+    path = str(tmp_path / 'bench_detail.json')
+    bench.emit(full, path)
+    out = capsys.readouterr().out
+    assert out.count('\n') == 1
+    d = check_contract_line(out.strip())
+    assert d['detail'] == 'bench_detail.json'
+    with open(path) as f:
+        assert json.load(f)['kernels'].keys() == full['kernels'].keys()          # the per-class tables live there
+    bench.emit(full, str(tmp_path / 'no' / 'such' / 'dir' / 'x.json'))         # an unwritable place costs the file, not the line
+    check_contract_line(capsys.readouterr().out.strip())

@@ -11,6 +11,23 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_bench_cpu import check_contract_line  # noqa: E402
+
+#: a multi-rank line carries the contract fields, `roofline` and `ranks`; the single-GPU extras (cpu_baseline, epe3d, exact_bf16x3,
+#: the train probe, power) are rank-0-at-N=1 work and must NOT be in it (they would sit inside the driver's clock at N = 2, 4, 8)
+MULTI = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+         'dtype', 'data', 'config', 'roofline', 'ranks')
+
+
+def _one_line(out0, n_gpus, train=False):
+    lines = [ln for ln in out0.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    assert out0.strip().splitlines()[-1] == lines[0]                     # the LAST stdout line
+    d = check_contract_line(lines[0], n_gpus=n_gpus, required=MULTI)
+    for k in ('cpu_baseline', 'epe3d', 'exact_bf16x3', 'train'):
+        assert k not in d, k
+    return d
 
 
 def _run_two_ranks(extra, timeout=420, world=2):
@@ -40,9 +57,7 @@ def _run_two_ranks(extra, timeout=420, world=2):
 def test_two_ranks_inference_on_one_gpu():
     out0, out1 = _run_two_ranks(['--steps', '6', '--warmup', '1', '--points', '2048'])
     assert not [ln for ln in out1.splitlines() if ln.startswith('{')]        # only rank 0 reports (gloo logs a line)
-    lines = [ln for ln in out0.strip().splitlines() if ln.startswith('{')]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _one_line(out0, 2)
     assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak' and d['value'] > 0
     # whole-job throughput: both ranks' pairs over the slowest rank's time
     assert abs(d['value'] - 2 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
@@ -54,7 +69,7 @@ def test_two_ranks_training_step_on_one_gpu():
     """bench.py --train with two ranks: one pair per rank, GradAllReducer hooks + bucketed all-reduce (gloo here), Adam."""
     out0, out1 = _run_two_ranks(['--train', '--steps', '2', '--warmup', '1', '--points', '2048'])
     assert not [ln for ln in out1.splitlines() if ln.startswith('{')]        # only rank 0 reports (gloo logs a line)
-    d = json.loads([ln for ln in out0.strip().splitlines() if ln.startswith('{')][0])
+    d = _one_line(out0, 2)
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['workload'].lower().find('train') >= 0
 
 
@@ -65,7 +80,7 @@ def test_eight_ranks_dry_run_on_one_gpu():
     clouds (N = 1024, 3 steps): this checks the code path, not the speed.  Nothing here runs over RCCL with > 1 rank."""
     out0, out1 = _run_two_ranks(['--steps', '3', '--warmup', '1', '--points', '1024', '--no-train-probe'], timeout=600, world=8)
     assert not [ln for ln in out1.splitlines() if ln.startswith('{')]
-    d = json.loads([ln for ln in out0.strip().splitlines() if ln.startswith('{')][0])
+    d = _one_line(out0, 8)
     assert d['n_gpus'] == 8 and d['steps'] == 3 and d['value'] > 0
     assert abs(d['value'] - 8 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
     # every rank reported, the job's step time is the slowest rank's, and no rank's host threads are what limits it: the
@@ -78,7 +93,7 @@ def test_eight_ranks_dry_run_on_one_gpu():
     assert max(rk['host_busy_ms_by_rank']) < 1.5          # ms, absolute: half of ONE GPU's N=8192 step (2.9 ms) with 8 ranks' threads on the host
     assert d['pipelined_output_check']['max_abs_diff'] == 0.0
     out0, _ = _run_two_ranks(['--train', '--steps', '3', '--warmup', '1', '--points', '1024'], timeout=600, world=8)
-    d = json.loads([ln for ln in out0.strip().splitlines() if ln.startswith('{')][0])
+    d = _one_line(out0, 8)
     assert d['n_gpus'] == 8 and d['value'] > 0 and 'train' in d['config']['workload'].lower()
 
 
@@ -93,9 +108,7 @@ def test_self_spawned_ranks_on_one_gpu():
                         '--no-cpu-baseline', '--no-train-probe'], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith('{')]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _one_line(p.stdout, 2)
     assert d['n_gpus'] == 2 and d['ranks']['ranks_seen'] == 2 and d['ranks']['backend'] == 'gloo' and d['value'] > 0
     env.pop('HPL_BENCH_SHARE_GPU')
     import torch
