@@ -786,7 +786,10 @@ def main():
             if not native_train:
                 opt.zero_grad(set_to_none=True)
             loss.backward()
-            reducer()
+            if native_train:
+                tplan.reduce_fallback()      # same bucket order as the ranks that ran the native program
+            else:
+                reducer()
             if not (native_train and tplan.adam_step(opt)):
                 opt.step()
             return flow

@@ -167,7 +167,9 @@ class Trainer(object):
         if self.tplan is None:
             self.opt.zero_grad(set_to_none=True)
         loss.backward()
-        if self.reducer is not None:
+        if self.tplan is not None:
+            self.tplan.reduce_fallback()             # same bucket order as the ranks that ran the native program
+        elif self.reducer is not None:
             self.reducer()
         if self.tplan is None or not self.tplan.adam_step(self.opt):
             self.opt.step()

@@ -120,6 +120,16 @@ class _Backward(object):
     def _touch(self, p):
         self.ready[self.pid[id(p)]] = len(self.P.ops) - 1
 
+    def _stores(self, p):
+        """The op just emitted STORES into p's gradient vector (OP_COLSUM zeroes its target, OP_VCOPY copies over it), the weight
+        gradients ACCUMULATE into the zeroed arena: a parameter that feeds two forward ops (a shared module, a bias used by a
+        slice and a conv) would silently keep only the last store.  No model here shares one; refuse instead of being wrong."""
+        i = self.pid[id(p)]
+        if i in self.ready:
+            raise _lib.HplError('native backward: parameter %d receives a second gradient contribution through a storing op '
+                                '(shared parameters are not supported by TrainPlan; use the autograd path)' % i)
+        self._touch(p)
+
     def _bank(self, w, R, Q, F, sr, sq, sf, base, mirror):
         self.P.bank.register(w.detach(), R, Q, F, sr, sq, sf, base, mirror)
         self.P.weights.append((w, R, Q, F, sr, sq, sf, base, mirror))
@@ -176,7 +186,7 @@ class _Backward(object):
         if m['bias'] >= 0:
             b = P.biases[m['bias']]
             P.raw(OP_COLSUM, a=g, M=M, C=N, bias=self._gvec(b), flags=F_SIDE)
-            self._touch(b)
+            self._stores(b)
         # dZ[(v*K + k)] = sum_f g[inverse[f][v*K + k]]: the same gather-sum through the inverse table (built once per step and level)
         inv = self.inv.get(L)
         if inv is None:
@@ -227,7 +237,7 @@ class _Backward(object):
             self._touch(bparam)
         if pair is not None:                          # conv bias + layer bias were one vector in the forward: one gradient, two owners
             P.raw(OP_VCOPY, weight=self._gvec(pair[0]), bias=self._gvec(pair[1]), N=N, flags=F_SIDE)
-            self._touch(pair[1])
+            self._stores(pair[1])
         # data gradient
         if a.buf == self.leaf:
             return
@@ -272,7 +282,7 @@ class _Backward(object):
         if m['bias'] >= 0:
             b = P.biases[m['bias']]
             P.raw(OP_COLSUM, a=g, M=m['N'], C=m['C'], bias=self._gvec(b), flags=F_SIDE)
-            self._touch(b)
+            self._stores(b)
 
 
 class TrainPlan(ForwardPlan):
@@ -416,6 +426,12 @@ class TrainPlan(ForwardPlan):
         cached = getattr(lat, '_train_tables', None)
         if cached is not None:
             return cached
+        # a lattice the native forward cannot take (reference wire format without pair tables, a level without a blur table,
+        # too few levels) goes down the documented autograd path instead of raising inside the step
+        if not self.accepts(lat) or not hasattr(lat, 'levels') or any(lv.blur[0] is None or lv.clouds[1] is None
+                                                                      for lv in lat.levels[:self.NLEV]):
+            lat._train_tables = False
+            return False
         arr0, n, keep = level_tables(lat, self.hint)
         n = self.NLEV
         arr = (LevelTables * n)()
@@ -543,6 +559,15 @@ class TrainPlan(ForwardPlan):
         """Wait for the all-reduces (several ranks) and divide: after this the .grad views hold the step's gradients."""
         self.reducer.finish_flat()
 
+    def reduce_fallback(self):
+        """The all-reduce of a step this rank ran through autograd because the native program refused its lattice (step() returned
+        None): the gradients sit in the same flat arena, and the buckets go out in THIS plan's order -- `bucket_order`, what a rank
+        on the native program issues --, not in the reducer's index order: ranks on different paths in the same step still post the
+        same collectives in the same slots (a bucket of another size in a slot hangs or corrupts the job)."""
+        for b in self.bucket_order:
+            self.reducer.launch_flat(b)
+        self.reducer.finish_flat()
+
     def adam_step(self, opt):
         """optimizer.step() (main.py:216) for a torch.optim.Adam over exactly this plan's parameters (one group, weight_decay 0, no
         amsgrad / maximize: main.py:138-140) as ONE launch (hpl_adam_flat) over the flat parameter / gradient arrays and two flat
@@ -590,7 +615,15 @@ class TrainPlan(ForwardPlan):
         step_t.add_(1.0)
         # the launch wrote the parameters behind autograd's back: their version counters are what every weight-image cache keys on
         if bump is not None:
-            bump(tuple(self.params), tuple(p._version + 1 for p in self.params))
-        else:
+            try:
+                bump(tuple(self.params), tuple(p._version + 1 for p in self.params))
+            except TypeError:
+                # older torch: _unsafe_set_version_counter(Tensor, int), one tensor per call
+                try:
+                    for p in self.params:
+                        bump(p, p._version + 1)
+                except TypeError:
+                    bump = self._adam[4] = None          # no usable signature: the epoch every cache also keys on
+        if bump is None:
             ops.invalidate_weight_cache()
         return True

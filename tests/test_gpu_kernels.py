@@ -491,7 +491,8 @@ def test_fast_and_generic_epilogues_are_bit_identical():
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
-@pytest.mark.parametrize('kind', ['gconv_f32_stencil', 'gconv_f32_dense_splitk', 'gconv3_groups', 'gconv3_dense', 'wgrad_f32', 'splat', 'slice'])
+@pytest.mark.parametrize('kind', ['gconv_f32_stencil', 'gconv_f32_dense_splitk', 'gconv3_groups', 'gconv3_dense', 'gconv3_groups_bf16x3',
+                                  'gconv3_dense_bf16x3', 'gconv3_stencil_splitk', 'gconv3_stencil_splitk_bf16x3', 'wgrad_f32', 'splat', 'slice'])
 def test_results_do_not_depend_on_what_runs_beside_them(kind):
     """Every kernel with hand-counted load waits (buffer loads the compiler's s_waitcnt bookkeeping does not see) on a side stream
     while memory-bound kernels of another stream saturate HBM: the same result as alone.  (This disturbance exposed the
@@ -500,6 +501,11 @@ def test_results_do_not_depend_on_what_runs_beside_them(kind):
     from hplflownet_amd import ops
     g = torch.Generator().manual_seed(2)
     dev = 'cuda'
+    # round 6 (ADVICE): both operand forms of the split kernel (fp16 pairs / bf16 triples: the LDS stages and products differ, the
+    # hand-counted waits do not), its split-K form (mid-size stencil, partial tiles + finish), and a disturbance that is not only
+    # elementwise reads: copies that saturate HBM in both directions and a stream of same-address atomics beside it
+    planes = 3 if kind.endswith('_bf16x3') else None
+    kind = kind.replace('_bf16x3', '')
     if kind in ('gconv_f32_stencil', 'wgrad_f32'):
         M, C, N, F = 70000, 68, 64, 15
     elif kind == 'gconv_f32_dense_splitk':
@@ -508,6 +514,8 @@ def test_results_do_not_depend_on_what_runs_beside_them(kind):
         M, C, N, F = 26000, 580, 1024, 8
     elif kind == 'gconv3_dense':
         M, C, N, F = 8192, 1024, 1024, 1
+    elif kind == 'gconv3_stencil_splitk':
+        M, C, N, F = 9433, 388, 256, 15               # bcn3_: 74 row tiles x 1 column tile, three workgroups per tile over K
     else:
         M, C, N, F = 52000, 68, 68, 4
     A = torch.randn(M, C, generator=g).to(dev)
@@ -521,7 +529,7 @@ def test_results_do_not_depend_on_what_runs_beside_them(kind):
         Wt = ops.weight_relayout(W, C, N, F, F, C * F, 1)
         kw = {}
         if kind.startswith('gconv3'):
-            kw['Wt3'] = ops.weight_split3(Wt)
+            kw['Wt3'] = ops.weight_split3(Wt, planes=planes) if planes else ops.weight_split3(Wt)
             if F > 1:
                 perm = ops.tap_order(nbr)
                 kw.update(row_perm=perm, tiles=ops.tile_index(nbr, perm, BM=128))
@@ -539,13 +547,23 @@ def test_results_do_not_depend_on_what_runs_beside_them(kind):
     ref = fn().clone()
     torch.cuda.synchronize()
     X = torch.randn(30000, 1024, device=dev)
+    X2 = torch.empty_like(X)
+    cnt = torch.zeros(64, device=dev)
+    hot = torch.zeros(1 << 20, dtype=torch.int64, device=dev)          # index_add_ onto 64 words: a stream of contended atomics
+    ones = torch.ones(1 << 20, device=dev)
     side = torch.cuda.Stream(priority=-1)
-    for _ in range(8):
+    third = torch.cuda.Stream()
+    for it in range(8):
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(side):
             side.wait_event(ev)
             out = fn()
+        with torch.cuda.stream(third):
+            third.wait_event(ev)
+            for _ in range(3):
+                X2.copy_(X)
+                cnt.index_add_(0, hot, ones)
         for _ in range(4):
             Z = torch.relu(X) + 1
         torch.cuda.synchronize()

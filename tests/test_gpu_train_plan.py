@@ -210,3 +210,22 @@ def test_native_step_does_not_see_what_the_workspace_held(fill):
     assert torch.equal(f0, f1) and l0 == l1 and bool(torch.isfinite(g1).all())
     scale = float(g0.abs().max())
     assert float((g1 - g0).abs().max()) <= max(2.0 * float((g2 - g0).abs().max()), 1e-6 * scale)
+
+
+def test_refused_lattice_takes_the_documented_fallback_in_the_plans_bucket_order():
+    """ADVICE (round 5): (a) a lattice the native program cannot take -- the reference's wire format: no pair tables -- makes step()
+    return None (the documented autograd fallback) instead of raising from inside tables(); (b) the fallback's all-reduce goes out
+    in the plan's own bucket order (what ranks on the native program issue), not the reducer's index order."""
+    from hplflownet_amd.train_plan import TrainPlan
+    model, gen, t = _setup('HPLFlowNetShallow', 512)
+    plan = TrainPlan(model)
+    lat = gen.build(t[0], t[1])
+    import hplflownet_amd as H
+    assert plan.step(t[0], t[1], t[2], H.to_reference_format(lat)) is None          # the reference's generated_data (a list of dicts)
+    bogus = types.SimpleNamespace(levels=[])                       # not a lattice this plan accepts
+    assert plan.step(t[0], t[1], t[2], bogus) is None
+    seen = []
+    plan.reducer.launch_flat = lambda b: seen.append(b)
+    plan.reducer.finish_flat = lambda: seen.append('finish')
+    plan.reduce_fallback()
+    assert seen == list(plan.bucket_order) + ['finish'] and sorted(plan.bucket_order) == list(range(len(plan.reducer.buckets)))
