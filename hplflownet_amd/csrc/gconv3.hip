@@ -1008,6 +1008,16 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
         p.col_share = 8 / g;
         p.col_rows = p.col_share == 1 ? p.tiles_m : (int)cdiv(p.tiles_m, COL_CHUNK * p.col_share) * COL_CHUNK;
         grid = p.tiles_n * p.col_share * p.col_rows;
+        // Round 6: ROW-major XCD order (gconv_common.h tile_coords, col_share < 0) -- the column tiles of a tile-row resident on one
+        // XCD together, so that its gathered rows are fetched into that L2 once instead of once per column tile.  A/B in one call
+        // (profiles/r06a_xcd_order_ab.txt, column-major -> row-major): forward passes 380 -> 378, 291 -> 287, 257 -> 255, 218 -> 215 us;
+        // the data gradients (five / three 128-wide column tiles) 527 -> 432 us (bcn1_), 322 -> 305 us (bcn2_).
+        constexpr int xcd_row_major = 1;
+        if (xcd_row_major && p.splits <= 1 && p.tiles_n > 1 && p.tiles_n <= 8) {
+            p.col_share = -1;
+            p.col_rows = (int)cdiv(p.tiles_m, 8);
+            grid = 8 * p.col_rows * p.tiles_n;
+        }
     }
     grid *= p.splits;
     // the epilogue's 32-bit buffer addressing: every destination / residual below 2 GB, rows below 2^24, the residual not wrapped

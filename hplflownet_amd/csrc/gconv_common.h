@@ -98,6 +98,18 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
     const int q = nwg / 8, r = nwg % 8;
     const int xcd = bid % 8, pos = bid / 8;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // bijective
+    if (p.row_perm && p.col_share < 0) {
+        // Row-major order (round 6; the split-operand launches, gconv3.hip launch_split3): XCD x owns the scheduled tile-rows x, x + 8, ... (heaviest first) and
+        // walks the column tiles of a tile-row back to back, so the tiles_n column tiles of one tile-row are resident on ONE XCD
+        // at the same time: its gathered A rows are fetched into that L2 once, not once per column tile; the weight panels of all
+        // column tiles then stream through every L2 (from the Infinity Cache).  Grid = 8 * col_rows * tiles_n.
+        const int x2 = blockIdx.x % 8, pos2 = blockIdx.x / 8;
+        const int j = pos2 / p.tiles_n;
+        tn = pos2 - j * p.tiles_n;
+        const int row = j * 8 + x2;
+        tm = row < p.tiles_m ? (p.tile_idx ? p.tile_mask[(int64_t)row * 8 + 6] : p.tiles_m - 1 - row) : -1;
+        return;
+    }
     if (p.row_perm && p.col_share > 0) {
         // Column-major order: an XCD works through ONE column tile at a time (its weight panel stays in that
         // L2), heaviest tile-rows first.  Column tiles shared by col_share XCDs deal their tile-rows round

@@ -377,3 +377,4 @@ extern "C" int hpl_table_invert(const int32_t *T, int64_t stride, int K, int64_t
     HPL_CHECK_LAUNCH("hpl_table_invert");
     return HPL_OK;
 }
+

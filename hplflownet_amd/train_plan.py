@@ -97,6 +97,7 @@ class _Backward(object):
         self.gvec = {}                 # parameter index -> bias index of its gradient vector (resolved to a pointer later)
         self.gimg = {}                 # forward weight key -> (weight index of the gradient image, (param, C, O, F, Ctot, c0))
         self.ready = {}                # parameter index -> index of the last op that writes its gradient
+        self.touched = [set(), set()]  # per scenario of the SHRINK condition: parameters whose gradient an emitted op writes
         self.gout = None
         self.inv = {}                  # level -> buffer of the inverse pc2 correlation table
 
@@ -119,15 +120,20 @@ class _Backward(object):
 
     def _touch(self, p):
         self.ready[self.pid[id(p)]] = len(self.P.ops) - 1
+        for sc in _Sim._scenarios(self.P.cond):
+            self.touched[sc].add(self.pid[id(p)])
 
     def _stores(self, p):
         """The op just emitted STORES into p's gradient vector (OP_COLSUM zeroes its target, OP_VCOPY copies over it), the weight
-        gradients ACCUMULATE into the zeroed arena: a parameter that feeds two forward ops (a shared module, a bias used by a
-        slice and a conv) would silently keep only the last store.  No model here shares one; refuse instead of being wrong."""
+        gradients ACCUMULATE into the zeroed arena: a parameter that feeds two forward ops that both run (a shared module, a bias
+        used by a slice and a conv) would silently keep only the last store.  No model here shares one; refuse instead of being
+        wrong.  (The two alternative op sequences of an Up layer touch the same parameters under OPPOSITE conditions: only one of
+        them runs, so contributions count per scenario, as in _Sim.)"""
         i = self.pid[id(p)]
-        if i in self.ready:
-            raise _lib.HplError('native backward: parameter %d receives a second gradient contribution through a storing op '
-                                '(shared parameters are not supported by TrainPlan; use the autograd path)' % i)
+        for sc in _Sim._scenarios(self.P.cond):
+            if i in self.touched[sc]:
+                raise _lib.HplError('native backward: parameter %d receives a second gradient contribution through a storing op '
+                                    '(shared parameters are not supported by TrainPlan; use the autograd path)' % i)
         self._touch(p)
 
     def _bank(self, w, R, Q, F, sr, sq, sf, base, mirror):

@@ -1,0 +1,54 @@
+"""CPU: the native training step's PROGRAM (hplflownet_amd.train_plan._Backward over plan.build_program) is plain Python -- it
+emits without a device.  Checks of the emitter that round 5's advisor asked for: every parameter of both models gets exactly the
+gradient writers the model's wiring implies, and a model that SHARES a parameter between two forward ops that both run is refused
+instead of silently keeping only the last storing op's contribution."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _emit(model):
+    from hplflownet_amd import ops
+    from hplflownet_amd.plan import build_program
+    from hplflownet_amd.train_plan import _Backward
+    P = build_program(model, ops.WeightBank())
+    n_fwd = len(P.ops)
+    B = _Backward(P, model, [p for p in model.parameters()])
+    B.leaf = next(o.out.buf for o in P.ops if o.kind == 5)
+    B.emit()
+    return P, B, n_fwd
+
+
+def _model(arch):
+    import hplflownet_amd as H
+    from hplflownet_amd.synthetic import SCALES_FILTER_MAP
+    nl = 7 if arch == 'HPLFlowNet' else 5
+    a = types.SimpleNamespace(dim=3, scales_filter_map=SCALES_FILTER_MAP[:nl], evaluate=False, use_leaky=True, bcn_use_bias=True,
+                              bcn_use_norm=True, last_relu=False, DEVICE='cpu')
+    return getattr(H, arch)(a)
+
+
+@pytest.mark.parametrize('arch,n_fwd', [('HPLFlowNet', 122), ('HPLFlowNetShallow', 64)])
+def test_backward_program_covers_every_parameter(arch, n_fwd):
+    m = _model(arch)
+    P, B, nf = _emit(m)
+    n_par = len(list(m.parameters()))
+    assert nf == n_fwd and len(P.ops) > 2 * nf
+    assert sorted(B.ready) == list(range(n_par))                    # every parameter's gradient has a last writer
+    # both outcomes of the per-level SHRINK condition write every parameter (the two orders of an Up layer emit under opposite
+    # conditions: each scenario sees each parameter, none twice through a storing op -- _stores would have raised)
+    assert B.touched[0] == B.touched[1] == set(range(n_par))
+
+
+def test_shared_parameter_is_refused():
+    from hplflownet_amd._lib import HplError
+    m = _model('HPLFlowNetShallow')
+    m.bcn3_.bias = m.bcn2_.bias                 # one slice bias feeding two Up layers that both run
+    with pytest.raises(HplError, match='second gradient contribution'):
+        _emit(m)
