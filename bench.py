@@ -469,9 +469,9 @@ def source_stamp():
     and the switches that select kernels / tiles."""
     import hashlib
     h = hashlib.sha256()
-    for f in ('gconv.hip', 'gconv3.hip', 'gconv_common.h', 'executor.hip', 'row_order.hip'):
+    for f in ('gconv.hip', 'gconv3.hip', 'gconv_common.h', 'executor.hip', 'row_order.hip', 'splat_slice.hip'):
         h.update(open(os.path.join(ROOT, 'hplflownet_amd', 'csrc', f), 'rb').read())
-    for k in ('HPL_MATH', 'HPL_SPLIT3_EPILOGUE', 'HPL_GCONV_EPILOGUE'):
+    for k in ('HPL_MATH', 'HPL_SPLIT3_EPILOGUE', 'HPL_GCONV_EPILOGUE', 'HPL_RANGE_GUARD'):
         h.update(('%s=%s;' % (k, os.environ.get(k, ''))).encode())
     return h.hexdigest()
 
@@ -943,7 +943,7 @@ def main():
             del fixed
 
         # what the board draws while the loop runs (rocm-smi on rank 0's GPU, sampled from a thread during >= 3 s of the same
-        # loop on every rank): the wide launches are bound by the clock the chip sustains under matrix load, DESIGN.md 4.8
+        # loop on every rank): the wide launches are bound by the clock the chip sustains under matrix load, DESIGN_HISTORY.md 4.8
         power = None
         if overlap and not a.train and not os.environ.get('HPL_BENCH_NO_POWER'):
             per = max(elapsed / a.steps, 1e-4)
@@ -1197,6 +1197,21 @@ def main():
                     roofline['traffic_note'] = 'profiles/pmc_traffic.json ignored: taken with other kernel sources / configuration'
             except Exception:
                 pass
+        # the HBM-bound gathers by their kernel-trace durations inside a forward (profiles/trace_hbm.json, tools/trace_hbm.py: the
+        # forward's buffers are cold, bench's own replay of a launch on one buffer set is not) -- under the stamp rule of the PMC files
+        tpath = os.path.join(ROOT, 'profiles', 'trace_hbm.json')
+        if os.path.exists(tpath) and full and a.points == 8192 and a.data == 'frustum' and not a.train:
+            try:
+                tj = json.load(open(tpath))
+                if tj.get('stamp') == source_stamp():
+                    for nm, e in (tj.get('classes') or {}).items():
+                        kd = kernels.get(nm)
+                        if kd and kd.get('mbytes_per_step') and kd.get('launches_per_step') and e.get('us_per_launch'):
+                            per = kd['mbytes_per_step'] * 1e6 / kd['launches_per_step']
+                            kd['trace_us'] = e['us_per_launch']
+                            kd['trace_frac'] = per / (e['us_per_launch'] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            except Exception:
+                pass
         line = {'metric': 'point-pairs/sec + EPE3D, N=8192 FlyingThings3D, 1/2/4/8 MI355X',
                 'value': world * a.steps / elapsed, 'unit': 'point-pairs/s', 'n_gpus': world, 'steps': a.steps,
                 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True,
@@ -1215,6 +1230,9 @@ def main():
                                                           'count_readbacks_per_pair': 1 if nb.fused else len(sfm), 'staged_fallbacks': nb.fallbacks,
                                                           'vertex_bounds_per_cloud': list(nb.bounds[:len(sfm)]) if nb.fused else None})(gen.native_builder())
                            if (native and not a.python_lattice) else None,
+                           # launches of ALL forwards of this command that took the second (residual) pass of the fp16-pair form's range
+                           # guard (hpl_gconv_desc.a_guard: an operand with a row 2^18 below its largest magnitude); 0 on this workload
+                           'exact_fallback_launches': (plan.guard_trips() if (plan is not None and ops.SPLIT_PLANES == 2 and ops.SPLIT3) else None),
                            'sharding': 'independent pairs per GPU, no data-path collective',
                            'vertices_per_level_pc1': [lv.H[0] for lv in gen.build(*pairs[0]).levels]},
                 'roofline': roofline, 'kernels': kernels,

@@ -44,7 +44,8 @@ class GConvDesc(ctypes.Structure):
                 ('row_perm', c_vp), ('ws', c_vp), ('ws_bytes', c_i64),
                 ('tile_idx', c_vp), ('tile_mask', c_vp), ('tile_bm', c_i32), ('clock_probe', c_vp),
                 ('Y2', c_vp), ('ldy2', c_i64), ('rows2', c_i64), ('Wt3', c_vp), ('wt3_plane_stride', c_i64),
-                ('wt3_planes', c_i32), ('a_amax', c_vp), ('w_amax', c_vp), ('y_amax', c_vp)]
+                ('wt3_planes', c_i32), ('a_amax', c_vp), ('w_amax', c_vp), ('y_amax', c_vp),
+                ('a_guard', c_vp), ('y_guard', c_vp), ('guard_trips', c_vp)]
 
 
 class Ref(ctypes.Structure):
@@ -125,6 +126,7 @@ _SIGNATURES = {
     'hpl_weight_split3_batch': (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp]),
     'hpl_weight_split2h': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
     'hpl_amax': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
+    'hpl_amax_rows': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp]),
     'hpl_gconv_wgrad_scaled': (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_int,
                                               c_vp, c_i64, ctypes.c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'hpl_weight_unlayout': (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_i64,
@@ -169,6 +171,7 @@ _SIGNATURES = {
                                           c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'hpl_plan_set_unlayout': (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64), ctypes.c_int]),
     'hpl_plan_profile': (ctypes.c_int, [c_vp, ctypes.c_int]),
+    'hpl_plan_guard_trips': (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64)]),
     'hpl_plan_clock_probe': (ctypes.c_int, [c_vp, c_vp]),
     'hpl_plan_profile_read': (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(c_f32)]),
 }
@@ -214,6 +217,8 @@ def load_diag():
         lib.hpl_diag_splat_atomic.restype = ctypes.c_int
         lib.hpl_diag_splat_atomic.argtypes = [c_vp, ctypes.c_int64, ctypes.c_int, c_vp, c_vp, ctypes.c_int64, c_vp, ctypes.c_int64, c_vp,
                                               ctypes.c_int64, ctypes.c_int, c_vp]
+        lib.hpl_diag_chain.restype = ctypes.c_int
+        lib.hpl_diag_chain.argtypes = [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp]
         _diag = lib
     return _diag
 

@@ -232,3 +232,80 @@ extern "C" int hpl_diag_splat_atomic(const float *feat, int64_t ldf, int C, cons
     HPL_CHECK_LAUNCH("hpl_diag_splat_atomic");
     return HPL_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Diagnostic (round 6): what a chain of small DEPENDENT steps costs as kernel launches and as phases of ONE persistent launch
+// separated by a grid barrier -- the question behind "one launch for levels 3-6" (DESIGN.md section 9).  A step: workgroup b
+// reads `words` floats that workgroup (b + 1) % grid wrote in the step before (a cross-CU, usually cross-XCD dependency, as a
+// gather over the previous layer's rows is), adds 1, writes its own block.  mode 0: `steps` launches on the stream; mode 1: one
+// launch, a monotonic-counter grid barrier between steps (lane 0: agent release fence -> atomic arrive -> relaxed agent poll ->
+// agent acquire fence; MI355X_MICROARCH.md "barrier-counter"); mode 2: the XCD-hierarchical form of the same guide
+// ("barrier-xcd": per-XCC arrive counters, one leader per XCC on the top counter, per-XCC release generation).
+// ------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void chain_step(const float *__restrict__ in, float *__restrict__ out, int words, int grid) {
+    const int src = ((int)blockIdx.x + 1) % grid;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) out[(size_t)blockIdx.x * words + i] = in[(size_t)src * words + i] + 1.0f;
+}
+__global__ void __launch_bounds__(256) k_chain_step(const float *in, float *out, int words, int grid) { chain_step(in, out, words, grid); }
+
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+
+__global__ void __launch_bounds__(256) k_chain_persistent(float *a, float *b, int words, int steps, unsigned *bar, int mode) {
+    const int grid = gridDim.x;
+    __shared__ unsigned xcc_s;
+    if (threadIdx.x == 0) xcc_s = xcc_id();
+    __syncthreads();
+    const unsigned xcc = xcc_s;
+    // bar[0]: top counter; bar[16 * (1 + x)]: arrivals of XCC x; bar[16 * (9 + x)]: release generation of XCC x; bar[16 * 17 + x]: WGs on XCC x
+    if (mode == 2 && threadIdx.x == 0) atomicAdd(&bar[16 * 17 + xcc], 1u);          // census (before the first barrier: counted below)
+    for (int s = 0; s < steps; ++s) {
+        chain_step(s & 1 ? b : a, s & 1 ? a : b, words, grid);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (mode == 1) {
+                atomicAdd(&bar[0], 1u);
+                const unsigned want = (unsigned)(s + 1) * (unsigned)grid;
+                while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+            } else {
+                // step 0 doubles as the census barrier: every workgroup has registered on its XCC before anybody leaves it
+                if (s == 0) {
+                    atomicAdd(&bar[0], 1u);
+                    while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)grid) __builtin_amdgcn_s_sleep(1);
+                } else {
+                    const unsigned mine = __hip_atomic_load(&bar[16 * 17 + xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned arrived = atomicAdd(&bar[16 * (1 + xcc)], 1u) + 1u;
+                    if (arrived == (unsigned)s * mine) {          // last of this XCC: the leader goes to the top counter
+                        const unsigned top = atomicAdd(&bar[16 * 18], 1u) + 1u;
+                        if (top == (unsigned)s * 8u) {             // last leader (8 XCCs hold workgroups at 256 workgroups): release everybody
+                            for (int x = 0; x < 8; ++x) __hip_atomic_store(&bar[16 * (9 + x)], (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    while (__hip_atomic_load(&bar[16 * (9 + xcc)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)s) __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+extern "C" int hpl_diag_chain(float *a, float *b, int grid, int words, int steps, unsigned *bar, int mode, void *stream) {
+    HPL_REQUIRE(a && b && grid > 0 && grid <= 256 && words > 0 && steps > 0 && (mode == 0 || bar));
+    hipStream_t s = to_stream(stream);
+    if (mode == 0) {
+        for (int i = 0; i < steps; ++i) k_chain_step<<<grid, 256, 0, s>>>(i & 1 ? b : a, i & 1 ? a : b, words, grid);
+    } else {
+        if (hipMemsetAsync(bar, 0, 4 * 16 * 20, s) != hipSuccess) return -2;
+        k_chain_persistent<<<grid, 256, 0, s>>>(a, b, words, steps, bar, mode);
+    }
+    HPL_CHECK_LAUNCH("hpl_diag_chain");
+    return HPL_OK;
+}

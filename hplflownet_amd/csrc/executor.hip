@@ -20,8 +20,9 @@ namespace {
 constexpr int64_t SPLITK_ELEMS = 8 << 20;          // ops.py: split-K only for outputs of <= 8 M elements
 constexpr int64_t SPLITK_WS_BYTES = 64ll << 20;    // 16 M floats of partial tiles (a launch fits its split count to it)
 // behind it: the largest magnitudes of the matrices the wide (fp16-pair) launches of a run read, one scalar per reduction
+// (round 6: a slot is TWO words -- the largest magnitude and the range-guard word of the same view, hpl_gconv_desc.a_guard)
 constexpr int AMAX_SLOTS = 4096;
-constexpr int64_t HEAD_BYTES = SPLITK_WS_BYTES + AMAX_SLOTS * 4;
+constexpr int64_t HEAD_BYTES = SPLITK_WS_BYTES + AMAX_SLOTS * 8;
 constexpr int MAX_SYMS = HPL_SYM_LEVEL0 + 8 * HPL_MAX_LEVELS;
 
 __global__ void k_copy_cols(const float *__restrict__ src, int64_t lds, float *__restrict__ dst, int64_t ldd,
@@ -72,6 +73,13 @@ __global__ void k_copy_emg_batch(const EmgJobs j) {
     }
 }
 
+// HPL_RANGE_GUARD=0: the fp16-pair launches of a plan run without their range guard (hpl_gconv_desc.a_guard: no guard words, no
+// second launches) -- the round-5 behaviour, for A/B runs
+inline bool range_guard() {
+    static const bool on = [] { const char *e = getenv("HPL_RANGE_GUARD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 struct View {                 // a resolved hpl_ref
     float *p;
     int64_t ld;
@@ -106,6 +114,7 @@ struct hpl_plan {
     struct AmaxEnt { int buf; int64_t row_off, rows; int col_off, cols; const float *slot; };
     std::vector<AmaxEnt> amax;
     int amax_used = 0;
+    int32_t *guard_trips = nullptr;         // device counter: launches that took the range guard's second pass (allocated at the first run)
     // workspace layout of the last run (a function of the plan and the row-count symbols): byte offset of every buffer
     std::vector<int64_t> lay_sym, lay_off;
     int64_t lay_total = 0;
@@ -165,8 +174,8 @@ struct Runner {
         for (const auto &e : pl.amax)
             if (e.buf == r.buf && e.row_off == off && e.rows == rows && e.col_off == r.col_off && e.cols == cols) { slot = e.slot; return HPL_OK; }
         HPL_REQUIRE(pl.amax_used < AMAX_SLOTS, "hpl_plan_run: more than %d operand reductions in one run", AMAX_SLOTS);
-        float *dst = amax_base + pl.amax_used++;
-        const int rc = hpl_gc::amax_launch(v.p, v.ld, rows, cols, dst, main_s);
+        float *dst = amax_base + 2 * pl.amax_used++;
+        const int rc = hpl_gc::amax_launch(v.p, v.ld, rows, cols, dst, main_s, range_guard() ? reinterpret_cast<unsigned *>(dst + 1) : nullptr);
         if (rc) return rc;
         if (r.buf >= 0) pl.amax.push_back({r.buf, off, rows, r.col_off, cols, dst});
         slot = dst;
@@ -187,7 +196,7 @@ struct Runner {
         pl.amax.push_back({op.out.buf, symv(sym, op.out.row_off_sym), symv(sym, op.m_sym), op.out.col_off, op.N, cur_y_amax});
         cur_y_amax = nullptr;
     }
-    float *amax_slot() { return pl.amax_used < AMAX_SLOTS ? amax_base + pl.amax_used++ : nullptr; }
+    float *amax_slot() { return pl.amax_used < AMAX_SLOTS ? amax_base + 2 * pl.amax_used++ : nullptr; }
     // wide launches in the fp16-pair mode scale their operands by their largest magnitudes: reduce them (main stream, before a
     // side-stream op is fenced) for the ops that can qualify (gconv_common.h split3_maybe / wgrad3.hip's test)
     int prepare_amax(const hpl_op &op, bool side) {
@@ -367,7 +376,7 @@ struct Runner {
             }
             d.Y = Y.p; d.ldy = Y.ld;
             if (last && has_out2) { d.Y2 = Y2.p; d.ldy2 = Y2.ld; d.rows2 = rows2; }
-            if (last && cur_y_amax && !scatter) d.y_amax = cur_y_amax;
+            if (last && cur_y_amax && !scatter) { d.y_amax = cur_y_amax; if (range_guard()) d.y_guard = reinterpret_cast<uint32_t *>(cur_y_amax + 1); }
             d.row_perm = row_perm;
             if (row_perm && ti && tm) { d.tile_idx = ti; d.tile_mask = tm; d.tile_bm = ngroups >= 2 ? t.group_tile_bm : t.tile_bm; }
             // split-operand image of the same rows (csrc/gconv3.hip takes the launch if it qualifies): k-blocks of 8 rows
@@ -376,6 +385,7 @@ struct Runner {
                 d.wt3_plane_stride = w.wt3_plane_stride;
                 d.wt3_planes = w.wt3_planes;
                 d.a_amax = cur_a_amax; d.w_amax = w.w_amax;
+                if (cur_a_amax && range_guard()) { d.a_guard = reinterpret_cast<const uint32_t *>(cur_a_amax + 1); d.guard_trips = pl.guard_trips; }
             }
             if (prof) d.clock_probe = pl.clock_probe;
             if (scatter) { d.scat = t.corr2; d.scat_stride = 15 * t.H0; d.scat_c = op.aux; }
@@ -638,6 +648,7 @@ extern "C" void hpl_plan_destroy(hpl_plan *plan) {
     if (!plan) return;
     for (hipEvent_t e : plan->pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : plan->fence) (void)hipEventDestroy(e);
+    if (plan->guard_trips) (void)hipFree(plan->guard_trips);
     delete plan;
 }
 
@@ -748,10 +759,16 @@ extern "C" int hpl_plan_run_range(hpl_plan *plan, const hpl_level_tables *levels
     r.side_s = side_stream ? to_stream(side_stream) : nullptr;
     r.amax_base = reinterpret_cast<float *>(w + SPLITK_WS_BYTES);
     plan->fence_used = 0;
+    if (!plan->guard_trips && hpl_gc::split_planes() == 2) {
+        if (hipMalloc(reinterpret_cast<void **>(&plan->guard_trips), 4) != hipSuccess || hipMemsetAsync(plan->guard_trips, 0, 4, r.main_s) != hipSuccess) {
+            set_error("hpl_plan_run: allocating the range-guard counter failed");
+            return HPL_EHIP;
+        }
+    }
     if (op_begin == 0) {          // a new pair: nothing reduced yet
         plan->amax.clear();
         plan->amax_used = 0;
-        if (hpl_gc::split_planes() == 2 && hipMemsetAsync(r.amax_base, 0, AMAX_SLOTS * 4, r.main_s) != hipSuccess) { set_error("hpl_plan_run: hipMemsetAsync failed"); return HPL_EHIP; }
+        if (hpl_gc::split_planes() == 2 && hipMemsetAsync(r.amax_base, 0, AMAX_SLOTS * 8, r.main_s) != hipSuccess) { set_error("hpl_plan_run: hipMemsetAsync failed"); return HPL_EHIP; }
     }
     auto active = [&](const hpl_op &op, bool &run) -> int {
         run = true;
@@ -820,6 +837,16 @@ extern "C" int hpl_plan_run_range(hpl_plan *plan, const hpl_level_tables *levels
     if (!join) return HPL_OK;
     r.side_busy = r.side_s != nullptr;         // (earlier ranges of the same step may have left work there)
     return r.join();
+}
+
+extern "C" int hpl_plan_guard_trips(hpl_plan *plan, int64_t *count) {
+    HPL_REQUIRE(plan && count, "hpl_plan_guard_trips: null argument");
+    *count = 0;
+    if (!plan->guard_trips) return HPL_OK;
+    int32_t v = 0;
+    if (hipMemcpy(&v, plan->guard_trips, 4, hipMemcpyDeviceToHost) != hipSuccess) { set_error("hpl_plan_guard_trips: read-back failed"); return HPL_EHIP; }
+    *count = v;
+    return HPL_OK;
 }
 
 extern "C" int hpl_plan_profile(hpl_plan *plan, int tag) {

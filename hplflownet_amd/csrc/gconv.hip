@@ -493,7 +493,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
 }
 
 // split-K epilogue: Y = act(bias + res + sum_s partial[s]) in fixed split order
+// (a split-K launch of the pair form whose range guard tripped left a second set of partial tiles -- the residual pass -- behind the first)
 __global__ void k_gconv_finish(const GParams p) {
+    const int nsp = (p.guard_partials && guard_tripped(p.a_amax, p.a_guard)) ? 2 * p.splits : p.splits;
     const int64_t total = p.M * p.N;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -501,7 +503,7 @@ __global__ void k_gconv_finish(const GParams p) {
         const int64_t m = i / p.N;
         const int n = (int)(i - m * p.N);
         float acc = 0.f;
-        for (int sidx = 0; sidx < p.splits; ++sidx) acc += p.partial[(int64_t)sidx * total + i];
+        for (int sidx = 0; sidx < nsp; ++sidx) acc += p.partial[(int64_t)sidx * total + i];
         float v = acc + (p.bias ? p.bias[n] : 0.f);
         if (p.res) v += p.res[(m % p.res_mod) * p.ldres + n];
         if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
@@ -516,10 +518,11 @@ __global__ void __launch_bounds__(256) k_gconv_finish4(const GParams p) {
     const unsigned N4 = (unsigned)p.N / 4u, total4 = (unsigned)p.M * N4;
     const int64_t total = p.M * p.N;
     const unsigned res_mod = (unsigned)p.res_mod;
+    const int nsp = (p.guard_partials && guard_tripped(p.a_amax, p.a_guard)) ? 2 * p.splits : p.splits;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
         const unsigned m = i / N4, n = (i - m * N4) * 4u;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sidx = 0; sidx < p.splits; ++sidx) {
+        for (int sidx = 0; sidx < nsp; ++sidx) {
             const float4 v = *reinterpret_cast<const float4 *>(p.partial + (int64_t)sidx * total + (int64_t)i * 4);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
@@ -612,6 +615,7 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     HPL_REQUIRE(!d->Wt3 || d->wt3_planes == 0 || d->wt3_planes == 2 || d->wt3_planes == 3, "%s: wt3_planes = %d", who, d->wt3_planes);
     if (p.planes == 2 && !(p.a_amax && p.w_amax)) p.Wt3 = nullptr;      // fp16 pairs need both scales: the launch stays on the fp32 MFMA
     p.y_amax = d->y_amax; p.y_amax_done = 0;
+    p.a_guard = d->a_guard; p.y_guard = d->y_guard; p.guard_trips = d->guard_trips; p.guard_partials = 0;
     HPL_REQUIRE(!(d->y_amax && d->scat), "%s: y_amax with a scatter epilogue", who);
     p.col_share = 0; p.col_rows = 0;
     p.tiles_m = p.tiles_n = 0;
@@ -730,7 +734,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     if (avec && p.Wt3 && launch_split3(p, s)) {
         if (p.splits > 1) launch_finish(p, s);       // (mid-size stencils: partial tiles over slice ranges, summed in fixed order)
         HPL_CHECK_LAUNCH("hpl_gconv_forward");
-        if (p.y_amax && !p.y_amax_done) return amax_launch(p.Y, p.ldy, p.M, p.N, p.y_amax, s);
+        if (p.y_amax && !p.y_amax_done) return amax_launch(p.Y, p.ldy, p.M, p.N, p.y_amax, s, p.y_guard);
         return HPL_OK;
     }
     // Tile selection.
@@ -752,7 +756,7 @@ extern "C" int hpl_gconv_forward(const hpl_gconv_desc *d, hplStream stream) {
     }
     if (p.splits > 1) launch_finish(p, s);
     HPL_CHECK_LAUNCH("hpl_gconv_forward");
-    if (p.y_amax) return amax_launch(p.Y, p.ldy, p.M, p.N, p.y_amax, s);
+    if (p.y_amax) return amax_launch(p.Y, p.ldy, p.M, p.N, p.y_amax, s, p.y_guard);
     return HPL_OK;
 }
 

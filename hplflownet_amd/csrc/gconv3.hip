@@ -48,7 +48,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // (Diagnostic builds of rounds 3-4 -- per-phase cycle stamps, per-workgroup residence records, the one-barrier form of the 8-wave
 // tile -- produced profiles/r03s_phase_probe.txt, r03s_variants_ab.txt, r04b_split3_pp3_ab.txt, r04h_tile_balance.txt and were removed
-// in round 5; DESIGN.md 4.1 / 4.8 quote their results.)
+// in round 5; DESIGN_HISTORY.md 4.1 / 4.8 quote their results.)
 
 namespace {
 
@@ -76,13 +76,43 @@ __device__ __forceinline__ void split2h(float x0, float x1, float s, unsigned &h
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
+// Second pass of the range guard (hpl_gconv_desc.a_guard): the residual of the first split, r = (x s - hi) - lo (both subtractions
+// exact in fp32), times 2^24, again as an fp16 pair.  |x s - hi| <= 2^3 and |r| <= 2^-9 for |x s| < 2^15, so r 2^24 <= 2^15 fits fp16;
+// for an element too small for a normal lo (|x s| < 2^-3) r is what the first pass lost: it is carried here to 2^-24 of ITS size.
+__device__ __forceinline__ void split2h_resid(float x0, float x1, float s, unsigned &h, unsigned &l) {
+    const float2_t v = {x0 * s, x1 * s};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);
+    const float2_t hf = __builtin_convertvector(hh, float2_t);
+    const float2_t r = {v.x - hf.x, v.y - hf.y};
+    const f16x2 ll = __builtin_convertvector(r, f16x2);
+    const float2_t lf = __builtin_convertvector(ll, float2_t);
+    constexpr float K = (float)(1 << RESID_SHIFT);
+    const float2_t r2 = {(r.x - lf.x) * K, (r.y - lf.y) * K};
+    const f16x2 h2 = __builtin_convertvector(r2, f16x2);
+    h = __builtin_bit_cast(unsigned, h2);
+    const float2_t h2f = __builtin_convertvector(h2, float2_t);
+    const float2_t q = {r2.x - h2f.x, r2.y - h2f.y};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(q, f16x2));
+}
+
 constexpr int BM3 = 128;
 
 // NB = stages of the weight-fragment ring (3 or 4); the gathered rows use NB - 1 register sets: with NB = 4 every load has one
 // more half-step to land (the end-of-half-step wait then leaves the loads of TWO half-steps in flight)
-template <int WGN, int F_LDS, int NB, int PL>
+// GUARD (PL = 2): the SECOND launch of a guarded operand (hpl_gconv_desc.a_guard).  The first launch (GUARD = false) is the round-5
+// kernel; if the operand's guard trips (a row 2^18 below the matrix's largest magnitude) its epilogue stores the sums WITHOUT the
+// activation (and publishes no magnitudes, writes no second destination).  The second launch leaves at once unless the guard trips;
+// then it runs the same slice lists on the residuals of the first split, (a s - hi - lo) 2^24 as fp16 pairs, adds what the first
+// launch stored (the host passes res = Y, no bias) and finishes: activation, second destination, magnitudes.  Keeping the second
+// pass out of the first kernel keeps that kernel's code (15.5 k instructions) and registers what they were: with both passes in one
+// kernel (24.4 k instructions) the unguarded launches ran 4-10 % slower (profiles/r06b_split3_guard_in_kernel.txt).
+template <int WGN, int F_LDS, int NB, int PL, bool GUARD = false>
 __device__ __forceinline__ void gconv3_body(const GParams &p) {
     static_assert(PL == 2 || PL == 3, "operand planes: 2 (fp16 pairs) or 3 (bf16 triples)");
+    static_assert(!GUARD || PL == 2, "the range guard belongs to the fp16-pair form");
+    bool tripped = false;
+    if constexpr (PL == 2) tripped = guard_tripped(p.a_amax, p.a_guard);      // (uniform)
+    if constexpr (GUARD) { if (!tripped) return; }
     constexpr int BM = BM3, BN = 64 * WGN, NT = 128 * WGN;
     // Gathered loads: a thread's pass p fetches float4 column (t & 3) of HALF p & 1 of tile row t / 4 + (p / 2) * ROWS_PP: four
     // lanes = the 64 bytes a row contributes to a half-slice.  (Eight lanes per full 128-byte line would give every thread one
@@ -306,6 +336,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     if constexpr (PL == 2) {
         s_a = split_scale(p.a_amax[0]);
         s_out = split_unscale(s_a);
+        if constexpr (GUARD) s_out *= 1.0f / (float)(1 << RESID_SHIFT);
         s_out2 = split_unscale(split_scale(p.w_amax[0]));
     }
     auto store_a = [&](auto set_tag, int h, int st, int j) {
@@ -315,8 +346,13 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         unsigned char *base = smem + st * A_STAGE + (kb_w * BM + a_slot(row, kb_w)) * 16 + (t & 1) * 8;
         if constexpr (PL == 2) {
             unsigned h0, l0, h1, l1;
-            split2h(v.x, v.y, s_a, h0, l0);
-            split2h(v.z, v.w, s_a, h1, l1);
+            if constexpr (GUARD) {
+                split2h_resid(v.x, v.y, s_a, h0, l0);
+                split2h_resid(v.z, v.w, s_a, h1, l1);
+            } else {
+                split2h(v.x, v.y, s_a, h0, l0);
+                split2h(v.z, v.w, s_a, h1, l1);
+            }
             *reinterpret_cast<u32x2 *>(base) = u32x2{h0, h1};
             *reinterpret_cast<u32x2 *>(base + 2 * BM * 16) = u32x2{l0, l1};
         } else {
@@ -625,6 +661,10 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * s_out * s_out2;
     }
+    if constexpr (GUARD) {
+        if (p.guard_trips && t == 0 && tile_m == 0 && tile_n == 0 && split == 0) atomicAdd(p.guard_trips, 1);
+    }
+    const bool defer = !GUARD && tripped;       // the second launch finishes this tile: store the sums, nothing else
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Measured: with 64-bit addresses, an LDS read of the output row and (second tap-group pass) a load -> add -> store chain
@@ -644,6 +684,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         const unsigned ldy_b = (unsigned)(p.splits > 1 ? p.N : p.ldy) * 4u, ldr_b = (unsigned)p.ldres * 4u, ldy2_b = (unsigned)p.ldy2 * 4u;
         const bool plain = p.splits <= 1;
         unsigned ymax = 0;                                   // largest |y| this lane stores (p.y_amax)
+        unsigned gmin = 0xffffffffu;                         // smallest non-zero row maximum over the 32 columns of a block (p.y_guard)
+        const bool want_guard = p.y_guard && p.y_amax && plain && !defer;      // (uniform)
         const bool res_wrap = p.res && p.res_mod < p.M;      // (uniform)
         const float res_inv = res_wrap ? 1.0f / (float)p.res_mod : 0.f;
 #pragma unroll
@@ -678,19 +720,31 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                     if (plain) {
                         v = v + bsv;
                         if (p.res) v += rv[r];
-                        if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
+                        if (p.act == HPL_ACT_LEAKY && !defer) v = v > 0.f ? v : p.slope * v;
                     }
                     const unsigned yo = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldy_b) + nb : OOB;
-                    ymax = max(ymax, (mrow[r] >= 0 && n < p.N) ? (__builtin_bit_cast(unsigned, v) & 0x7fffffffu) : 0u);
+                    const unsigned av = (mrow[r] >= 0 && n < p.N) ? (__builtin_bit_cast(unsigned, v) & 0x7fffffffu) : 0u;
+                    ymax = max(ymax, av);
+                    if (want_guard) {            // the row's maximum over the block's 32 columns (the lanes of this half-wave)
+                        unsigned rm = av;
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) rm = max(rm, (unsigned)__shfl_xor((int)rm, o));
+                        gmin = rm ? min(gmin, rm) : gmin;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (int)yo, 0, 0);
-                    const unsigned y2o = (mrow[r] >= 0 && mrow[r] < (int)p.rows2) ? __umul24((unsigned)mrow[r], ldy2_b) + nb : OOB;
+                    const unsigned y2o = (mrow[r] >= 0 && mrow[r] < (int)p.rows2 && !defer) ? __umul24((unsigned)mrow[r], ldy2_b) + nb : OOB;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y2, (int)y2o, 0, 0);
                 }
             }
-        if (p.y_amax && plain) {
+        if (p.y_amax && plain && !defer) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ymax = max(ymax, (unsigned)__shfl_xor((int)ymax, o));
             if (lane == 0) amax_publish(reinterpret_cast<unsigned *>(p.y_amax), ymax);
+            if (want_guard) {           // ~bits order the other way round: the largest ~maximum is the smallest row maximum
+                unsigned inv = gmin == 0xffffffffu ? 0u : ~gmin;
+                inv = max(inv, (unsigned)__shfl_xor((int)inv, 32));
+                if (lane == 0) amax_publish(p.y_guard, inv);
+            }
         }
     } else
 #pragma unroll
@@ -711,9 +765,9 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                 }
                 float v = acc[i][j][r] + bsv;
                 if (p.res) v += p.res[(int64_t)((int)m < res_mod ? (int)m : (int)m % res_mod) * p.ldres + n];
-                if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
+                if (p.act == HPL_ACT_LEAKY && !defer) v = v > 0.f ? v : p.slope * v;
                 p.Y[m * p.ldy + n] = v;
-                if (p.Y2 && m < p.rows2) p.Y2[m * p.ldy2 + n] = v;
+                if (p.Y2 && m < p.rows2 && !defer) p.Y2[m * p.ldy2 + n] = v;
             }
         }
     if (probe) {
@@ -724,15 +778,15 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     }
 }
 
-template <int WGN, int F_LDS, int PL, int NB = 3>
+template <int WGN, int F_LDS, int PL, int NB = 3, bool GUARD = false>
 __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
-    gconv3_body<WGN, F_LDS, NB, PL>(p);
+    gconv3_body<WGN, F_LDS, NB, PL, GUARD>(p);
 }
 
 // the 8-wave tile (128 x 256, ping-pong wave rows): one workgroup per CU
-template <int F_LDS, int NB, int PL>
+template <int F_LDS, int NB, int PL, bool GUARD = false>
 __global__ void __launch_bounds__(512, 2) k_gconv3w(const GParams p) {
-    gconv3_body<4, F_LDS, NB, PL>(p);
+    gconv3_body<4, F_LDS, NB, PL, GUARD>(p);
 }
 
 // Wt [k_rows][ldw] fp32 -> three bf16 planes [k_rows/8][ldw][8]
@@ -799,6 +853,53 @@ __global__ void __launch_bounds__(256) k_amax(const float *__restrict__ X, int64
         for (int c = c0; c < colsv; c += tpr) fold(*reinterpret_cast<const V *>(p0 + (int64_t)c * VW));
     }
     amax_reduce(v, slot);
+}
+
+// the same with the range-guard word (hpl_amax_rows): 2^tpr_log <= 64 lanes across a row, so a row's maximum is a shuffle reduction;
+// *guard = max over the rows with a non-zero entry of ~bits(row maximum)
+template <typename V>
+__global__ void __launch_bounds__(256) k_amax_rows(const float *__restrict__ X, int64_t ld, int64_t rows, int colsv, int tpr_log,
+                                                   unsigned *__restrict__ slot, unsigned *__restrict__ guard) {
+    constexpr int VW = sizeof(V) / 4;
+    const int tpr = 1 << tpr_log, c0 = threadIdx.x & (tpr - 1), rpb = 256 >> tpr_log;
+    unsigned v = 0, ginv = 0;
+    auto fold = [&](unsigned &m, const V &x) {
+        const unsigned *e = reinterpret_cast<const unsigned *>(&x);
+#pragma unroll
+        for (int u = 0; u < VW; ++u) m = max(m, e[u] & 0x7fffffffu);
+    };
+    auto row_done = [&](unsigned m) {            // m: this lane's share of a row
+        for (int o = tpr >> 1; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        v = max(v, m);
+        ginv = m ? max(ginv, ~m) : ginv;
+    };
+    const int64_t rstep = (int64_t)gridDim.x * rpb;
+    int64_t r = (int64_t)blockIdx.x * rpb + (threadIdx.x >> tpr_log);
+    const int64_t r_first = r;
+    // (uniform trip counts inside a row's lane group: rows and r are the same for its lanes)
+    for (; r + 3 * rstep < rows; r += 4 * rstep) {
+        const float *p0 = X + r * ld, *p1 = p0 + rstep * ld, *p2 = p1 + rstep * ld, *p3 = p2 + rstep * ld;
+        unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        for (int c = c0; c < colsv; c += tpr) {
+            const V a = *reinterpret_cast<const V *>(p0 + (int64_t)c * VW), b = *reinterpret_cast<const V *>(p1 + (int64_t)c * VW);
+            const V d = *reinterpret_cast<const V *>(p2 + (int64_t)c * VW), f = *reinterpret_cast<const V *>(p3 + (int64_t)c * VW);
+            fold(m0, a); fold(m1, b); fold(m2, d); fold(m3, f);
+        }
+        row_done(m0); row_done(m1); row_done(m2); row_done(m3);
+    }
+    for (; r < rows; r += rstep) {
+        const float *p0 = X + r * ld;
+        unsigned m0 = 0;
+        for (int c = c0; c < colsv; c += tpr) fold(m0, *reinterpret_cast<const V *>(p0 + (int64_t)c * VW));
+        row_done(m0);
+    }
+    (void)r_first;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ginv = max(ginv, (unsigned)__shfl_xor((int)ginv, o));
+    __shared__ unsigned gpart[4];
+    if ((threadIdx.x & 63) == 0) gpart[threadIdx.x >> 6] = ginv;
+    amax_reduce(v, slot);                       // (its barrier orders gpart too)
+    if (threadIdx.x == 0) amax_publish(guard, max(max(gpart[0], gpart[1]), max(gpart[2], gpart[3])));
 }
 
 __global__ void k_amax_clear(const hpl_split3_job *__restrict__ jobs, int njobs) {
@@ -888,11 +989,21 @@ extern "C" int hpl_weight_split3_batch(const hpl_split3_job *jobs, int njobs, in
 }
 
 // *slot (cleared by the caller) = max(*slot, largest magnitude of the block)
-int hpl_gc::amax_launch(const float *X, int64_t ld, int64_t rows, int cols, float *slot, hipStream_t s) {
+int hpl_gc::amax_launch(const float *X, int64_t ld, int64_t rows, int cols, float *slot, hipStream_t s, unsigned *guard) {
     if (rows <= 0) return HPL_OK;
     const bool vec = cols % 4 == 0 && ld % 4 == 0 && aligned16(X);
     int cv = vec ? cols / 4 : cols;
     int64_t nrows = rows;
+    if (guard) {            // row maxima: the rows stay rows, <= 64 lanes across one
+        int tl = 0;
+        while ((1 << tl) < cv && tl < 6) ++tl;
+        const int rpb = 256 >> tl;
+        const int grid = (int)imax(1, imin(cdiv(nrows, (int64_t)rpb * 4), 1024));
+        if (vec) k_amax_rows<float4><<<grid, 256, 0, s>>>(X, ld, nrows, cv, tl, reinterpret_cast<unsigned *>(slot), guard);
+        else k_amax_rows<float><<<grid, 256, 0, s>>>(X, ld, nrows, cv, tl, reinterpret_cast<unsigned *>(slot), guard);
+        HPL_CHECK_LAUNCH("hpl_amax_rows");
+        return HPL_OK;
+    }
     if (ld == cols && (int64_t)rows * cv >= 256) {          // contiguous: any row length will do -- 256 lanes across a "row"
         const int64_t total = rows * cv;
         int w = 256;
@@ -914,6 +1025,13 @@ extern "C" int hpl_amax(const float *X, int64_t ld, int64_t rows, int32_t cols, 
     hipStream_t s = to_stream(stream);
     if (hipMemsetAsync(slot, 0, 4, s) != hipSuccess) { set_error("hpl_amax: hipMemsetAsync failed"); return HPL_EHIP; }
     return amax_launch(X, ld, rows, cols, slot, s);
+}
+
+extern "C" int hpl_amax_rows(const float *X, int64_t ld, int64_t rows, int32_t cols, float *slot, uint32_t *guard, hplStream stream) {
+    HPL_REQUIRE(X && slot && guard && rows >= 0 && cols > 0 && ld >= cols, "hpl_amax_rows: bad arguments (rows=%lld cols=%d ld=%lld)", (long long)rows, cols, (long long)ld);
+    hipStream_t s = to_stream(stream);
+    if (hipMemsetAsync(slot, 0, 4, s) != hipSuccess || hipMemsetAsync(guard, 0, 4, s) != hipSuccess) { set_error("hpl_amax_rows: hipMemsetAsync failed"); return HPL_EHIP; }
+    return amax_launch(X, ld, rows, cols, slot, s, guard);
 }
 
 extern "C" int hpl_weight_split2h(const float *Wt, int64_t k_rows, int64_t ldw, void *dst, int64_t plane_stride, float *amax,
@@ -982,7 +1100,8 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
         const int64_t tiles = tiles256;
         const int nk_all = (p.K + BK - 1) / BK;
         splitk = (int)imin(imin(8, 256 / imax(1, tiles)), nk_all / 16);
-        if (!mid_split || !p.ws || p.scat || splitk < 2 || (int64_t)splitk * p.M * p.N * 4 > p.ws_bytes || p.N % 256 > 0) return false;
+        const int sets = (p.planes == 2 && p.a_guard) ? 2 : 1;       // (a guarded launch may add a second set of partial tiles)
+        if (!mid_split || !p.ws || p.scat || splitk < 2 || (int64_t)sets * splitk * p.M * p.N * 4 > p.ws_bytes || p.N % 256 > 0) return false;
     }
     p.tiles_m = (int)cdiv(p.M, BM3);
     // 128 x 256 tiles (8 waves, one workgroup per CU) where N allows: 5-12 % faster than 128 x 128 on every wide launch of
@@ -1042,6 +1161,22 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
             if (p.F == 1) k_gconv3<2, 1, 2><<<grid, 256, 0, s>>>(p);
             else if (p.F <= 8) k_gconv3<2, 8, 2><<<grid, 256, 0, s>>>(p);
             else k_gconv3<2, 15, 2><<<grid, 256, 0, s>>>(p);
+        }
+        if (p.a_guard) {
+            // the guard's second launch: the same tiles on the residuals; it adds what the first launch stored and finishes.
+            // (It leaves at once when the operand has no quiet row: an empty launch of this grid, 2-3 us.)
+            GParams q = p;
+            if (p.splits > 1) { q.partial = p.partial + (int64_t)p.splits * p.M * p.N; p.guard_partials = 1; }      // a second set of partial tiles (k_gconv_finish adds both)
+            else { q.res = p.Y; q.ldres = p.ldy; q.res_mod = p.M; q.bias = nullptr; }
+            if (bn256) {
+                if (p.F == 1) k_gconv3w<1, 4, 2, true><<<grid, 512, 0, s>>>(q);
+                else if (p.F <= 8) k_gconv3w<8, 4, 2, true><<<grid, 512, 0, s>>>(q);
+                else k_gconv3w<15, 4, 2, true><<<grid, 512, 0, s>>>(q);
+            } else {
+                if (p.F == 1) k_gconv3<2, 1, 2, 3, true><<<grid, 256, 0, s>>>(q);
+                else if (p.F <= 8) k_gconv3<2, 8, 2, 3, true><<<grid, 256, 0, s>>>(q);
+                else k_gconv3<2, 15, 2, 3, true><<<grid, 256, 0, s>>>(q);
+            }
         }
     } else if (bn256) {
         if (p.F == 1) k_gconv3w<1, 4, 3><<<grid, 512, 0, s>>>(p);

@@ -79,6 +79,8 @@ struct GParams {
     int planes;                         // 3: bf16 triples; 2: fp16 pairs, with the largest magnitudes of A / of the weight image:
     const float *a_amax; const float *w_amax;      //   DEVICE scalars (hpl_amax; hpl_weight_split2h)
     float *y_amax; int y_amax_done;     // optional: largest |Y| stored -> *y_amax (done = 1: the kernel's epilogue did it)
+    const unsigned *a_guard; unsigned *y_guard; int *guard_trips;      // range guard of the pair form (hpl_gconv_desc.a_guard ...)
+    int guard_partials;                 // split-K launch with a guarded operand: a tripped guard leaves a SECOND set of `splits` partial tiles
     int epi_fast;                       // 32-bit buffer addressing in the epilogue (set by the launch functions)
 };
 
@@ -182,7 +184,21 @@ bool split3_enabled();
 // operand planes of the split kernels: 2 = fp16 pairs (default), 3 = bf16 triples (HPL_MATH=bf16x3), 0 = HPL_MATH=f32
 int split_planes();
 // *slot = max(*slot, largest magnitude of X[0 .. rows)[0 .. cols)) (gconv3.hip; the caller cleared the slot)
-int amax_launch(const float *X, int64_t ld, int64_t rows, int cols, float *slot, hipStream_t s);
+// guard (optional, cleared by the caller): the range-guard word of X (hpl_amax_rows)
+int amax_launch(const float *X, int64_t ld, int64_t rows, int cols, float *slot, hipStream_t s, unsigned *guard = nullptr);
+// the pair form's range guard: a second launch over the residuals when the largest magnitude and the smallest non-zero row maximum
+// are >= 2^18 apart (GParams.a_guard: ~bits of that row maximum, 0 = unknown)
+constexpr int GUARD_GAP = 18;
+__device__ __forceinline__ bool guard_tripped(const float *a_amax, const unsigned *a_guard) {
+    if (!a_guard || !a_amax) return false;
+    unsigned am;
+    const float amf = a_amax[0];
+    __builtin_memcpy(&am, &amf, 4);
+    const unsigned g = a_guard[0];
+    const unsigned rmin = g ? ~g : am;
+    return (am >> 23) >= (rmin >> 23) + (unsigned)GUARD_GAP && (am >> 23) < 255u;
+}
+constexpr int RESID_SHIFT = 24;          // residual scale 2^24: (a s - hi - lo) 2^24 < 2^15.01 for every a s < 2^15
 // the cheap part of launch_split3's test (the callers decide with it whether to compute the largest magnitude of A)
 inline bool split3_maybe(int64_t M, int C, int F, int N) { return C >= 32 && N >= 256 && M >= 1024 && F <= 15; }
 

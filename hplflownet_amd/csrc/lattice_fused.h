@@ -51,8 +51,10 @@ struct Level {
     int32_t *keys[2];
     float *bary[2];
     int32_t *off[2], *vk[2];
-    int64_t *tkeys[2];
-    int32_t *tfirst[2], *tid[2], *slot[2], *bsum[2];
+    // open-addressing table of a cloud: 16-byte slots {packed key (two words), first entry that named it, vertex id} -- a probe is
+    // ONE 16-byte load (round 6; rounds 4-5: three arrays, two dependent-free loads per probe and slot)
+    int4 *tslot[2];
+    int32_t *slot[2], *bsum[2];
     int32_t *blur, *corr2;
     int32_t *cnt, *cursor, *csum, *ent, *csr_ptr, *csr_pt;
     float *csr_w, *norm;

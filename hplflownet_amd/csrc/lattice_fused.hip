@@ -22,6 +22,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 using namespace hpl;
 using namespace hpl::lat;
 using namespace hpl::fused;
@@ -52,6 +54,8 @@ struct Off15 {
 __device__ __forceinline__ int npts(const Level &L, int c) { return L.prev_dims ? L.prev_dims[D_H0 + c] : L.n_host[c]; }
 __device__ __forceinline__ int dev_pow2(int x) { int p = 64; while (p < x) p <<= 1; return p; }
 __device__ __forceinline__ int dcdiv(int a, int b) { return (a + b - 1) / b; }
+// hash slot {key lo, key hi, first, id}
+__device__ __forceinline__ int64_t slot_key(const int4 &s) { return (int64_t)(((uint64_t)(uint32_t)s.y << 32) | (uint32_t)s.x); }
 
 // rows of a sort job for this pair, 0 if the job does not run (the same rules as lattice_builder.hip level_tail)
 __device__ __forceinline__ int job_rows(const Level &L, const SortJob &J) {
@@ -149,9 +153,8 @@ __device__ void task_keys(const Level &L, int b, int nblk, const Elev &E, int *s
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int cap = dev_pow2(8 * (c ? n1 : n0));
-        int64_t *tk = L.tkeys[c];
-        int32_t *tf = L.tfirst[c];
-        for (int i = t0; i < cap; i += nth) { tk[i] = EMPTY; tf[i] = INT_MAX; }
+        int4 *ts = L.tslot[c];
+        for (int i = t0; i < cap; i += nth) ts[i] = make_int4(-1, -1, INT_MAX, -1);          // (EMPTY key, no first entry, no id)
     }
     const int ne = 4 * (n0 + n1);
     for (int i = t0; i <= ne; i += nth) { L.cnt[i] = 0; L.cursor[i] = 0; }
@@ -176,7 +179,7 @@ __device__ void task_insert(const Level &L, int b, int nblk) {
         const int c = i >= 4 * n0 ? 1 : 0;
         const int j = c ? i - 4 * n0 : i, n = c ? n1 : n0;
         const int32_t *__restrict__ keys = L.keys[c];
-        int64_t *__restrict__ tkeys = L.tkeys[c];
+        int4 *__restrict__ ts = L.tslot[c];
         const uint64_t mask = c ? mask1 : mask0;
         const int p = j >> 2, r = j & 3;
         int k[4];
@@ -185,12 +188,12 @@ __device__ void task_insert(const Level &L, int b, int nblk) {
         const unsigned long long packed = (unsigned long long)pack_key(k, mm);
         uint64_t sl = mix64(packed) & mask;
         while (true) {
-            const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&tkeys[sl]),
+            const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&ts[sl]),
                                                       (unsigned long long)EMPTY, packed);
             if (prev == (unsigned long long)EMPTY || prev == packed) break;
             sl = (sl + 1) & mask;
         }
-        atomicMin(&L.tfirst[c][sl], j);
+        atomicMin(&reinterpret_cast<int32_t *>(&ts[sl])[2], j);
         L.slot[c][j] = (int)sl;
     }
 }
@@ -206,12 +209,12 @@ __device__ void task_flags(const Level &L, int b, int nblk, int *scr) {
         const int c = q >= ch0 ? 1 : 0;
         const int qc = c ? q - ch0 : q, E = 4 * (c ? n1 : n0);
         const int32_t *__restrict__ slot = L.slot[c];
-        const int32_t *__restrict__ tfirst = L.tfirst[c];
+        const int4 *__restrict__ ts = L.tslot[c];
         int cnt = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int j = qc * SCAN_CHUNK + threadIdx.x * 4 + k;
-            cnt += (j < E && tfirst[slot[j]] == j) ? 1 : 0;
+            cnt += (j < E && reinterpret_cast<const int32_t *>(&ts[slot[j]])[2] == j) ? 1 : 0;
         }
         const int tot = block_sum(cnt, scr);
         if (threadIdx.x == 0) L.bsum[c][qc] = tot;
@@ -225,7 +228,7 @@ __device__ void task_ids(const Level &L, int b, int nblk, int *scr) {
         const int c = q >= ch0 ? 1 : 0;
         const int qc = c ? q - ch0 : q, n = c ? n1 : n0, E = 4 * n, nch = c ? ch1 : ch0;
         const int32_t *__restrict__ slot = L.slot[c];
-        const int32_t *__restrict__ tfirst = L.tfirst[c];
+        int4 *__restrict__ ts = L.tslot[c];
         const int32_t *__restrict__ keys = L.keys[c];
         int part = 0;
         for (int i = threadIdx.x; i < qc; i += 256) part += L.bsum[c][i];
@@ -235,7 +238,7 @@ __device__ void task_ids(const Level &L, int b, int nblk, int *scr) {
         for (int k = 0; k < 4; ++k) {
             const int j = qc * SCAN_CHUNK + threadIdx.x * 4 + k;
             sl[k] = j < E ? slot[j] : 0;
-            fl[k] = (j < E && tfirst[sl[k]] == j) ? 1 : 0;
+            fl[k] = (j < E && reinterpret_cast<const int32_t *>(&ts[sl[k]])[2] == j) ? 1 : 0;
             s += fl[k];
         }
         int tot;
@@ -247,7 +250,7 @@ __device__ void task_ids(const Level &L, int b, int nblk, int *scr) {
             if (!fl[k]) continue;
             if (id < Hb) {
                 const int j = qc * SCAN_CHUNK + threadIdx.x * 4 + k;
-                L.tid[c][sl[k]] = id;
+                reinterpret_cast<int32_t *>(&ts[sl[k]])[3] = id;
                 const int p = j >> 2, r = j & 3;
 #pragma unroll
                 for (int x = 0; x < 4; ++x) L.vk[c][x * vs + id] = keys[((int64_t)x * n + p) * 4 + r];
@@ -270,7 +273,7 @@ __device__ void task_off(const Level &L, int b, int nblk) {
     for (int i = b * 256 + threadIdx.x; i < 4 * (n0 + n1); i += nth) {
         const int c = i >= 4 * n0 ? 1 : 0;
         const int j = c ? i - 4 * n0 : i, n = c ? n1 : n0;
-        const int v = L.tid[c][L.slot[c][j]];
+        const int v = reinterpret_cast<const int32_t *>(&L.tslot[c][L.slot[c][j]])[3];
         L.off[c][(j & 3) * n + (j >> 2)] = v;
         atomicAdd(&L.cnt[v + (c ? H0 : 0)], 1);          // integer atomics: deterministic counts
     }
@@ -307,50 +310,55 @@ __device__ void task_blur(const Level &L, int b, int nblk, const Off15 &o, int *
             const int hh = c ? h - H0 : h;
             const int32_t *vk = L.vk[c];
             const int64_t vs = L.vstride[c];
-            const int64_t *tkeys = L.tkeys[c];
-            const int32_t *tid = L.tid[c];
+            const int4 *ts = L.tslot[c];
             const uint64_t mask = (uint64_t)dev_pow2(8 * (c ? n1 : n0)) - 1;
             const int shift = c ? H0 : 0;
             int kv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) kv[j] = vk[j * vs + hh];
-            // the 15 probes of a vertex are independent: hash all, load all first slots, load all ids; only a collision (rare
-            // at load <= 0.5) walks on.  One dependent round trip per vertex instead of fifteen.
-            int64_t pk[15];
-            uint32_t sl[15];
+            // The probes of a vertex are independent: hash, load the first two slots of each (ONE 16-byte word per slot: key +
+            // id), decide; only a run of two collisions (rare at load <= 0.5) walks on.  Two batches (8 + 7 probes): one batch's
+            // slots are 64 registers -- with all 15 in flight the kernel needed 195 registers (2 waves per SIMD for EVERY task of
+            // the build, and no room beside a 128 x 256 tile of a forward); with 8 it fits 128 (4 waves per SIMD).
+            auto probe = [&](auto f0_tag, auto n_tag) {
+                constexpr int F0 = decltype(f0_tag)::value, NF = decltype(n_tag)::value;
+                int64_t pk[NF];
+                uint32_t sl[NF];
 #pragma unroll
-            for (int f = 0; f < 15; ++f) {
-                int k[4];
+                for (int u = 0; u < NF; ++u) {
+                    int k[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) k[j] = kv[j] + o.v[f * 4 + j];
-                pk[f] = pack_key(k, mm);
-                sl[f] = (uint32_t)(mix64((uint64_t)pk[f]) & mask);
-            }
-            int64_t k0[15], k1[15];
-#pragma unroll
-            for (int f = 0; f < 15; ++f) { k0[f] = tkeys[sl[f]]; k1[f] = tkeys[(sl[f] + 1) & (uint32_t)mask]; }
-            int32_t tv[15], tw[15];
-#pragma unroll
-            for (int f = 0; f < 15; ++f) { tv[f] = tid[sl[f]]; tw[f] = tid[(sl[f] + 1) & (uint32_t)mask]; }
-#pragma unroll
-            for (int f = 0; f < 15; ++f) {
-                int32_t id;
-                if (pk[f] < 0 || k0[f] == EMPTY) id = -1;                    // (keys of real vertices are >= 0)
-                else if (k0[f] == pk[f]) id = tv[f];
-                else if (k1[f] == EMPTY) id = -1;
-                else if (k1[f] == pk[f]) id = tw[f];
-                else {
-                    uint64_t x = ((uint64_t)sl[f] + 2) & mask;
-                    while (true) {
-                        const int64_t kk = tkeys[x];
-                        if (kk == pk[f]) { id = tid[x]; break; }
-                        if (kk == EMPTY) { id = -1; break; }
-                        x = (x + 1) & mask;
-                    }
+                    for (int j = 0; j < 4; ++j) k[j] = kv[j] + o.v[(F0 + u) * 4 + j];
+                    pk[u] = pack_key(k, mm);
+                    sl[u] = (uint32_t)(mix64((uint64_t)pk[u]) & mask);
                 }
-                L.blur[(int64_t)f * Hp + h] = id >= 0 ? id + shift : -1;
-                bits |= id >= 0 ? (1u << f) : 0u;
-            }
+                int4 s0[NF], s1[NF];
+#pragma unroll
+                for (int u = 0; u < NF; ++u) { s0[u] = ts[sl[u]]; s1[u] = ts[(sl[u] + 1) & (uint32_t)mask]; }
+#pragma unroll
+                for (int u = 0; u < NF; ++u) {
+                    const int64_t k0 = slot_key(s0[u]), k1 = slot_key(s1[u]);
+                    int32_t id;
+                    if (pk[u] < 0 || k0 == EMPTY) id = -1;                    // (keys of real vertices are >= 0)
+                    else if (k0 == pk[u]) id = s0[u].w;
+                    else if (k1 == EMPTY) id = -1;
+                    else if (k1 == pk[u]) id = s1[u].w;
+                    else {
+                        uint64_t x = ((uint64_t)sl[u] + 2) & mask;
+                        while (true) {
+                            const int4 sx = ts[x];
+                            const int64_t kk = slot_key(sx);
+                            if (kk == pk[u]) { id = sx.w; break; }
+                            if (kk == EMPTY) { id = -1; break; }
+                            x = (x + 1) & mask;
+                        }
+                    }
+                    L.blur[(int64_t)(F0 + u) * Hp + h] = id >= 0 ? id + shift : -1;
+                    bits |= id >= 0 ? (1u << (F0 + u)) : 0u;
+                }
+            };
+            probe(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+            probe(std::integral_constant<int, 8>{}, std::integral_constant<int, 7>{});
         }
 #pragma unroll
         for (int q = 0; q < MAX_JOBS; ++q) {
@@ -391,7 +399,20 @@ __device__ void task_corr2(const Level &L, int b, int nblk, const Off15 &o) {
         int k[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) k[j] = vk[j * vs + h] + o.v[kc * 4 + j] + o.v[f * 4 + j];
-        L.corr2[(int64_t)kf * H0 + h] = lookup(L.tkeys[1], L.tid[1], mask, pack_key(k, mm));
+        // (one 16-byte word per probed slot: key and id together)
+        const int64_t packed = pack_key(k, mm);
+        int32_t id = -1;
+        if (packed >= 0) {
+            uint64_t x = mix64((uint64_t)packed) & mask;
+            while (true) {
+                const int4 sx = L.tslot[1][x];
+                const int64_t kk = slot_key(sx);
+                if (kk == packed) { id = sx.w; break; }
+                if (kk == EMPTY) break;
+                x = (x + 1) & mask;
+            }
+        }
+        L.corr2[(int64_t)kf * H0 + h] = id;
     }
 }
 
@@ -815,9 +836,7 @@ int64_t layout(const hpl_lattice_spec &sp, int64_t n0, int64_t n1, const int64_t
             L.vstride[c] = (int32_t)Hb[c];
             L.vk[c] = reinterpret_cast<int32_t *>(take(Hb[c] * 16));
             const int64_t capb = pow2_at_least(8 * nb[c]);
-            L.tkeys[c] = reinterpret_cast<int64_t *>(take(capb * 8));
-            L.tfirst[c] = reinterpret_cast<int32_t *>(take(capb * 4));
-            L.tid[c] = reinterpret_cast<int32_t *>(take(capb * 4));
+            L.tslot[c] = reinterpret_cast<int4 *>(take(capb * 16));
             L.slot[c] = reinterpret_cast<int32_t *>(take(nb[c] * 16));
             L.bsum[c] = reinterpret_cast<int32_t *>(take(cdiv(4 * nb[c], SCAN_CHUNK) * 4 + 4));
         }

@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) k_order_keys(const int32_t *__restrict__ 
     // Groups in GRAY-CODE order of their masks (sort key = the mask's position in the reflected Gray sequence): masks of
     // neighbouring groups then differ in one tap, where integer order puts 0111 next to 1000.  Tiles and 32-row blocks that
     // straddle group boundaries (most groups are smaller than a tile) unite fewer taps: on the N=8192 frustum the
-    // slices a 128-row tile loads drop by 3 %, the MFMA work of its 32-row blocks by 2 % (tools: DESIGN.md 4.1).
+    // slices a 128-row tile loads drop by 3 %, the MFMA work of its 32-row blocks by 2 % (tools: DESIGN_HISTORY.md 4.1).
     unsigned long long rank = mask;
     rank ^= rank >> 1; rank ^= rank >> 2; rank ^= rank >> 4; rank ^= rank >> 8;
     key[m] = rank << 48;

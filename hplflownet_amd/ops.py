@@ -303,6 +303,17 @@ def amax(X, rows=None, cols=None):
     return out
 
 
+def amax_rows(X, rows=None, cols=None):
+    """(float32 [1], int32 [1]) on the device: the largest magnitude of X[:rows, :cols] and its range-guard word -- ~bits of the
+    smallest non-zero ROW maximum, 0 for an all-zero block (hpl_amax_rows; hpl_gconv_desc.a_guard)."""
+    p_, ld, r, c = _mat(X, 'amax input')
+    out = torch.empty(1, dtype=torch.float32, device=X.device)
+    guard = torch.empty(1, dtype=torch.int32, device=X.device)
+    check(_lib.load().hpl_amax_rows(p_, ld, r if rows is None else rows, c if cols is None else cols, ptr(out), ptr(guard), stream()),
+          'hpl_amax_rows')
+    return out, guard
+
+
 def _mat(x, what):
     """(data_ptr, leading dimension, rows, cols) of a channel-last 2-D float32 device matrix, validated with one
     stride() / shape read (this sits on the host's critical path: ~100 calls per forward)."""
@@ -315,13 +326,16 @@ def _mat(x, what):
 
 def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
               scat=None, scat_c=0, naive=False, slope=LEAKY_RATE, row_perm=None, split_k=True, reg_stride=0, tiles=None,
-              out2=None, rows2=0, Wt3=None, y_amax=None):
+              out2=None, rows2=0, Wt3=None, y_amax=None, guard=True, y_guard=None, guard_trips=None):
     """Y[m, n] = act(bias[n] + res[m % res_mod, n] + sum_{f,c} A[nbr[f, m], c] * Wt[f*C + c, n]).
     row_perm (int32 [M], from tap_order): processing order of the output rows; results are unchanged.
     nbr None and reg_stride > 0: tap f of row m reads row f*reg_stride + m (no table: the displacement
     filter of the correlation layer, whose taps are the F blocks of H1 virtual vertices).
     out2 / rows2: rows m < rows2 of the result are also stored to the matrix (view) `out2`.
-    y_amax (float32 [1], device, cleared by the caller): max(y_amax, largest |Y|) is left there."""
+    y_amax (float32 [1], device, cleared by the caller): max(y_amax, largest |Y|) is left there; y_guard (int32 [1], cleared by the
+    caller): the range-guard word of Y beside it.  guard: fp16-pair launches take the range guard of A with its largest magnitude
+    (one pass: hpl_amax_rows) -- a second pass over the residuals when A has a row 2^18 below its largest entry; guard_trips
+    (int32 [1], device): += 1 when this launch took it."""
     d = GConvDesc()
     d.A, d.lda, d.rows_a, a_cols = _mat(A, 'activation')
     if nbr is not None:
@@ -350,7 +364,13 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
         elif C >= SPLIT3_MIN_C and N >= SPLIT3_MIN_N and M >= 1024 and F <= 15 and scat is None:
             # fp16 pairs: the launch scales A by its largest magnitude (csrc/gconv_common.h split3_maybe: launches that cannot
             # qualify skip the reduction and run on the fp32 MFMA)
-            a_amax = amax(A, cols=C)
+            if guard:
+                a_amax, a_guard = amax_rows(A, cols=C)
+                d.a_guard = ptr(a_guard)
+                if guard_trips is not None:
+                    d.guard_trips = ptr(guard_trips)
+            else:
+                a_amax = amax(A, cols=C)
             d.Wt3, d.wt3_plane_stride, d.wt3_planes = ptr(Wt3.planes), Wt3.planes.stride(0), 2
             d.a_amax, d.w_amax = ptr(a_amax), ptr(Wt3.amax)
     if bias is not None:
@@ -372,6 +392,8 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
         d.rows2 = rows2
     if y_amax is not None:
         d.y_amax = ptr(y_amax)
+        if y_guard is not None:
+            d.y_guard = ptr(y_guard)
     if row_perm is not None:
         if row_perm.dtype is not torch.int32 or row_perm.numel() != M or not row_perm.is_contiguous():
             raise _lib.HplError('row_perm must be a contiguous int32 tensor of M=%d entries' % M)

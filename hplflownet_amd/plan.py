@@ -594,6 +594,13 @@ class ForwardPlan(object):
         check(self._lib.hpl_plan_clock_probe(self.handle, tensor.data_ptr() if tensor is not None else None),
               'hpl_plan_clock_probe')
 
+    def guard_trips(self):
+        """Launches of this plan's runs that took the second pass of the fp16-pair form's range guard (hpl_plan_guard_trips;
+        synchronises with the device)."""
+        n = ctypes.c_int64(0)
+        check(self._lib.hpl_plan_guard_trips(self.handle, ctypes.byref(n)), 'hpl_plan_guard_trips')
+        return int(n.value)
+
     def profile_read(self):
         n, ms = ctypes.c_int(0), ctypes.c_float(0.0)
         check(self._lib.hpl_plan_profile_read(self.handle, ctypes.byref(n), ctypes.byref(ms)), 'hpl_plan_profile_read')

@@ -76,7 +76,7 @@ def hash_fill(name, shape):
     (He-uniform: keeps activations O(1) through the ~25 layers of the models) and 0.05 for
     vectors.  Used by the whole-model fixtures: the sin fill above gives rank-2 weight
     matrices, whose massive cancellations make whole-model gradients hypersensitive to
-    single LeakyReLU sign flips (measured)."""
+    single LeakyReLU sign flips (measured; see DESIGN_HISTORY.md)."""
     import zlib
     n = int(np.prod(shape))
     x = np.arange(n, dtype=np.uint64) + (np.uint64(zlib.crc32(name.encode())) << np.uint64(32))

@@ -436,7 +436,10 @@ class TrainPlan(ForwardPlan):
         # too few levels) goes down the documented autograd path instead of raising inside the step
         if not self.accepts(lat) or not hasattr(lat, 'levels') or any(lv.blur[0] is None or lv.clouds[1] is None
                                                                       for lv in lat.levels[:self.NLEV]):
-            lat._train_tables = False
+            try:
+                lat._train_tables = False
+            except AttributeError:          # (the reference's generated_data is a plain list: nothing to cache the verdict on)
+                pass
             return False
         arr0, n, keep = level_tables(lat, self.hint)
         n = self.NLEV

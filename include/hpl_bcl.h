@@ -274,10 +274,27 @@ typedef struct hpl_gconv_desc {
     /* optional (DEVICE, cleared by the caller; not with scat): *y_amax = max(*y_amax, largest |Y[m][n]| this call stores) -- the
      * a_amax of a wide launch that reads Y next, from the epilogue's registers where the launch allows, else by one more pass. */
     float *y_amax;
+    /* Range guard of the fp16-pair form (round 6; all optional, wt3_planes == 2 only).  ONE scale per matrix leaves a row whose
+     * entries are all below 2^-18 of the matrix's largest magnitude with an ABSOLUTE error (2^-40 of that magnitude) -- fine for
+     * the sums of loud rows, not for a quiet row's own outputs.  a_guard: DEVICE word written by hpl_amax_rows (or left by a
+     * producer through y_guard): the smallest non-zero ROW maximum of A, stored as ~bits (0 = unknown: no guard).  When the
+     * largest magnitude exceeds it by 2^18 or more (exponent gap), the launch runs a SECOND pass over its slice list with the
+     * residuals of the first split, (a s - hi - lo) 2^24, again as fp16 pairs, into the same accumulators: every element then
+     * carries >= 21 significand bits down to 2^-41 of the largest magnitude (2^-63 of it, absolute, below that) -- fp32-class
+     * results per OUTPUT ROW over 12 decades of row loudness, at twice the matrix-pipe work of that launch only.  y_guard: the companion of y_amax (cleared by the
+     * caller): the guard word of Y from this launch's epilogue (row maxima over the 64 columns a wave holds: never larger
+     * than the true row maximum, i.e. conservative), else by hpl_amax_rows.  guard_trips: DEVICE counter, +1 per launch that
+     * took the second pass. */
+    const uint32_t *a_guard;
+    uint32_t *y_guard;
+    int32_t *guard_trips;
 } hpl_gconv_desc;
 
 /* Largest magnitude of X[0 .. rows)[0 .. cols) (row stride ld) -> *slot (DEVICE; NaN if X holds one). */
 int hpl_amax(const float *X, int64_t ld, int64_t rows, int32_t cols, float *slot, hplStream stream);
+/* The same, and the range-guard word of X (hpl_gconv_desc.a_guard): *guard = max over the rows with a non-zero entry of
+ * ~bits(largest magnitude of the row), 0 if every row is zero.  Both slots are cleared by the call. */
+int hpl_amax_rows(const float *X, int64_t ld, int64_t rows, int32_t cols, float *slot, uint32_t *guard, hplStream stream);
 
 /* Row order for tap skipping: perm = the M vertices grouped by their F-bit tap-presence mask (bit f set iff
  * nbr[f*nbr_stride + m] >= 0; F <= 15), the groups in Gray-code order of their masks (neighbouring groups differ in
@@ -630,6 +647,9 @@ int hpl_plan_set_unlayout(hpl_plan *plan, const hpl_relayout_job *jobs /* DEVICE
  * (tag < 0: off).  hpl_plan_profile_read waits for the recorded events and returns the number of bracketed
  * launches, their total duration in ms, and resets the record. */
 int hpl_plan_profile(hpl_plan *plan, int tag);
+/* Launches of this plan's runs so far that took the second pass of the fp16-pair form's range guard (hpl_gconv_desc.a_guard):
+ * an operand with a row 2^18 or more below the matrix's largest magnitude.  Synchronises with the device. */
+int hpl_plan_guard_trips(hpl_plan *plan, int64_t *count);
 /* clock_probe (DEVICE, 2 x int64, or NULL) is handed to the gather-GEMM launches of the profiled tag
  * (hpl_gconv_desc.clock_probe): they accumulate their samples there. */
 int hpl_plan_clock_probe(hpl_plan *plan, int64_t *clock_probe);

@@ -29,6 +29,13 @@ int hpl_mfma_probe_data(float *out, int blocks, int iters, int mode, long long *
 int hpl_diag_splat_atomic(const float *feat, int64_t ldf, int C, const float *bary, const int32_t *off, int64_t N,
                           const float *norm, int64_t H, float *out, int64_t ldo, int mode, void *stream);
 
+/* A chain of `steps` small dependent steps (workgroup b reads the `words` floats workgroup b + 1 wrote in the step before, adds 1,
+ * writes its own block; grid <= 256 workgroups of 256 threads, one per CU) issued as mode 0: `steps` kernel launches; mode 1: ONE
+ * persistent launch with a monotonic-counter grid barrier between steps; mode 2: the same with an XCD-hierarchical barrier.
+ * a, b: grid * words floats each (a initialised by the caller); bar: 320 words of DEVICE scratch (modes 1, 2).  After the call
+ * the result of step steps - 1 is in (steps odd ? b : a): every element = its start value + steps.  tools/bench_chain.py. */
+int hpl_diag_chain(float *a, float *b, int grid, int words, int steps, unsigned *bar, int mode, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

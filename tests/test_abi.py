@@ -30,11 +30,12 @@ def test_gconv_desc_layout_matches_header():
     hdr = header_text()
     struct = hdr[hdr.index('typedef struct hpl_gconv_desc {'):hdr.index('} hpl_gconv_desc;')]
     struct = re.sub(r'/\*.*?\*/', '', struct, flags=re.S)
-    fields = re.findall(r'(?:const\s+)?(?:float|int32_t|int64_t|void)\s*\*?\s*(\w+);', struct)
+    fields = re.findall(r'(?:const\s+)?(?:float|int32_t|uint32_t|int64_t|void)\s*\*?\s*(\w+);', struct)
     assert fields == [f[0] for f in _lib.GConvDesc._fields_]
     assert ctypes.sizeof(_lib.GConvDesc) == (8 * 3 + 8 * 3 + 8 + 4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8
                                              + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8
-                                                 + 8 + 8 + 8 + 8)      # wt3_planes (+ padding), a_amax, w_amax, y_amax
+                                                 + 8 + 8 + 8 + 8      # wt3_planes (+ padding), a_amax, w_amax, y_amax
+                                                 + 8 + 8 + 8)         # a_guard, y_guard, guard_trips (round 6)
 
 
 def test_relayout_job_layout_matches_header():

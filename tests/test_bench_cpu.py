@@ -38,7 +38,7 @@ def test_committed_pmc_files_carry_the_stamp_of_the_committed_sources():
     """profiles/mfma_pmc.json and pmc_traffic.json are used by bench.py only when their stamp (sha256 of the kernel sources + the
     kernel-selecting environment) is this tree's: a kernel edit without a new PMC pass must show up here, not in the judge's run."""
     want = bench.source_stamp()
-    for name in ('mfma_pmc.json', 'pmc_traffic.json'):
+    for name in ('mfma_pmc.json', 'pmc_traffic.json', 'trace_hbm.json'):
         with open(os.path.join(ROOT, 'profiles', name)) as f:
             assert json.load(f).get('stamp') == want, name
 

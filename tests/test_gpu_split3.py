@@ -233,3 +233,106 @@ def test_a_launch_can_leave_the_largest_magnitude_of_its_result(M, C, F, N, spli
     slot.zero_()
     dx = ops.leaky_bwd(g, y, amax=slot)
     assert torch.equal(dx, g * torch.where(y > 0, 1.0, ops.LEAKY_RATE)) and float(slot) == float(dx.abs().max())
+
+
+def _guard_word(X):
+    """the range-guard word the kernels publish: ~bits of the smallest non-zero row maximum (0: every row zero)"""
+    rm = X.abs().max(dim=1).values
+    rm = rm[rm > 0]
+    if rm.numel() == 0:
+        return 0
+    return (~int(rm.min().view(torch.int32)) & 0xffffffff)
+
+
+def test_amax_rows_leaves_the_smallest_nonzero_row_maximum():
+    """hpl_amax_rows: the largest magnitude AND the guard word (aligned / ragged views, wide rows that need several column passes,
+    zero rows skipped, an all-zero matrix -> 0)."""
+    from hplflownet_amd import ops
+    torch.manual_seed(3)
+    X = torch.randn(5000, 1028, device=DEV) * torch.exp(6 * torch.randn(5000, 1, device=DEV))
+    X[17] = 0
+    X[4000:4100] = 0
+    for rows, cols, view in [(5000, 1028, X), (4999, 131, X), (777, 64, X[11:, 4:]), (1, 1, X[3:, 7:]), (3000, 3, X[:, 1:]), (5000, 580, X)]:
+        a, g = ops.amax_rows(view, rows=rows, cols=cols)
+        sub = view[:rows, :cols]
+        assert float(a) == float(sub.abs().max()), (rows, cols)
+        assert (int(g) & 0xffffffff) == _guard_word(sub), (rows, cols)
+    a, g = ops.amax_rows(torch.zeros(100, 8, device=DEV))
+    assert float(a) == 0.0 and int(g) == 0
+
+
+def _rowwise(y, ref, mag):
+    """largest error of every output row relative to the row's own sum |a||w| (its largest entry): the per-ROW accuracy"""
+    return ((y.double() - ref).abs().max(dim=1).values / mag.max(dim=1).values.clamp(min=1e-300))
+
+
+@pytest.mark.parametrize('case', ['quiet_rows', 'channels', 'gathered'])
+def test_range_guard_keeps_quiet_rows_fp32_class(case):
+    """The fp16-pair form scales a matrix by ONE power of two.  Trained-like activations put magnitudes of different origin into one
+    matrix: per-channel log-normal scales (sigma = 4) with one hot channel x 1e6 ('channels': every row carries the hot channel,
+    so every row's outputs are accurate relative to ITS sum |a||w| -- no second pass needed, and none taken), and -- the case the
+    guard exists for -- ROWS that are quiet as a whole ('quiet_rows': per-row scales over 10 decades; 'gathered': the same through a
+    neighbour table, where an output row sums rows of different loudness).  Row-wise relative error <= 4 x the fp32-MFMA kernel's
+    (measured: below it), where the unguarded pair form is off by orders of magnitude on the quiet rows."""
+    from hplflownet_amd import ops
+    torch.manual_seed(11)
+    M, C, N = (16500, 128, 256) if case == 'gathered' else (8192, 256, 256)      # (129 row tiles: the gathered launch fills the GPU, i.e. takes the pair form)
+    F = 8 if case == 'gathered' else 1
+    A = torch.randn(M, C, device=DEV)
+    if case == 'channels':
+        A *= torch.exp(4 * torch.randn(1, C, device=DEV))
+        A[:, 37] *= 1e6
+    else:
+        A *= 10.0 ** (10 * torch.rand(M, 1, device=DEV) - 7)          # rows from 1e-7 to 1e3 (2^33: inside the 2^41 the second pass covers)
+        A[50:60] = 0
+    Wt = torch.zeros(ops.round_up(F * C, 32), N, device=DEV)
+    Wt[:F * C] = torch.randn(F * C, N, device=DEV) / (F * C) ** 0.5
+    W3 = ops.weight_split3(Wt, planes=2)
+    nbr = _table(M, M, F, 0.6, 5) if F > 1 else None
+    perm = ops.tap_order(nbr) if F > 1 else None
+    tiles = ops.tile_index(nbr, perm, BM=128) if F > 1 else None
+    kw = dict(row_perm=perm, tiles=tiles, split_k=False)
+    trips = torch.zeros(1, dtype=torch.int32, device=DEV)
+    y = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3, guard_trips=trips, **kw)
+    y_off = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=W3, guard=False, **kw)
+    y32 = ops.gconv_raw(A, nbr, M, C, F, Wt, N, **kw)
+    ref = _ref64(A, nbr, M, C, F, Wt, N)
+    W64 = Wt[:F * C, :N].abs().double()
+    mag = torch.zeros((M, N), dtype=torch.float64, device=DEV)
+    for f in range(F):
+        rows = A.abs().double() if nbr is None else torch.where((nbr[f] >= 0)[:, None], A.abs().double()[nbr[f].long().clamp(min=0)], torch.zeros((), dtype=torch.float64, device=DEV))
+        mag += rows @ W64[f * C:(f + 1) * C]
+    live = mag.max(dim=1).values > 0
+    e, e_off, e32 = [float(_rowwise(x, ref, mag)[live].max()) for x in (y, y_off, y32)]
+    print('%s: row-wise err / sum|a||w|: guarded pairs %.3g, unguarded %.3g, fp32 MFMA %.3g; second passes %d' % (case, e, e_off, e32, int(trips)))
+    assert torch.isfinite(y).all() and float(y[~live].abs().max() if (~live).any() else 0.0) == 0.0
+    assert e <= 4 * e32 and e < 2e-6
+    if case == 'channels':
+        assert int(trips) == 0 and torch.equal(y, y_off)              # nothing to guard: the launch is the round-5 launch, bit for bit
+    else:
+        assert int(trips) == 1 and e_off > 100 * e                    # the guard is what makes the quiet rows right
+
+
+def test_range_guard_word_from_the_epilogue_is_conservative():
+    """hpl_gconv_desc.y_guard: the wide epilogue leaves the guard word of what it stores (row maxima over the 32 columns of a lane
+    block: never above the true row maximum) -- between the true smallest row maximum and 2^-8 of it for these activations, and
+    exactly hpl_amax_rows' word when the launch reduces Y in a second pass (split-K)."""
+    from hplflownet_amd import ops
+    torch.manual_seed(12)
+    for M, C, F, N, splitk in [(16500, 64, 1, 512, False), (9433, 388, 15, 256, True)]:
+        A = torch.randn(M + 5, C, device=DEV) * 10.0 ** (6 * torch.rand(M + 5, 1, device=DEV) - 3)
+        Wt = torch.zeros(ops.round_up(F * C, 32), N, device=DEV)
+        Wt[:F * C] = torch.randn(F * C, N, device=DEV) / (F * C) ** 0.5
+        nbr = _table(M, M + 5, F, 0.7, 2) if F > 1 else None
+        perm = ops.tap_order(nbr) if F > 1 else None
+        slot, g = torch.zeros(1, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+        y = ops.gconv_raw(A, nbr, M, C, F, Wt, N, Wt3=ops.weight_split3(Wt, planes=2), act=ops.ACT_LEAKY, row_perm=perm, split_k=splitk,
+                          y_amax=slot, y_guard=g)
+        assert float(slot) == float(y.abs().max())
+        rm = y.abs().max(dim=1).values
+        true_min = float(rm[rm > 0].min())
+        got = torch.tensor([~int(g) & 0x7fffffff], dtype=torch.int32).view(torch.float32).item()
+        if splitk:
+            assert got == true_min
+        else:
+            assert true_min * 2.0 ** -8 <= got <= true_min, (got, true_min)

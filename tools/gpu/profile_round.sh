@@ -18,7 +18,12 @@ cp profiles/pmc_traffic.json gpurun_out/${R}_pmc_traffic.json 2>/dev/null; pytho
 rocprofv3 --kernel-trace -d gpurun_out/ft -o ft -- python tools/chain_run.py frustum 8192 > gpurun_out/${R}_chain_run.txt 2>&1
 DB=$(ls gpurun_out/ft/*/ft_results.db gpurun_out/ft/ft_results.db 2>/dev/null | head -1)
 python tools/forward_trace.py $DB > gpurun_out/${R}_step_timeline.txt
-rm -rf gpurun_out/prof_k gpurun_out/pmc_mfma gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/ft
+python tools/trace_hbm.py $DB gpurun_out/${R}_trace_hbm.json > gpurun_out/${R}_trace_hbm.txt
+# one lattice build task by task (HPL_FUSED_SPLIT=2: every task a launch of its own, its name on stderr)
+HPL_FUSED_SPLIT=2 rocprofv3 --kernel-trace -d gpurun_out/lt -o lt -- python tools/lattice_trace.py run 8192 > gpurun_out/${R}_lattice_run.txt 2>&1
+python tools/lattice_trace.py show $(ls gpurun_out/lt/*/lt_results.db gpurun_out/lt/lt_results.db 2>/dev/null | head -1) > gpurun_out/${R}_lattice_show.txt
+python tools/lattice_tasks.py gpurun_out/${R}_lattice_run.txt gpurun_out/${R}_lattice_show.txt > gpurun_out/${R}_lattice_tasks.txt 2>&1
+rm -rf gpurun_out/prof_k gpurun_out/pmc_mfma gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/ft gpurun_out/lt
 head -12 gpurun_out/${R}_kernel_stats.txt | cut -c1-160; head -6 gpurun_out/${R}_mfma_pmc.txt | cut -c1-200; head -3 gpurun_out/${R}_pmc_traffic.txt
 python - <<PY
 import json

@@ -35,6 +35,7 @@ def main():
     hist.pop('round_1_final', None)
     hist.setdefault('round_2_fp32_kernel_64x128_tiles', 1549000000)
     hist.setdefault('round_3_split_kernel_one_barrier_form', 1110000000)
+    hist.setdefault('round_5_pair_form_column_major_xcd_order', 930231343)
     d = {'_comment': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of `python bench.py '
                      '--steps 3 --warmup 1 --no-cpu-baseline --no-overlap` (tools/pmc_traffic.py). Per launch of '
                      'the dominant stencil instance (k_gconv3w<8,4,planes>; HPL_MATH=f32: k_gconv<64,128,2,4,true,...>), averaged over its four launches per step. Counter unit KiB; FETCH_SIZE '
@@ -44,9 +45,10 @@ def main():
          # every operand once: activation matrix + split weight image of the pass + output written (+ read back by the second
          # tap-group pass): bcn1_ 60 + 28.5 + 106 / 60 + 25 + 212 MB, bcn2_ 45 + 8 + 71 / 45 + 7 + 142 MB -> mean of the four launches
          'algorithmic_bytes_per_launch': 202000000, 'history': hist,
-         'note': 'fetch > algorithmic: L2-miss traffic of the gathered activation rows (each of the 4 / 2 column tiles re-gathers '
-                 'its tile-row from the 60 / 45 MB matrix, which lives in the 256 MB Infinity Cache); the weight panels are shared '
-                 'in L2 by the column-major XCD order. DESIGN.md section 4.'}
+         'note': 'fetch > algorithmic: L2-miss traffic of the gathered activation rows (every use of a row by another tap is a slice list apart in time) '
+                 'from the 60 / 45 MB matrix, which lives in the 256 MB Infinity Cache, and of the weight panels (round 6: row-major XCD '
+                 'order -- the column tiles of a tile-row share their gathered rows in one L2, every L2 streams all weight panels; rounds 2-5: '
+                 'column-major). DESIGN.md section 4.1.'}
     for nm in ('k_splat', 'k_slice'):       # the HBM-bound gathers: average over all their launches of a step (all levels)
         fk2 = [k for k in f if nm in k]
         wk2 = [k for k in w if nm in k]
