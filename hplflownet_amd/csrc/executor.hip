@@ -75,10 +75,13 @@ __global__ void k_copy_emg_batch(const EmgJobs j) {
 
 // HPL_RANGE_GUARD=0: the fp16-pair launches of a plan run without their range guard (hpl_gconv_desc.a_guard: no guard words, no
 // second launches) -- the round-5 behaviour, for A/B runs
-inline bool range_guard() {
-    static const bool on = [] { const char *e = getenv("HPL_RANGE_GUARD"); return !(e && e[0] == '0'); }();
-    return on;
+// (diagnostic values: 2 = guard words only -- reductions and epilogues leave them, no launch reads them --, 3 = second launches only,
+// reading words nobody wrote = 0 = unknown = no trip, 4 = reductions' words + second launches, not the epilogues')
+inline int range_guard_mode() {
+    static const int m = [] { const char *e = getenv("HPL_RANGE_GUARD"); return e ? atoi(e) : 1; }();
+    return m;
 }
+inline bool range_guard() { return range_guard_mode() != 0; }
 
 struct View {                 // a resolved hpl_ref
     float *p;
@@ -175,7 +178,7 @@ struct Runner {
             if (e.buf == r.buf && e.row_off == off && e.rows == rows && e.col_off == r.col_off && e.cols == cols) { slot = e.slot; return HPL_OK; }
         HPL_REQUIRE(pl.amax_used < AMAX_SLOTS, "hpl_plan_run: more than %d operand reductions in one run", AMAX_SLOTS);
         float *dst = amax_base + 2 * pl.amax_used++;
-        const int rc = hpl_gc::amax_launch(v.p, v.ld, rows, cols, dst, main_s, range_guard() ? reinterpret_cast<unsigned *>(dst + 1) : nullptr);
+        const int rc = hpl_gc::amax_launch(v.p, v.ld, rows, cols, dst, main_s, (range_guard() && range_guard_mode() != 3) ? reinterpret_cast<unsigned *>(dst + 1) : nullptr);
         if (rc) return rc;
         if (r.buf >= 0) pl.amax.push_back({r.buf, off, rows, r.col_off, cols, dst});
         slot = dst;
@@ -376,7 +379,7 @@ struct Runner {
             }
             d.Y = Y.p; d.ldy = Y.ld;
             if (last && has_out2) { d.Y2 = Y2.p; d.ldy2 = Y2.ld; d.rows2 = rows2; }
-            if (last && cur_y_amax && !scatter) { d.y_amax = cur_y_amax; if (range_guard()) d.y_guard = reinterpret_cast<uint32_t *>(cur_y_amax + 1); }
+            if (last && cur_y_amax && !scatter) { d.y_amax = cur_y_amax; if (range_guard() && range_guard_mode() < 3) d.y_guard = reinterpret_cast<uint32_t *>(cur_y_amax + 1); }
             d.row_perm = row_perm;
             if (row_perm && ti && tm) { d.tile_idx = ti; d.tile_mask = tm; d.tile_bm = ngroups >= 2 ? t.group_tile_bm : t.tile_bm; }
             // split-operand image of the same rows (csrc/gconv3.hip takes the launch if it qualifies): k-blocks of 8 rows
@@ -385,7 +388,7 @@ struct Runner {
                 d.wt3_plane_stride = w.wt3_plane_stride;
                 d.wt3_planes = w.wt3_planes;
                 d.a_amax = cur_a_amax; d.w_amax = w.w_amax;
-                if (cur_a_amax && range_guard()) { d.a_guard = reinterpret_cast<const uint32_t *>(cur_a_amax + 1); d.guard_trips = pl.guard_trips; }
+                if (cur_a_amax && range_guard() && range_guard_mode() != 2) { d.a_guard = reinterpret_cast<const uint32_t *>(cur_a_amax + 1); d.guard_trips = pl.guard_trips; }
             }
             if (prof) d.clock_probe = pl.clock_probe;
             if (scatter) { d.scat = t.corr2; d.scat_stride = 15 * t.H0; d.scat_c = op.aux; }

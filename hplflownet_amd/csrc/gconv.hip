@@ -615,7 +615,7 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     HPL_REQUIRE(!d->Wt3 || d->wt3_planes == 0 || d->wt3_planes == 2 || d->wt3_planes == 3, "%s: wt3_planes = %d", who, d->wt3_planes);
     if (p.planes == 2 && !(p.a_amax && p.w_amax)) p.Wt3 = nullptr;      // fp16 pairs need both scales: the launch stays on the fp32 MFMA
     p.y_amax = d->y_amax; p.y_amax_done = 0;
-    p.a_guard = d->a_guard; p.y_guard = d->y_guard; p.guard_trips = d->guard_trips; p.guard_partials = 0;
+    p.a_guard = d->a_guard; p.y_guard = d->y_guard; p.guard_trips = d->guard_trips; p.guard_partials = 0; p.guard_grid = 0;
     HPL_REQUIRE(!(d->y_amax && d->scat), "%s: y_amax with a scatter epilogue", who);
     p.col_share = 0; p.col_rows = 0;
     p.tiles_m = p.tiles_n = 0;

@@ -76,6 +76,18 @@ __device__ __forceinline__ void split2h(float x0, float x1, float s, unsigned &h
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
+// Largest of an unsigned over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), in every lane of the row: four v_max_u32 with a DPP
+// operand (quad xor 1, quad xor 2, half-row mirror, row mirror).  The guard word of the wide epilogue takes a row's maximum over the 16
+// columns these lanes hold; as five __shfl_xor steps per element (ds_bpermute_b32: 320 dependent LDS-pipe operations per lane and tile)
+// it cost 16-50 us per launch (dense 1x1 launches 72 -> 89, 77 -> 128 us: profiles/r06e_step_timeline_shfl_epilogue.txt against r05y_step_timeline.txt's).
+__device__ __forceinline__ unsigned dpp_row_max(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));       // quad_perm [1, 0, 3, 2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));       // quad_perm [2, 3, 0, 1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));      // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));      // row_mirror
+    return v;
+}
+
 // Second pass of the range guard (hpl_gconv_desc.a_guard): the residual of the first split, r = (x s - hi) - lo (both subtractions
 // exact in fp32), times 2^24, again as an fp16 pair.  |x s - hi| <= 2^3 and |r| <= 2^-9 for |x s| < 2^15, so r 2^24 <= 2^15 fits fp16;
 // for an element too small for a normal lo (|x s| < 2^-3) r is what the first pass lost: it is carried here to 2^-24 of ITS size.
@@ -96,6 +108,7 @@ __device__ __forceinline__ void split2h_resid(float x0, float x1, float s, unsig
 }
 
 constexpr int BM3 = 128;
+constexpr int GUARD_WGS = 256;          // workgroups of a guard launch (k_gconv3 / k_gconv3w with GUARD)
 
 // NB = stages of the weight-fragment ring (3 or 4); the gathered rows use NB - 1 register sets: with NB = 4 every load has one
 // more half-step to land (the end-of-half-step wait then leaves the loads of TWO half-steps in flight)
@@ -107,7 +120,7 @@ constexpr int BM3 = 128;
 // pass out of the first kernel keeps that kernel's code (15.5 k instructions) and registers what they were: with both passes in one
 // kernel (24.4 k instructions) the unguarded launches ran 4-10 % slower (profiles/r06b_split3_guard_in_kernel.txt).
 template <int WGN, int F_LDS, int NB, int PL, bool GUARD = false>
-__device__ __forceinline__ void gconv3_body(const GParams &p) {
+__device__ __forceinline__ void gconv3_body(const GParams &p, const unsigned block) {
     static_assert(PL == 2 || PL == 3, "operand planes: 2 (fp16 pairs) or 3 (bf16 triples)");
     static_assert(!GUARD || PL == 2, "the range guard belongs to the fp16-pair form");
     bool tripped = false;
@@ -149,7 +162,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     unsigned short *Ks = reinterpret_cast<unsigned short *>(tapmask_s + 8);
 
     int tile_m, tile_n;
-    tile_coords(p, tile_m, tile_n);
+    tile_coords(p, tile_m, tile_n, block);
     if (tile_m < 0) return;
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
@@ -158,7 +171,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     const int wm = wave / WGN, wn = wave % WGN;
     const int li = lane & 31, hi = lane >> 5;
 
-    const bool probe = p.clock_probe && (blockIdx.x & 63) == 0 && t == 0;
+    const bool probe = p.clock_probe && (block & 63) == 0 && t == 0;
     long long probe_c = 0, probe_w = 0;
     if (probe) { probe_c = (long long)__builtin_readcyclecounter(); probe_w = (long long)__builtin_amdgcn_s_memrealtime(); }
 
@@ -238,7 +251,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     int split = 0;
     if (p.splits > 1) {
         const int ngrid = p.row_perm && p.col_share > 0 ? p.tiles_n * p.col_share * p.col_rows : p.tiles_m * p.tiles_n;
-        split = blockIdx.x / ngrid;
+        split = (int)block / ngrid;
         const int k_lo = (int)((int64_t)nk * split / p.splits), k_hi = (int)((int64_t)nk * (split + 1) / p.splits);
         auto below = [&](int kt) {           // list entries with slice index < kt (the list is ascending)
             int a = 0, b = nsl;
@@ -684,7 +697,7 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         const unsigned ldy_b = (unsigned)(p.splits > 1 ? p.N : p.ldy) * 4u, ldr_b = (unsigned)p.ldres * 4u, ldy2_b = (unsigned)p.ldy2 * 4u;
         const bool plain = p.splits <= 1;
         unsigned ymax = 0;                                   // largest |y| this lane stores (p.y_amax)
-        unsigned gmin = 0xffffffffu;                         // smallest non-zero row maximum over the 32 columns of a block (p.y_guard)
+        unsigned gmin = 0xffffffffu;                         // smallest non-zero row maximum over 16 columns of a block (p.y_guard)
         const bool want_guard = p.y_guard && p.y_amax && plain && !defer;      // (uniform)
         const bool res_wrap = p.res && p.res_mod < p.M;      // (uniform)
         const float res_inv = res_wrap ? 1.0f / (float)p.res_mod : 0.f;
@@ -725,10 +738,8 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
                     const unsigned yo = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldy_b) + nb : OOB;
                     const unsigned av = (mrow[r] >= 0 && n < p.N) ? (__builtin_bit_cast(unsigned, v) & 0x7fffffffu) : 0u;
                     ymax = max(ymax, av);
-                    if (want_guard) {            // the row's maximum over the block's 32 columns (the lanes of this half-wave)
-                        unsigned rm = av;
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) rm = max(rm, (unsigned)__shfl_xor((int)rm, o));
+                    if (want_guard) {            // the row's maximum over 16 of the block's columns (one DPP row of lanes)
+                        const unsigned rm = dpp_row_max(av);
                         gmin = rm ? min(gmin, rm) : gmin;
                     }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (int)yo, 0, 0);
@@ -739,11 +750,24 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
         if (p.y_amax && plain && !defer) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ymax = max(ymax, (unsigned)__shfl_xor((int)ymax, o));
-            if (lane == 0) amax_publish(reinterpret_cast<unsigned *>(p.y_amax), ymax);
+            unsigned inv = 0u;
             if (want_guard) {           // ~bits order the other way round: the largest ~maximum is the smallest row maximum
-                unsigned inv = gmin == 0xffffffffu ? 0u : ~gmin;
+                inv = gmin == 0xffffffffu ? 0u : ~gmin;          // (lanes 0 / 32: every row of the wave over its columns 0-15)
                 inv = max(inv, (unsigned)__shfl_xor((int)inv, 32));
-                if (lane == 0) amax_publish(p.y_guard, inv);
+            }
+            // ONE publisher per workgroup (round 6; was one per wave): the tiles of a one-round launch end together, so looking
+            // before the atomic does not thin them out -- 2 048 waves queued on the two words of a slot at the end of a dense
+            // 256-tile launch.  The stages of the contraction loop are dead here; the barrier in front keeps the waves that
+            // still read fragments of the last half-step apart from the scratch words.
+            __syncthreads();
+            unsigned *red = reinterpret_cast<unsigned *>(smem);
+            if (lane == 0) { red[2 * wave] = ymax; red[2 * wave + 1] = inv; }
+            __syncthreads();
+            if (t == 0) {
+#pragma unroll
+                for (int w = 1; w < NT / 64; ++w) { ymax = max(ymax, red[2 * w]); inv = max(inv, red[2 * w + 1]); }
+                amax_publish(reinterpret_cast<unsigned *>(p.y_amax), ymax);
+                if (want_guard) amax_publish(p.y_guard, inv);
             }
         }
     } else
@@ -778,15 +802,32 @@ __device__ __forceinline__ void gconv3_body(const GParams &p) {
     }
 }
 
+// A guard launch is PERSISTENT: min(tiles, GUARD_WGS) workgroups, workgroup b takes the tiles b, b + gridDim.x, ... (GUARD_WGS is a
+// multiple of 8: a tile stays on the XCD the launch order gives it).  It almost always leaves at once.  What it costs the pipelined
+// loop then does not depend on its size (8 / 32 / 128 / 1024 workgroups: 438-462 / 444-457 / 444-455 / 432-459 pairs/s, without
+// the guard 474-478: profiles/r06j_guard_wgs_ab.txt) -- it is the extra dependent launch behind every wide one (second launches
+// without the guard words: -4 %, the words without the launches: -1 %: profiles/r06k_guard_parts_ab.txt).
+template <int WGN, int F_LDS, int NB, int PL>
+__device__ __forceinline__ void gconv3_guard_loop(const GParams &p) {
+    if (!guard_tripped(p.a_amax, p.a_guard)) return;
+    for (unsigned b = blockIdx.x; b < (unsigned)p.guard_grid; b += gridDim.x) {
+        gconv3_body<WGN, F_LDS, NB, PL, true>(p, b);
+        __builtin_amdgcn_s_waitcnt(0);          // (the next tile's hand-counted load waits start from an empty queue)
+        __syncthreads();                        // (its prologue rewrites the LDS tables this tile's epilogue read)
+    }
+}
+
 template <int WGN, int F_LDS, int PL, int NB = 3, bool GUARD = false>
 __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
-    gconv3_body<WGN, F_LDS, NB, PL, GUARD>(p);
+    if constexpr (GUARD) gconv3_guard_loop<WGN, F_LDS, NB, PL>(p);
+    else gconv3_body<WGN, F_LDS, NB, PL, false>(p, blockIdx.x);
 }
 
 // the 8-wave tile (128 x 256, ping-pong wave rows): one workgroup per CU
 template <int F_LDS, int NB, int PL, bool GUARD = false>
 __global__ void __launch_bounds__(512, 2) k_gconv3w(const GParams p) {
-    gconv3_body<4, F_LDS, NB, PL, GUARD>(p);
+    if constexpr (GUARD) gconv3_guard_loop<4, F_LDS, NB, PL>(p);
+    else gconv3_body<4, F_LDS, NB, PL, false>(p, blockIdx.x);
 }
 
 // Wt [k_rows][ldw] fp32 -> three bf16 planes [k_rows/8][ldw][8]
@@ -874,11 +915,12 @@ __global__ void __launch_bounds__(256) k_amax_rows(const float *__restrict__ X, 
         ginv = m ? max(ginv, ~m) : ginv;
     };
     const int64_t rstep = (int64_t)gridDim.x * rpb;
-    int64_t r = (int64_t)blockIdx.x * rpb + (threadIdx.x >> tpr_log);
-    const int64_t r_first = r;
-    // (uniform trip counts inside a row's lane group: rows and r are the same for its lanes)
-    for (; r + 3 * rstep < rows; r += 4 * rstep) {
-        const float *p0 = X + r * ld, *p1 = p0 + rstep * ld, *p2 = p1 + rstep * ld, *p3 = p2 + rstep * ld;
+    // four rows of a lane group in flight; a group short of four rows re-reads its first one (max and guard are idempotent), so the
+    // tail of the matrix is one round of loads as well (a single-row tail loop took a 25 841-row matrix in 1 + 3 dependent rounds:
+    // 19.7 against 12.4 us for hpl_amax's pass over the same bytes).  Uniform trip counts inside a row's lane group.
+    for (int64_t r = (int64_t)blockIdx.x * rpb + (threadIdx.x >> tpr_log); r < rows; r += 4 * rstep) {
+        const int64_t r1 = r + rstep < rows ? r + rstep : r, r2 = r + 2 * rstep < rows ? r + 2 * rstep : r, r3 = r + 3 * rstep < rows ? r + 3 * rstep : r;
+        const float *p0 = X + r * ld, *p1 = X + r1 * ld, *p2 = X + r2 * ld, *p3 = X + r3 * ld;
         unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         for (int c = c0; c < colsv; c += tpr) {
             const V a = *reinterpret_cast<const V *>(p0 + (int64_t)c * VW), b = *reinterpret_cast<const V *>(p1 + (int64_t)c * VW);
@@ -887,13 +929,6 @@ __global__ void __launch_bounds__(256) k_amax_rows(const float *__restrict__ X, 
         }
         row_done(m0); row_done(m1); row_done(m2); row_done(m3);
     }
-    for (; r < rows; r += rstep) {
-        const float *p0 = X + r * ld;
-        unsigned m0 = 0;
-        for (int c = c0; c < colsv; c += tpr) fold(m0, *reinterpret_cast<const V *>(p0 + (int64_t)c * VW));
-        row_done(m0);
-    }
-    (void)r_first;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ginv = max(ginv, (unsigned)__shfl_xor((int)ginv, o));
     __shared__ unsigned gpart[4];
@@ -998,6 +1033,8 @@ int hpl_gc::amax_launch(const float *X, int64_t ld, int64_t rows, int cols, floa
         int tl = 0;
         while ((1 << tl) < cv && tl < 6) ++tl;
         const int rpb = 256 >> tl;
+        // (grid cap, 9 reductions of a forward: 256: 145 us, 512: 127, 1024: 124, 2048: 161, 4096: 33-47 us for each of the three large ones -- a
+        // one-round grid ends all at once, on the slot's two atomics)
         const int grid = (int)imax(1, imin(cdiv(nrows, (int64_t)rpb * 4), 1024));
         if (vec) k_amax_rows<float4><<<grid, 256, 0, s>>>(X, ld, nrows, cv, tl, reinterpret_cast<unsigned *>(slot), guard);
         else k_amax_rows<float><<<grid, 256, 0, s>>>(X, ld, nrows, cv, tl, reinterpret_cast<unsigned *>(slot), guard);
@@ -1166,16 +1203,18 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
             // the guard's second launch: the same tiles on the residuals; it adds what the first launch stored and finishes.
             // (It leaves at once when the operand has no quiet row: an empty launch of this grid, 2-3 us.)
             GParams q = p;
+            q.guard_grid = grid;
+            const int ggrid = (int)imin(grid, GUARD_WGS);
             if (p.splits > 1) { q.partial = p.partial + (int64_t)p.splits * p.M * p.N; p.guard_partials = 1; }      // a second set of partial tiles (k_gconv_finish adds both)
             else { q.res = p.Y; q.ldres = p.ldy; q.res_mod = p.M; q.bias = nullptr; }
             if (bn256) {
-                if (p.F == 1) k_gconv3w<1, 4, 2, true><<<grid, 512, 0, s>>>(q);
-                else if (p.F <= 8) k_gconv3w<8, 4, 2, true><<<grid, 512, 0, s>>>(q);
-                else k_gconv3w<15, 4, 2, true><<<grid, 512, 0, s>>>(q);
+                if (p.F == 1) k_gconv3w<1, 4, 2, true><<<ggrid, 512, 0, s>>>(q);
+                else if (p.F <= 8) k_gconv3w<8, 4, 2, true><<<ggrid, 512, 0, s>>>(q);
+                else k_gconv3w<15, 4, 2, true><<<ggrid, 512, 0, s>>>(q);
             } else {
-                if (p.F == 1) k_gconv3<2, 1, 2, 3, true><<<grid, 256, 0, s>>>(q);
-                else if (p.F <= 8) k_gconv3<2, 8, 2, 3, true><<<grid, 256, 0, s>>>(q);
-                else k_gconv3<2, 15, 2, 3, true><<<grid, 256, 0, s>>>(q);
+                if (p.F == 1) k_gconv3<2, 1, 2, 3, true><<<ggrid, 256, 0, s>>>(q);
+                else if (p.F <= 8) k_gconv3<2, 8, 2, 3, true><<<ggrid, 256, 0, s>>>(q);
+                else k_gconv3<2, 15, 2, 3, true><<<ggrid, 256, 0, s>>>(q);
             }
         }
     } else if (bn256) {

@@ -80,6 +80,7 @@ struct GParams {
     const float *a_amax; const float *w_amax;      //   DEVICE scalars (hpl_amax; hpl_weight_split2h)
     float *y_amax; int y_amax_done;     // optional: largest |Y| stored -> *y_amax (done = 1: the kernel's epilogue did it)
     const unsigned *a_guard; unsigned *y_guard; int *guard_trips;      // range guard of the pair form (hpl_gconv_desc.a_guard ...)
+    int guard_grid;                     // guard launches are persistent: workgroup b takes the tiles b, b + gridDim.x, ... of this many
     int guard_partials;                 // split-K launch with a guarded operand: a tripped guard leaves a SECOND set of `splits` partial tiles
     int epi_fast;                       // 32-bit buffer addressing in the epilogue (set by the launch functions)
 };
@@ -94,9 +95,10 @@ __device__ __forceinline__ int64_t src_row(const GParams &p, int f, int64_t m) {
 // XCDs (private 4 MiB L2 each).  Re-number so that each XCD owns a contiguous run of tiles,
 // and walk tiles_n fastest inside a band of 8 tile-rows so that concurrently resident
 // workgroups of one XCD share both gathered A rows and weight panels in that L2.
-__device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) {
+// (block: the workgroup id the tile is derived from -- blockIdx.x, or the virtual id of a persistent launch: gconv3.hip's guard launches)
+__device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn, const unsigned block) {
     const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x % nwg;       // (split-K: grid = splits x tiles)
+    const int bid = (int)block % nwg;       // (split-K: grid = splits x tiles)
     const int q = nwg / 8, r = nwg % 8;
     const int xcd = bid % 8, pos = bid / 8;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // bijective
@@ -105,7 +107,7 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
         // walks the column tiles of a tile-row back to back, so the tiles_n column tiles of one tile-row are resident on ONE XCD
         // at the same time: its gathered A rows are fetched into that L2 once, not once per column tile; the weight panels of all
         // column tiles then stream through every L2 (from the Infinity Cache).  Grid = 8 * col_rows * tiles_n.
-        const int x2 = blockIdx.x % 8, pos2 = blockIdx.x / 8;
+        const int x2 = (int)block % 8, pos2 = (int)block / 8;
         const int j = pos2 / p.tiles_n;
         tn = pos2 - j * p.tiles_n;
         const int row = j * 8 + x2;
@@ -118,7 +120,7 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
         // robin.  The grid is rounded up to 8 equal runs; surplus workgroups get tm = -1.
         const int gsz = p.tiles_n * p.col_share * p.col_rows;
         const int q2 = gsz / 8, r2 = gsz % 8;
-        const int b2 = p.splits > 1 ? blockIdx.x % gsz : blockIdx.x;      // (split-K: grid = splits x gsz)
+        const int b2 = p.splits > 1 ? (int)block % gsz : (int)block;      // (split-K: grid = splits x gsz)
         const int x2 = b2 % 8, pos2 = b2 / 8;
         const int id2 = (x2 < r2 ? x2 * (q2 + 1) : r2 * (q2 + 1) + (x2 - r2) * q2) + pos2;
         const int v = id2 / p.col_rows, pos = id2 - v * p.col_rows;
@@ -173,6 +175,7 @@ __device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) 
     tm = band * BAND + in_band % rows_in_band;
     tn = in_band / rows_in_band;
 }
+__device__ __forceinline__ void tile_coords(const GParams &p, int &tm, int &tn) { tile_coords(p, tm, tn, blockIdx.x); }
 
 
 // host side (gconv.hip / gconv3.hip)

@@ -60,7 +60,7 @@ def test_two_ranks_inference_on_one_gpu():
     d = _one_line(out0, 2)
     assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak' and d['value'] > 0
     # whole-job throughput: both ranks' pairs over the slowest rank's time
-    assert abs(d['value'] - 2 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert abs(d['value'] - 2 * 1e3 / d['ms_per_step']) < 1e-5 * d['value']      # (the contract line carries 6 significant digits)
     assert d['pipelined_output_check']['max_abs_diff'] == 0.0
 
 
@@ -82,13 +82,13 @@ def test_eight_ranks_dry_run_on_one_gpu():
     assert not [ln for ln in out1.splitlines() if ln.startswith('{')]
     d = _one_line(out0, 8)
     assert d['n_gpus'] == 8 and d['steps'] == 3 and d['value'] > 0
-    assert abs(d['value'] - 8 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert abs(d['value'] - 8 * 1e3 / d['ms_per_step']) < 1e-5 * d['value']      # (the contract line carries 6 significant digits)
     # every rank reported, the job's step time is the slowest rank's, and no rank's host threads are what limits it: the
     # host time a step needs (enqueue of one forward + one lattice, minus the time spent waiting for the GPU) stays far
     # below the step, with eight ranks' threads running side by side on this host
     rk = d['ranks']
     assert rk['ranks_seen'] == 8 and len(rk['ms_per_step_by_rank']) == 8 and rk['backend'] == 'gloo'
-    assert abs(max(rk['ms_per_step_by_rank']) - d['ms_per_step']) < 1e-6 * d['ms_per_step']
+    assert abs(max(rk['ms_per_step_by_rank']) - d['ms_per_step']) < 1e-5 * d['ms_per_step']
     assert max(rk['host_busy_ms_by_rank']) < 0.5 * d['ms_per_step']
     assert max(rk['host_busy_ms_by_rank']) < 1.5          # ms, absolute: half of ONE GPU's N=8192 step (2.9 ms) with 8 ranks' threads on the host
     assert d['pipelined_output_check']['max_abs_diff'] == 0.0

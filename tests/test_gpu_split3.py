@@ -314,7 +314,7 @@ def test_range_guard_keeps_quiet_rows_fp32_class(case):
 
 
 def test_range_guard_word_from_the_epilogue_is_conservative():
-    """hpl_gconv_desc.y_guard: the wide epilogue leaves the guard word of what it stores (row maxima over the 32 columns of a lane
+    """hpl_gconv_desc.y_guard: the wide epilogue leaves the guard word of what it stores (row maxima over 16 columns of a lane
     block: never above the true row maximum) -- between the true smallest row maximum and 2^-8 of it for these activations, and
     exactly hpl_amax_rows' word when the launch reduces Y in a second pass (split-K)."""
     from hplflownet_amd import ops

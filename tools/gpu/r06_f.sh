@@ -1,0 +1,11 @@
+# round 6: the guard word of the wide epilogue by DPP row maxima, hpl_amax_rows with its tail in one round; guard on / off A/B
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r06f; mkdir -p $O
+export TMPDIR=/tmp
+python -m pytest tests/test_gpu_split3.py tests/test_gpu_kernels.py tests/test_gpu_multirank.py -x -q > $O/pytest_first.txt 2>&1; echo "first rc=$?"; tail -3 $O/pytest_first.txt
+for g in 0 1 0 1; do echo "HPL_RANGE_GUARD=$g"; HPL_RANGE_GUARD=$g python tools/chain_run.py frustum 8192 2>/dev/null | tail -1; done > $O/guard_ab_chain.txt; cat $O/guard_ab_chain.txt
+for g in 0 1 0 1; do echo "HPL_RANGE_GUARD=$g"; HPL_RANGE_GUARD=$g python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-train-probe --detail '' 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), d.get('steady'), d.get('forward_only'), d.get('single_pair_latency_ms'))"; done > $O/guard_ab_bench.txt; cat $O/guard_ab_bench.txt
+rocprofv3 --kernel-trace -d $O/ft -o ft -- python tools/chain_run.py frustum 8192 > $O/chain_run.txt 2>&1
+DB=$(ls $O/ft/*/ft_results.db $O/ft/ft_results.db 2>/dev/null | head -1)
+python tools/forward_trace.py $DB > $O/step_timeline.txt; rm -rf $O/ft
+head -1 $O/step_timeline.txt; tail -1 $O/step_timeline.txt; grep "k_gconv3w<1, 4, 2, false>\|k_amax_rows" $O/step_timeline.txt

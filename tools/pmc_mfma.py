@@ -18,7 +18,7 @@ import os
 import re
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # the wide tap-group passes: the split-operand kernel (default) or, with HPL_MATH=f32, the fp32-MFMA 64 x 128 stencil class
-DOMINANT = re.compile(r'k_gconv3w<8, 4, \d>' if os.environ.get('HPL_MATH', 'f16x2') != 'f32' else r'k_gconv<64, 128, 2, 4, true, (8|15)\b')
+DOMINANT = re.compile(r'k_gconv3w<8, 4, \d(, false)?>' if os.environ.get('HPL_MATH', 'f16x2') != 'f32' else r'k_gconv<64, 128, 2, 4, true, (8|15)\b')
 
 
 def main():
