@@ -806,7 +806,12 @@ __device__ __forceinline__ void gconv3_body(const GParams &p, const unsigned blo
 // multiple of 8: a tile stays on the XCD the launch order gives it).  It almost always leaves at once.  What it costs the pipelined
 // loop then does not depend on its size (8 / 32 / 128 / 1024 workgroups: 438-462 / 444-457 / 444-455 / 432-459 pairs/s, without
 // the guard 474-478: profiles/r06j_guard_wgs_ab.txt) -- it is the extra dependent launch behind every wide one (second launches
-// without the guard words: -4 %, the words without the launches: -1 %: profiles/r06k_guard_parts_ab.txt).
+// without the guard words: -4 %, the words without the launches: -1 %: profiles/r06k_guard_parts_ab.txt): in the loop such a launch
+// takes 14.5 us against 4.8 us alone (profiles/r06m_queue_gaps.txt) -- this kernel needs a CU of its own (100 KB of LDS, 8 waves of
+// 221 registers), which other pairs' wide tiles hold; a one-wave empty kernel behind EVERY op of the forward costs 1-2 %
+// (profiles/r06l_dummy_launch_ab.txt).  The second pass as a second BODY inside the first launch, tile by tile (no launch at all),
+// makes the first body 7-15 % slower (37-42 k instructions: profiles/r06n_guard_second_body_ab.txt), like the two contraction loops
+// of profiles/r06b_*: the second launch stays.
 template <int WGN, int F_LDS, int NB, int PL>
 __device__ __forceinline__ void gconv3_guard_loop(const GParams &p) {
     if (!guard_tripped(p.a_amax, p.a_guard)) return;
