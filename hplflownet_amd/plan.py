@@ -545,17 +545,6 @@ class ForwardPlan(object):
                 return False
         return True
 
-    def _phase_cut(self):
-        if not os.environ.get('HPL_PHASE_SPLIT'):
-            return 0
-        c = getattr(self, '_cut', None)
-        if c is None:
-            c = next((i for i, o in enumerate(self.prog.ops) if o.tag == TAG_WIDE_BLUR), 0)
-            c = max(0, c - int(os.environ.get('HPL_PHASE_BACK', '0')))
-            self._cut = c
-            self._lo_streams = {}
-        return c
-
     def workspace(self, nbytes, dev):
         """Round-robin workspaces: a forward's activations must survive until it has run; the caller's streams are
         ordered by events recorded behind each run."""
@@ -588,32 +577,8 @@ class ForwardPlan(object):
         slot, ws = self.workspace(need, p1.device)
         self._wait_images()
         out = torch.empty((p1.shape[1], 3), dtype=torch.float32, device=p1.device)
-        cut = self._phase_cut()
-        if cut:
-            # EXPERIMENT (HPL_PHASE_SPLIT=1): the launch-bound first part of the forward on the caller's (high-priority) stream,
-            # everything from the first wide stencil conv on a normal-priority stream of its own
-            hi = torch.cuda.current_stream()
-            lo = self._lo_streams.get(hi.cuda_stream)
-            if lo is None:
-                lo = self._lo_streams[hi.cuda_stream] = torch.cuda.Stream(device=p1.device, priority=int(os.environ.get('HPL_PHASE_LO_PRIO', '0')))
-            n_ops = len(self.prog.ops)
-
-            def run(a, b, st):
-                check(self._lib.hpl_plan_run_range(self.handle, arr, nlev, ptr(p1), ptr(p2), None, ptr(out), None, ws.data_ptr(), ws.numel(),
-                                                   st, None, a, b, 1), 'hpl_plan_run_range')
-            run(0, cut, hi.cuda_stream)
-            e1 = torch.cuda.Event()
-            e1.record(hi)
-            lo.wait_event(e1)
-            run(cut, n_ops, lo.cuda_stream)
-            e2 = torch.cuda.Event()
-            e2.record(lo)
-            hi.wait_event(e2)
-            out.record_stream(lo)
-            ws.record_stream(lo)
-        else:
-            check(self._lib.hpl_plan_run(self.handle, arr, nlev, ptr(p1), ptr(p2), ptr(out), ws.data_ptr(), ws.numel(),
-                                         stream()), 'hpl_plan_run')
+        check(self._lib.hpl_plan_run(self.handle, arr, nlev, ptr(p1), ptr(p2), ptr(out), ws.data_ptr(), ws.numel(),
+                                     stream()), 'hpl_plan_run')
         ev = torch.cuda.Event()
         ev.record()
         self._fence[slot] = ev
