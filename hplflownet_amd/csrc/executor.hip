@@ -114,7 +114,7 @@ struct hpl_plan {
     size_t fence_used = 0;
     // largest magnitudes reduced so far in this run (hpl_amax of a view, valid until an op writes the matrix): the wide launches
     // that read the same view share one reduction; a training step keeps them from its forward range to its backward ranges
-    struct AmaxEnt { int buf; int64_t row_off, rows; int col_off, cols; const float *slot; };
+    struct AmaxEnt { int buf; int64_t row_off, rows; int col_off, cols; const float *slot; bool guarded; };      // guarded: the slot's second word is the view's guard word
     std::vector<AmaxEnt> amax;
     int amax_used = 0;
     int32_t *guard_trips = nullptr;         // device counter: launches that took the range guard's second pass (allocated at the first run)
@@ -170,17 +170,21 @@ struct Runner {
     float *amax_base = nullptr;             // AMAX_SLOTS scalars in the workspace (cleared when a run starts at op 0)
     const float *cur_a_amax = nullptr, *cur_b_amax = nullptr;      // of the op being issued (prepare_amax)
     float *cur_y_amax = nullptr;            // where the op being issued leaves the largest magnitude of what it writes (or null)
+    bool cur_y_guarded = false;             // ... and the guard word of what it writes beside it
 
     // the largest magnitude of columns [0, cols) of a view, reduced on the MAIN stream unless this run already has it
-    int amax_of(const hpl_ref &r, const View &v, int64_t rows, int cols, const float *&slot) {
+    // (guard: the consumer is a guarded launch -- the reduction also leaves the view's guard word, hpl_amax_rows; a reduction kept from
+    // an unguarded consumer is not reused for a guarded one)
+    int amax_of(const hpl_ref &r, const View &v, int64_t rows, int cols, const float *&slot, bool guard) {
         const int64_t off = r.buf >= 0 ? symv(sym, r.row_off_sym) : 0;
+        guard = guard && range_guard() && range_guard_mode() != 3;
         for (const auto &e : pl.amax)
-            if (e.buf == r.buf && e.row_off == off && e.rows == rows && e.col_off == r.col_off && e.cols == cols) { slot = e.slot; return HPL_OK; }
+            if (e.buf == r.buf && e.row_off == off && e.rows == rows && e.col_off == r.col_off && e.cols == cols && (e.guarded || !guard)) { slot = e.slot; return HPL_OK; }
         HPL_REQUIRE(pl.amax_used < AMAX_SLOTS, "hpl_plan_run: more than %d operand reductions in one run", AMAX_SLOTS);
         float *dst = amax_base + 2 * pl.amax_used++;
-        const int rc = hpl_gc::amax_launch(v.p, v.ld, rows, cols, dst, main_s, (range_guard() && range_guard_mode() != 3) ? reinterpret_cast<unsigned *>(dst + 1) : nullptr);
+        const int rc = hpl_gc::amax_launch(v.p, v.ld, rows, cols, dst, main_s, guard ? reinterpret_cast<unsigned *>(dst + 1) : nullptr);
         if (rc) return rc;
-        if (r.buf >= 0) pl.amax.push_back({r.buf, off, rows, r.col_off, cols, dst});
+        if (r.buf >= 0) pl.amax.push_back({r.buf, off, rows, r.col_off, cols, dst, guard});
         slot = dst;
         return HPL_OK;
     }
@@ -196,15 +200,18 @@ struct Runner {
     // the op just issued left the largest magnitude of rows [off, off + rows) x its N columns of `out` in cur_y_amax
     void amax_produced(const hpl_op &op) {
         if (!cur_y_amax || op.out.buf < 0) return;
-        pl.amax.push_back({op.out.buf, symv(sym, op.out.row_off_sym), symv(sym, op.m_sym), op.out.col_off, op.N, cur_y_amax});
+        pl.amax.push_back({op.out.buf, symv(sym, op.out.row_off_sym), symv(sym, op.m_sym), op.out.col_off, op.N, cur_y_amax, cur_y_guarded});
         cur_y_amax = nullptr;
     }
+    // the range guard covers the forward: the data gradients of the training program carry HPL_FLAG_NOGUARD (include/hpl_bcl.h)
+    static bool guarded(const hpl_op &op) { return range_guard() && !(op.flags & HPL_FLAG_NOGUARD); }
     float *amax_slot() { return pl.amax_used < AMAX_SLOTS ? amax_base + 2 * pl.amax_used++ : nullptr; }
     // wide launches in the fp16-pair mode scale their operands by their largest magnitudes: reduce them (main stream, before a
     // side-stream op is fenced) for the ops that can qualify (gconv_common.h split3_maybe / wgrad3.hip's test)
     int prepare_amax(const hpl_op &op, bool side) {
         cur_a_amax = cur_b_amax = nullptr;
         cur_y_amax = nullptr;
+        cur_y_guarded = false;
         if (hpl_gc::split_planes() != 2) return HPL_OK;
         View A, B;
         int rc;
@@ -217,7 +224,7 @@ struct Runner {
             const int64_t M = symv(sym, op.m_sym);
             if ((op.flags & HPL_FLAG_SCATTER) || !hpl_gc::split3_maybe(M, op.C, op.F > 15 ? 15 : op.F, op.N)) return HPL_OK;
             if ((rc = view(op.a, A, "gconv input"))) return rc;
-            if ((rc = amax_of(op.a, A, A.rows, op.C, cur_a_amax))) return rc;
+            if ((rc = amax_of(op.a, A, A.rows, op.C, cur_a_amax, guarded(op)))) return rc;
             // a wide launch's result usually feeds the next wide launch (the 1x1 convs behind a blur conv): its epilogue reduces it
             if (!side && op.out.buf >= 0 && op.N >= 128) cur_y_amax = amax_slot();
             return HPL_OK;
@@ -227,8 +234,8 @@ struct Runner {
             const bool taps = (op.flags & HPL_FLAG_TAPS) && op.table == HPL_TBL_BLUR0;
             if (!(op.N >= 256 && op.C >= 128 && M >= 8192 && (taps || (op.F == 1 && op.table == HPL_TBL_NONE)))) return HPL_OK;
             if ((rc = view(op.a, A, "wgrad input")) || (rc = view(op.b, B, "wgrad output gradient"))) return rc;
-            if ((rc = amax_of(op.a, A, A.rows, op.C, cur_a_amax))) return rc;
-            return amax_of(op.b, B, M, op.N, cur_b_amax);
+            if ((rc = amax_of(op.a, A, A.rows, op.C, cur_a_amax, false))) return rc;
+            return amax_of(op.b, B, M, op.N, cur_b_amax, false);
         }
         return HPL_OK;
     }
@@ -379,7 +386,10 @@ struct Runner {
             }
             d.Y = Y.p; d.ldy = Y.ld;
             if (last && has_out2) { d.Y2 = Y2.p; d.ldy2 = Y2.ld; d.rows2 = rows2; }
-            if (last && cur_y_amax && !scatter) { d.y_amax = cur_y_amax; if (range_guard() && range_guard_mode() < 3) d.y_guard = reinterpret_cast<uint32_t *>(cur_y_amax + 1); }
+            if (last && cur_y_amax && !scatter) {
+                d.y_amax = cur_y_amax;
+                if (guarded(op) && range_guard_mode() < 3) { d.y_guard = reinterpret_cast<uint32_t *>(cur_y_amax + 1); cur_y_guarded = true; }
+            }
             d.row_perm = row_perm;
             if (row_perm && ti && tm) { d.tile_idx = ti; d.tile_mask = tm; d.tile_bm = ngroups >= 2 ? t.group_tile_bm : t.tile_bm; }
             // split-operand image of the same rows (csrc/gconv3.hip takes the launch if it qualifies): k-blocks of 8 rows
@@ -388,7 +398,7 @@ struct Runner {
                 d.wt3_plane_stride = w.wt3_plane_stride;
                 d.wt3_planes = w.wt3_planes;
                 d.a_amax = cur_a_amax; d.w_amax = w.w_amax;
-                if (cur_a_amax && range_guard() && range_guard_mode() != 2) { d.a_guard = reinterpret_cast<const uint32_t *>(cur_a_amax + 1); d.guard_trips = pl.guard_trips; }
+                if (cur_a_amax && guarded(op) && range_guard_mode() != 2) { d.a_guard = reinterpret_cast<const uint32_t *>(cur_a_amax + 1); d.guard_trips = pl.guard_trips; }
             }
             if (prof) d.clock_probe = pl.clock_probe;
             if (scatter) { d.scat = t.corr2; d.scat_stride = 15 * t.H0; d.scat_c = op.aux; }

@@ -415,6 +415,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
         const bool plain = p.splits <= 1;
         const bool res_wrap = p.res && p.res_mod < p.M;      // (uniform)
         const float res_inv = res_wrap ? 1.0f / (float)p.res_mod : 0.f;
+        const bool has_res = p.res != nullptr && plain, has_y2 = p.Y2 != nullptr && plain;      // (uniform)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -428,31 +429,38 @@ __global__ void __launch_bounds__(64 * WGM * WGN, COMPACT ? 6 : 1) k_gconv(const
                     const int32x4v mv = *reinterpret_cast<const int32x4v *>(Vs + wm * WTM + i * 32 + 8 * q + 4 * hi);
                     mrow[4 * q + 0] = mv.x; mrow[4 * q + 1] = mv.y; mrow[4 * q + 2] = mv.z; mrow[4 * q + 3] = mv.w;
                 }
+                // (round 6: a launch without a residual issues no residual loads -- it used to load 16 out-of-range words and wait for them
+                // in front of its stores, a memory round trip per block for nothing -- and one without a second destination no second
+                // stores: csrc/gconv3.hip's epilogue, profiles/r06r_tile_phase_probe.txt)
                 float rv[16];
+                if (has_res) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int rr = mrow[r];
-                    if (res_wrap) {              // residual row = m % res_mod (the correlation layer: rows f * H + v add row v): m < 2^24 is
-                        // exact in fp32, the quotient by reciprocal is off by at most one
-                        const int q = (int)((float)rr * res_inv);
-                        rr -= (int)__umul24((unsigned)q, (unsigned)p.res_mod);
-                        rr = rr < 0 ? rr + (int)p.res_mod : (rr >= (int)p.res_mod ? rr - (int)p.res_mod : rr);
+                    for (int r = 0; r < 16; ++r) {
+                        int rr = mrow[r];
+                        if (res_wrap) {          // residual row = m % res_mod (the correlation layer: rows f * H + v add row v): m < 2^24 is
+                            // exact in fp32, the quotient by reciprocal is off by at most one
+                            const int q = (int)((float)rr * res_inv);
+                            rr -= (int)__umul24((unsigned)q, (unsigned)p.res_mod);
+                            rr = rr < 0 ? rr + (int)p.res_mod : (rr >= (int)p.res_mod ? rr - (int)p.res_mod : rr);
+                        }
+                        const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)rr, ldr_b) + nb : OOB_E;
+                        rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)ro, 0, 0));
                     }
-                    const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)rr, ldr_b) + nb : OOB_E;
-                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)ro, 0, 0));
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r];
                     if (plain) {
                         v = v + bsv;
-                        if (p.res) v += rv[r];
+                        if (has_res) v += rv[r];
                         if (p.act == HPL_ACT_LEAKY) v = v > 0.f ? v : p.slope * v;
                     }
                     const unsigned yo = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldy_b) + nb : OOB_E;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (int)yo, 0, 0);
-                    const unsigned y2o = (mrow[r] >= 0 && mrow[r] < (int)p.rows2) ? __umul24((unsigned)mrow[r], ldy2_b) + nb : OOB_E;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y2, (int)y2o, 0, 0);
+                    if (has_y2) {
+                        const unsigned y2o = (mrow[r] >= 0 && mrow[r] < (int)p.rows2) ? __umul24((unsigned)mrow[r], ldy2_b) + nb : OOB_E;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y2, (int)y2o, 0, 0);
+                    }
                 }
             }
     } else
@@ -615,7 +623,7 @@ int hpl_gc::fill_params(const hpl_gconv_desc *d, GParams &p, const char *who) {
     HPL_REQUIRE(!d->Wt3 || d->wt3_planes == 0 || d->wt3_planes == 2 || d->wt3_planes == 3, "%s: wt3_planes = %d", who, d->wt3_planes);
     if (p.planes == 2 && !(p.a_amax && p.w_amax)) p.Wt3 = nullptr;      // fp16 pairs need both scales: the launch stays on the fp32 MFMA
     p.y_amax = d->y_amax; p.y_amax_done = 0;
-    p.a_guard = d->a_guard; p.y_guard = d->y_guard; p.guard_trips = d->guard_trips; p.guard_partials = 0; p.guard_grid = 0;
+    p.a_guard = d->a_guard; p.y_guard = d->y_guard; p.guard_trips = d->guard_trips; p.guard_partials = 0;
     HPL_REQUIRE(!(d->y_amax && d->scat), "%s: y_amax with a scatter epilogue", who);
     p.col_share = 0; p.col_rows = 0;
     p.tiles_m = p.tiles_n = 0;

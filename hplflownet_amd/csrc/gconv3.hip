@@ -108,7 +108,6 @@ __device__ __forceinline__ void split2h_resid(float x0, float x1, float s, unsig
 }
 
 constexpr int BM3 = 128;
-constexpr int GUARD_WGS = 256;          // workgroups of a guard launch (k_gconv3 / k_gconv3w with GUARD)
 
 // NB = stages of the weight-fragment ring (3 or 4); the gathered rows use NB - 1 register sets: with NB = 4 every load has one
 // more half-step to land (the end-of-half-step wait then leaves the loads of TWO half-steps in flight)
@@ -701,38 +700,63 @@ __device__ __forceinline__ void gconv3_body(const GParams &p, const unsigned blo
         const bool want_guard = p.y_guard && p.y_amax && plain && !defer;      // (uniform)
         const bool res_wrap = p.res && p.res_mod < p.M;      // (uniform)
         const float res_inv = res_wrap ? 1.0f / (float)p.res_mod : 0.f;
+        // Round 6 (profiles/r06r_tile_phase_probe.txt: the epilogue took 19.4 k cycles of EVERY tile, 19 % of a dense one): each of the
+        // four 32 x 32 blocks loaded its 16 residual values and waited for them before its stores -- behind the 32 stores of the
+        // block before (one counter for loads and stores): four store -> acknowledge -> load round trips per tile, also in launches
+        // WITHOUT a residual (loads at an out-of-range offset).  Now: no residual (uniform), no loads and no wait -- the stores stream;
+        // with one, all 64 loads are issued before the first store: one round trip.  The second destination is stored only if there is one.
+        const bool has_res = p.res != nullptr && plain;     // (uniform; split-K partials are stored raw)
+        const bool has_y2 = p.Y2 != nullptr && plain && !defer;      // (uniform)
+        auto rows_of = [&](int i, int (&mrow)[16]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int q = 0; q < 4; ++q) {
+                const int32x4v mv = *reinterpret_cast<const int32x4v *>(Vs + wm * 64 + i * 32 + 8 * q + 4 * hi);
+                mrow[4 * q + 0] = mv.x; mrow[4 * q + 1] = mv.y; mrow[4 * q + 2] = mv.z; mrow[4 * q + 3] = mv.w;
+            }
+        };
+        float rv[2][2][16];
+        auto load_res = [&](int i, int j, const int (&mrow)[16]) {
+            const int n = n0 + wn * 64 + j * 32 + li;
+            const unsigned nb = n < p.N ? (unsigned)n * 4u : OOB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int rr = mrow[r];
+                if (res_wrap) {          // residual row = m % res_mod (the correlation layer: rows f * H + v add row v): m < 2^24 is
+                    // exact in fp32, the quotient by reciprocal is off by at most one
+                    const int q = (int)((float)rr * res_inv);
+                    rr -= (int)__umul24((unsigned)q, (unsigned)p.res_mod);
+                    rr = rr < 0 ? rr + (int)p.res_mod : (rr >= (int)p.res_mod ? rr - (int)p.res_mod : rr);
+                }
+                const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)rr, ldr_b) + nb : OOB;
+                rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)ro, 0, 0));
+            }
+        };
+        constexpr bool HOIST = true;
+        if (HOIST && has_res) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int mrow[16];
+                rows_of(i, mrow);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) load_res(i, j, mrow);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int mrow[16];
+            rows_of(i, mrow);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 64 + j * 32 + li;
                 const unsigned nb = n < p.N ? (unsigned)n * 4u : OOB;
                 const float bsv = (p.bias && plain && n < p.N) ? p.bias[n] : 0.f;
-                int mrow[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int32x4v mv = *reinterpret_cast<const int32x4v *>(Vs + wm * 64 + i * 32 + 8 * q + 4 * hi);
-                    mrow[4 * q + 0] = mv.x; mrow[4 * q + 1] = mv.y; mrow[4 * q + 2] = mv.z; mrow[4 * q + 3] = mv.w;
-                }
-                float rv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int rr = mrow[r];
-                    if (res_wrap) {              // residual row = m % res_mod (the correlation layer: rows f * H + v add row v): m < 2^24 is
-                        // exact in fp32, the quotient by reciprocal is off by at most one
-                        const int q = (int)((float)rr * res_inv);
-                        rr -= (int)__umul24((unsigned)q, (unsigned)p.res_mod);
-                        rr = rr < 0 ? rr + (int)p.res_mod : (rr >= (int)p.res_mod ? rr - (int)p.res_mod : rr);
-                    }
-                    const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)rr, ldr_b) + nb : OOB;
-                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)ro, 0, 0));
-                }
+                if (!HOIST && has_res) load_res(i, j, mrow);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r];
                     if (plain) {
                         v = v + bsv;
-                        if (p.res) v += rv[r];
+                        if (has_res) v += rv[i][j][r];
                         if (p.act == HPL_ACT_LEAKY && !defer) v = v > 0.f ? v : p.slope * v;
                     }
                     const unsigned yo = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldy_b) + nb : OOB;
@@ -743,10 +767,13 @@ __device__ __forceinline__ void gconv3_body(const GParams &p, const unsigned blo
                         gmin = rm ? min(gmin, rm) : gmin;
                     }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (int)yo, 0, 0);
-                    const unsigned y2o = (mrow[r] >= 0 && mrow[r] < (int)p.rows2 && !defer) ? __umul24((unsigned)mrow[r], ldy2_b) + nb : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y2, (int)y2o, 0, 0);
+                    if (has_y2) {
+                        const unsigned y2o = (mrow[r] >= 0 && mrow[r] < (int)p.rows2) ? __umul24((unsigned)mrow[r], ldy2_b) + nb : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y2, (int)y2o, 0, 0);
+                    }
                 }
             }
+        }
         if (p.y_amax && plain && !defer) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ymax = max(ymax, (unsigned)__shfl_xor((int)ymax, o));
@@ -802,37 +829,24 @@ __device__ __forceinline__ void gconv3_body(const GParams &p, const unsigned blo
     }
 }
 
-// A guard launch is PERSISTENT: min(tiles, GUARD_WGS) workgroups, workgroup b takes the tiles b, b + gridDim.x, ... (GUARD_WGS is a
-// multiple of 8: a tile stays on the XCD the launch order gives it).  It almost always leaves at once.  What it costs the pipelined
-// loop then does not depend on its size (8 / 32 / 128 / 1024 workgroups: 438-462 / 444-457 / 444-455 / 432-459 pairs/s, without
-// the guard 474-478: profiles/r06j_guard_wgs_ab.txt) -- it is the extra dependent launch behind every wide one (second launches
-// without the guard words: -4 %, the words without the launches: -1 %: profiles/r06k_guard_parts_ab.txt): in the loop such a launch
-// takes 14.5 us against 4.8 us alone (profiles/r06m_queue_gaps.txt) -- this kernel needs a CU of its own (100 KB of LDS, 8 waves of
-// 221 registers), which other pairs' wide tiles hold; a one-wave empty kernel behind EVERY op of the forward costs 1-2 %
-// (profiles/r06l_dummy_launch_ab.txt).  The second pass as a second BODY inside the first launch, tile by tile (no launch at all),
-// makes the first body 7-15 % slower (37-42 k instructions: profiles/r06n_guard_second_body_ab.txt), like the two contraction loops
-// of profiles/r06b_*: the second launch stays.
-template <int WGN, int F_LDS, int NB, int PL>
-__device__ __forceinline__ void gconv3_guard_loop(const GParams &p) {
-    if (!guard_tripped(p.a_amax, p.a_guard)) return;
-    for (unsigned b = blockIdx.x; b < (unsigned)p.guard_grid; b += gridDim.x) {
-        gconv3_body<WGN, F_LDS, NB, PL, true>(p, b);
-        __builtin_amdgcn_s_waitcnt(0);          // (the next tile's hand-counted load waits start from an empty queue)
-        __syncthreads();                        // (its prologue rewrites the LDS tables this tile's epilogue read)
-    }
-}
-
+// The guard's second launch (GUARD = true) has the grid of the first and almost always leaves at once.  What it costs the pipelined
+// loop then does not depend on its size (a persistent form of 8 / 32 / 128 / 1024 workgroups: 438-462 / 444-457 / 444-455 / 432-459
+// pairs/s, without the guard 474-478: profiles/r06j_guard_wgs_ab.txt; the persistent form needed 253-256 registers and is gone) -- it
+// is the extra dependent launch behind every wide one (second launches without the guard words: -4 %, the words without the
+// launches: -1 %: profiles/r06k_guard_parts_ab.txt): in the loop such a launch takes 14.5 us against 4.8 us alone
+// (profiles/r06m_queue_gaps.txt) -- this kernel needs a CU of its own (100 KB of LDS, 8 waves of 221 registers), which other pairs'
+// wide tiles hold; a one-wave empty kernel behind EVERY op of the forward costs 1-2 % (profiles/r06l_dummy_launch_ab.txt).  The
+// second pass as a second BODY inside the first launch, tile by tile (no launch at all), makes the first body 7-15 % slower (37-42 k
+// instructions: profiles/r06n_guard_second_body_ab.txt), like the two contraction loops of profiles/r06b_*: the second launch stays.
 template <int WGN, int F_LDS, int PL, int NB = 3, bool GUARD = false>
 __global__ void __launch_bounds__(128 * WGN, 2) k_gconv3(const GParams p) {
-    if constexpr (GUARD) gconv3_guard_loop<WGN, F_LDS, NB, PL>(p);
-    else gconv3_body<WGN, F_LDS, NB, PL, false>(p, blockIdx.x);
+    gconv3_body<WGN, F_LDS, NB, PL, GUARD>(p, blockIdx.x);
 }
 
 // the 8-wave tile (128 x 256, ping-pong wave rows): one workgroup per CU
 template <int F_LDS, int NB, int PL, bool GUARD = false>
 __global__ void __launch_bounds__(512, 2) k_gconv3w(const GParams p) {
-    if constexpr (GUARD) gconv3_guard_loop<4, F_LDS, NB, PL>(p);
-    else gconv3_body<4, F_LDS, NB, PL, false>(p, blockIdx.x);
+    gconv3_body<4, F_LDS, NB, PL, GUARD>(p, blockIdx.x);
 }
 
 // Wt [k_rows][ldw] fp32 -> three bf16 planes [k_rows/8][ldw][8]
@@ -1208,8 +1222,7 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
             // the guard's second launch: the same tiles on the residuals; it adds what the first launch stored and finishes.
             // (It leaves at once when the operand has no quiet row: an empty launch of this grid, 2-3 us.)
             GParams q = p;
-            q.guard_grid = grid;
-            const int ggrid = (int)imin(grid, GUARD_WGS);
+            const int ggrid = grid;
             if (p.splits > 1) { q.partial = p.partial + (int64_t)p.splits * p.M * p.N; p.guard_partials = 1; }      // a second set of partial tiles (k_gconv_finish adds both)
             else { q.res = p.Y; q.ldres = p.ldy; q.res_mod = p.M; q.bias = nullptr; }
             if (bn256) {

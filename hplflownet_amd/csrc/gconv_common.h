@@ -80,7 +80,6 @@ struct GParams {
     const float *a_amax; const float *w_amax;      //   DEVICE scalars (hpl_amax; hpl_weight_split2h)
     float *y_amax; int y_amax_done;     // optional: largest |Y| stored -> *y_amax (done = 1: the kernel's epilogue did it)
     const unsigned *a_guard; unsigned *y_guard; int *guard_trips;      // range guard of the pair form (hpl_gconv_desc.a_guard ...)
-    int guard_grid;                     // guard launches are persistent: workgroup b takes the tiles b, b + gridDim.x, ... of this many
     int guard_partials;                 // split-K launch with a guarded operand: a tripped guard leaves a SECOND set of `splits` partial tiles
     int epi_fast;                       // 32-bit buffer addressing in the epilogue (set by the launch functions)
 };

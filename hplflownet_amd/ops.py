@@ -613,7 +613,7 @@ MAX_TAPS_PER_PASS = 15      # hpl_gconv_forward: F <= 15 (LDS-staged index table
 
 
 def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, res=None, res_mod=0, out=None,
-                 slope=LEAKY_RATE, row_perm=None, reg_stride=0, tiles=None):
+                 slope=LEAKY_RATE, row_perm=None, reg_stride=0, tiles=None, guard=True):
     """gconv_raw, run as one pass per tap group when `groups` = [(f0, f1, perm), ...] is given: pass i
     contracts taps [f0, f1) (rows f0*C.. of Wt, rows f0.. of the table) in its own row order and adds
     to the output of the passes before it; bias / residual enter the first pass, the activation the last."""
@@ -627,7 +627,7 @@ def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, r
     if not groups or not (nbr is not None or regular) or len(groups) < 2:
         return gconv_raw(A, nbr, M, C, F, Wt, N, bias=bias, act=act, res=res, res_mod=res_mod, out=out, slope=slope,
                          row_perm=row_perm, reg_stride=reg_stride, tiles=tiles if not isinstance(tiles, list) else None,
-                         Wt3=W3)
+                         Wt3=W3, guard=guard)
     y = out
     gt = tiles if isinstance(tiles, list) and len(tiles) == len(groups) else [None] * len(groups)
     for i, (f0, f1, perm) in enumerate(groups):
@@ -639,7 +639,7 @@ def gconv_passes(A, nbr, M, C, F, Wt, N, groups=None, bias=None, act=ACT_NONE, r
                       Wt[f0 * C:], N, bias=bias if first else None,
                       act=act if last else ACT_NONE, res=res if first else y, res_mod=res_mod if first else 0,
                       out=y, slope=slope, row_perm=perm, reg_stride=reg_stride, tiles=gt[i] if perm is not None else None,
-                      Wt3=w3)
+                      Wt3=w3, guard=guard)
     return y
 
 
@@ -718,12 +718,12 @@ class GConvFn(torch.autograd.Function):
                 WtT = _train_relayout(weight, O, C, 1, Ctot * F, F, 1, base=c0 * F)
                 # wide 1x1 layers: the data gradient is a dense GEMM of the same class as their forward (split operands)
                 W3 = split3_of(WtT) if (SPLIT3 and C >= SPLIT3_MIN_N and O >= SPLIT3_MIN_C) else None
-                gA_c = gconv_raw(g, None, M, O, 1, WtT, C, Wt3=W3)
+                gA_c = gconv_raw(g, None, M, O, 1, WtT, C, Wt3=W3, guard=False)       # (gradients run unguarded: HPL_FLAG_NOGUARD)
             elif bwd_mode == 'mirror':
                 if rows != M:
                     raise _lib.HplError('mirror backward needs a table over the same vertex set')
                 WtT = _train_relayout(weight, O, C, F, Ctot * F, F, 1, base=c0 * F, mirror=True)
-                gA_c = gconv_passes(g, nbr, M, O, F, WtT, C, ctx.groups, row_perm=ctx.row_perm, tiles=ctx.tiles)
+                gA_c = gconv_passes(g, nbr, M, O, F, WtT, C, ctx.groups, row_perm=ctx.row_perm, tiles=ctx.tiles, guard=False)
             else:   # scatter: G[m, (f, c)] = g[m] . W[:, c, f], added into row nbr[f, m]
                 # columns ordered (f, c): source element (o, f*C + c) = W[o, c0 + c, f]
                 Wcols = weight.view(O, Ctot, F)[:, c0:c0 + C, :].permute(0, 2, 1).reshape(O, F * C).contiguous()

@@ -29,7 +29,7 @@ from .plan import (BUF_OUT, ForwardPlan, ORD_NONE, OP_GCONV, OP_GSUM, OP_INVERT,
 
 OP_WGRAD, OP_LEAKY_BWD, OP_COLSUM, OP_SPLAT_BWD, OP_PSUM, OP_REGROUP, OP_ZERO, OP_EPE3D, OP_VCOPY, OP_UNLAYOUT = range(6, 16)
 OP_SPLAT, OP_COPY = 2, 4
-F_ACCUM, F_SCATTER, F_TAPS, F_SIDE, F_INVERSE = 1, 2, 4, 8, 16
+F_ACCUM, F_SCATTER, F_TAPS, F_SIDE, F_INVERSE, F_NOGUARD = 1, 2, 4, 8, 16, 32
 
 
 class _Sim(object):
@@ -177,7 +177,7 @@ class _Backward(object):
         self._touch(w)
         ga = self.G(a)
         wid = self._bank(w, O, C, F, Ctot * F, F, 1, c0 * F, 0)               # rows (k*O + o), columns c
-        P.gconv(g, ga, M, F * O, C, wid, flags=F_ACCUM if sim.claim(ga, cond) else 0)
+        P.gconv(g, ga, M, F * O, C, wid, flags=F_NOGUARD | (F_ACCUM if sim.claim(ga, cond) else 0))
 
     def _gsum(self, m):
         P, sim, cond = self.P, self.sim, m['cond']
@@ -253,20 +253,20 @@ class _Backward(object):
         tbl = m['table']
         if tbl == TBL_NONE:
             wid = self._bank(w, O, C, 1, sr, sq, 1, base, 0)
-            P.gconv(g, ga, M, O, C, wid, flags=F_ACCUM if sim.claim(ga, cond) else 0)
+            P.gconv(g, ga, M, O, C, wid, flags=F_NOGUARD | (F_ACCUM if sim.claim(ga, cond) else 0))
         elif tbl in (TBL_BLUR_PAIR, TBL_BLUR0, TBL_CORR1):          # symmetric table over the same vertex set: mirrored taps
             wid = self._bank(w, O, C, F, sr, sq, 1, base, 1)
             P.gconv(g, ga, M, O, C, wid, F=F, level=m['level'], table=tbl, order=m['order'], tag=m['tag'],
-                    flags=F_ACCUM if sim.claim(ga, cond) else 0)
+                    flags=F_NOGUARD | (F_ACCUM if sim.claim(ga, cond) else 0))
         elif tbl == TBL_CORR2:                                      # G[m, (f, c)] = g[m] . W[:, c, f], added into row corr2[f, m]
             wid = self._bank(w, O, C, F, sr, sq, 1, base, 2)
             if not sim.claim(ga, cond):
                 P.raw(OP_ZERO, out=ga)
-            P.gconv(g, ga, M, O, F * C, wid, level=m['level'], flags=F_SCATTER, aux=C)
+            P.gconv(g, ga, M, O, F * C, wid, level=m['level'], flags=F_SCATTER | F_NOGUARD, aux=C)
         elif tbl == TBL_REGULAR:                                    # rows f*M + m are distinct: a GEMM and a regrouping
             wid = self._bank(w, O, C, F, sr, sq, 1, base, 2)
             tmp = P.buf(M, F * C)
-            P.gconv(g, tmp, M, O, F * C, wid)
+            P.gconv(g, tmp, M, O, F * C, wid, flags=F_NOGUARD)
             P.raw(OP_REGROUP, a=tmp, out=ga, M=M, F=F, C=C, flags=F_ACCUM if sim.claim(ga, cond) else 0)
         else:
             raise AssertionError('gconv through table kind %d has no backward' % tbl)

@@ -508,6 +508,9 @@ int hpl_lattice_next_points(const int32_t *vkeys, int64_t vstride, int64_t H, fl
 #define HPL_FLAG_TAPS 4       /* wgrad: sum over the per-tap vertex lists of the level's cloud-1 blur table (when the run has them) */
 #define HPL_FLAG_INVERSE 16   /* HPL_OP_GSUM: see there */
 #define HPL_FLAG_SIDE 8       /* the op is a leaf of the backward graph: it may run on the side stream of hpl_plan_run_range */
+#define HPL_FLAG_NOGUARD 32   /* gconv: the fp16-pair form of this op runs WITHOUT its range guard (hpl_gconv_desc.a_guard): the data gradients
+                                 of the training program -- a quiet row of a gradient matrix is a vertex whose share of every weight gradient
+                                 lies below the rounding of the sums; the guard would run their launches twice (round 6: 1.4 ms of a step) */
 
 #define HPL_TBL_NONE 0
 #define HPL_TBL_BLUR_PAIR 1   /* blur table of the stacked pair [15][H0+H1]          (Down convs) */
