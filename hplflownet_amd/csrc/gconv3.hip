@@ -76,18 +76,6 @@ __device__ __forceinline__ void split2h(float x0, float x1, float s, unsigned &h
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
-// Largest of an unsigned over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), in every lane of the row: four v_max_u32 with a DPP
-// operand (quad xor 1, quad xor 2, half-row mirror, row mirror).  The guard word of the wide epilogue takes a row's maximum over the 16
-// columns these lanes hold; as five __shfl_xor steps per element (ds_bpermute_b32: 320 dependent LDS-pipe operations per lane and tile)
-// it cost 16-50 us per launch (dense 1x1 launches 72 -> 89, 77 -> 128 us: profiles/r06e_step_timeline_shfl_epilogue.txt against r05y_step_timeline.txt's).
-__device__ __forceinline__ unsigned dpp_row_max(unsigned v) {
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));       // quad_perm [1, 0, 3, 2]
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));       // quad_perm [2, 3, 0, 1]
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));      // row_half_mirror
-    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));      // row_mirror
-    return v;
-}
-
 // Second pass of the range guard (hpl_gconv_desc.a_guard): the residual of the first split, r = (x s - hi) - lo (both subtractions
 // exact in fp32), times 2^24, again as an fp16 pair.  |x s - hi| <= 2^3 and |r| <= 2^-9 for |x s| < 2^15, so r 2^24 <= 2^15 fits fp16;
 // for an element too small for a normal lo (|x s| < 2^-3) r is what the first pass lost: it is carried here to 2^-24 of ITS size.
@@ -468,11 +456,14 @@ __device__ __forceinline__ void gconv3_body(const GParams &p, const unsigned blo
             constexpr int NQ = PL == 3 ? 6 : 3;
             constexpr int PA[6] = {0, 0, 1, 0, PL == 3 ? 2 : 0, 1};
             constexpr int PB[6] = {0, 1, 0, PL == 3 ? 2 : 0, 0, 1};
+            // (the operands SWAPPED: the accumulators hold the 32 x 32 block TRANSPOSED -- lane l & 31 is the output row, register r the
+            // column (r & 3) + 8 (r >> 2) + 4 (l >> 5) -- so that four registers are four consecutive columns of a row: the epilogue
+            // moves 16 bytes per lane and instruction; both fragments have the same lane layout, the swap costs nothing)
             auto mfma = [&](const u32x4 &a, const u32x4 &b, floatx16 &c) {
                 if constexpr (PL == 3)
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
                 else
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
             };
             if constexpr (PP) {
                 // ---- memory phase: only what has to wait for the barrier -- the twelve fragment reads of this half-step.
@@ -696,82 +687,84 @@ __device__ __forceinline__ void gconv3_body(const GParams &p, const unsigned blo
         const unsigned ldy_b = (unsigned)(p.splits > 1 ? p.N : p.ldy) * 4u, ldr_b = (unsigned)p.ldres * 4u, ldy2_b = (unsigned)p.ldy2 * 4u;
         const bool plain = p.splits <= 1;
         unsigned ymax = 0;                                   // largest |y| this lane stores (p.y_amax)
-        unsigned gmin = 0xffffffffu;                         // smallest non-zero row maximum over 16 columns of a block (p.y_guard)
+        unsigned gmin = 0xffffffffu;                         // smallest non-zero row maximum over the wave's 64 columns (p.y_guard)
         const bool want_guard = p.y_guard && p.y_amax && plain && !defer;      // (uniform)
         const bool res_wrap = p.res && p.res_mod < p.M;      // (uniform)
         const float res_inv = res_wrap ? 1.0f / (float)p.res_mod : 0.f;
-        // Round 6 (profiles/r06r_tile_phase_probe.txt: the epilogue took 19.4 k cycles of EVERY tile, 19 % of a dense one): each of the
-        // four 32 x 32 blocks loaded its 16 residual values and waited for them before its stores -- behind the 32 stores of the
-        // block before (one counter for loads and stores): four store -> acknowledge -> load round trips per tile, also in launches
-        // WITHOUT a residual (loads at an out-of-range offset).  Now: no residual (uniform), no loads and no wait -- the stores stream;
-        // with one, all 64 loads are issued before the first store: one round trip.  The second destination is stored only if there is one.
+        // Round 6.  (a) profiles/r06r_tile_phase_probe.txt: the epilogue took 19.4 k cycles of EVERY tile (19 % of a dense one) -- each
+        // 32 x 32 block loaded its residual values (at an out-of-range offset when there is none) and waited for them behind the stores
+        // of the block before: four store -> acknowledge -> load round trips per tile.  Without a residual (uniform) there are no loads
+        // now, with one all of them are issued before the first store; the second destination is stored only if there is one: 13.8 k.
+        // (b) The accumulators are transposed (see mfma above): lane li holds output row wm * 64 + i * 32 + li, its registers 4 q .. 4 q + 3
+        // the columns 8 q + 4 hi .. + 3 of block (i, j) -- 16 accesses of 16 bytes per lane instead of 64 (+ 64) of 4.
         const bool has_res = p.res != nullptr && plain;     // (uniform; split-K partials are stored raw)
         const bool has_y2 = p.Y2 != nullptr && plain && !defer;      // (uniform)
-        auto rows_of = [&](int i, int (&mrow)[16]) {
+        int mrow[2];
+        unsigned yrow[2], rrow[2], y2row[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int32x4v mv = *reinterpret_cast<const int32x4v *>(Vs + wm * 64 + i * 32 + 8 * q + 4 * hi);
-                mrow[4 * q + 0] = mv.x; mrow[4 * q + 1] = mv.y; mrow[4 * q + 2] = mv.z; mrow[4 * q + 3] = mv.w;
+        for (int i = 0; i < 2; ++i) {
+            const int m = Vs[wm * 64 + i * 32 + li];
+            mrow[i] = m;
+            int rr = m;
+            if (res_wrap) {          // residual row = m % res_mod (the correlation layer: rows f * H + v add row v): m < 2^24 is exact in
+                // fp32, the quotient by reciprocal is off by at most one
+                const int q = (int)((float)rr * res_inv);
+                rr -= (int)__umul24((unsigned)q, (unsigned)p.res_mod);
+                rr = rr < 0 ? rr + (int)p.res_mod : (rr >= (int)p.res_mod ? rr - (int)p.res_mod : rr);
             }
-        };
-        float rv[2][2][16];
-        auto load_res = [&](int i, int j, const int (&mrow)[16]) {
-            const int n = n0 + wn * 64 + j * 32 + li;
-            const unsigned nb = n < p.N ? (unsigned)n * 4u : OOB;
+            yrow[i] = __umul24((unsigned)m, ldy_b);
+            rrow[i] = __umul24((unsigned)rr, ldr_b);
+            y2row[i] = __umul24((unsigned)m, ldy2_b);
+        }
+        // byte offset of columns n .. n + 3 of a row (OOB: row past M, column past N -- N % 4 == 0 on this path)
+        auto at = [&](int m, unsigned row_b, int n) { return (m >= 0 && n < p.N) ? row_b + (unsigned)n * 4u : OOB; };
+        auto col_of = [&](int j, int q) { return n0 + wn * 64 + j * 32 + 8 * q + 4 * hi; };
+        u32x4 rv[2][2][4];
+        if (has_res) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int rr = mrow[r];
-                if (res_wrap) {          // residual row = m % res_mod (the correlation layer: rows f * H + v add row v): m < 2^24 is
-                    // exact in fp32, the quotient by reciprocal is off by at most one
-                    const int q = (int)((float)rr * res_inv);
-                    rr -= (int)__umul24((unsigned)q, (unsigned)p.res_mod);
-                    rr = rr < 0 ? rr + (int)p.res_mod : (rr >= (int)p.res_mod ? rr - (int)p.res_mod : rr);
-                }
-                const unsigned ro = mrow[r] >= 0 ? __umul24((unsigned)rr, ldr_b) + nb : OOB;
-                rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)ro, 0, 0));
-            }
-        };
-        constexpr bool HOIST = true;
-        if (HOIST && has_res) {
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int mrow[16];
-                rows_of(i, mrow);
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) load_res(i, j, mrow);
-            }
+                    for (int q = 0; q < 4; ++q)
+                        rv[i][j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)at(mrow[i], rrow[i], col_of(j, q)), 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int mrow[16];
-            rows_of(i, mrow);
+            unsigned rowmax = 0;                             // largest |y| of this lane's row over its 32 columns of the wave's 64
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + li;
-                const unsigned nb = n < p.N ? (unsigned)n * 4u : OOB;
-                const float bsv = (p.bias && plain && n < p.N) ? p.bias[n] : 0.f;
-                if (!HOIST && has_res) load_res(i, j, mrow);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r];
-                    if (plain) {
-                        v = v + bsv;
-                        if (has_res) v += rv[i][j][r];
-                        if (p.act == HPL_ACT_LEAKY && !defer) v = v > 0.f ? v : p.slope * v;
+                for (int q = 0; q < 4; ++q) {
+                    const int n = col_of(j, q);
+                    float4_t bs = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias && plain && n < p.N) bs = *reinterpret_cast<const float4_t *>(p.bias + n);
+                    float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    const float bb[4] = {bs.x, bs.y, bs.z, bs.w};
+                    const unsigned rr4[4] = {rv[i][j][q].x, rv[i][j][q].y, rv[i][j][q].z, rv[i][j][q].w};
+                    u32x4 o;
+                    unsigned ob[4];
+                    const bool live = mrow[i] >= 0 && n < p.N;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float x = v[c];
+                        if (plain) {
+                            x = x + bb[c];
+                            if (has_res) x += __builtin_bit_cast(float, rr4[c]);
+                            if (p.act == HPL_ACT_LEAKY && !defer) x = x > 0.f ? x : p.slope * x;
+                        }
+                        ob[c] = __builtin_bit_cast(unsigned, x);
+                        const unsigned av = live ? (ob[c] & 0x7fffffffu) : 0u;
+                        ymax = max(ymax, av);
+                        rowmax = max(rowmax, av);
                     }
-                    const unsigned yo = mrow[r] >= 0 ? __umul24((unsigned)mrow[r], ldy_b) + nb : OOB;
-                    const unsigned av = (mrow[r] >= 0 && n < p.N) ? (__builtin_bit_cast(unsigned, v) & 0x7fffffffu) : 0u;
-                    ymax = max(ymax, av);
-                    if (want_guard) {            // the row's maximum over 16 of the block's columns (one DPP row of lanes)
-                        const unsigned rm = dpp_row_max(av);
-                        gmin = rm ? min(gmin, rm) : gmin;
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, (int)yo, 0, 0);
-                    if (has_y2) {
-                        const unsigned y2o = (mrow[r] >= 0 && mrow[r] < (int)p.rows2) ? __umul24((unsigned)mrow[r], ldy2_b) + nb : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y2, (int)y2o, 0, 0);
-                    }
+                    o.x = ob[0]; o.y = ob[1]; o.z = ob[2]; o.w = ob[3];
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, (int)at(mrow[i], yrow[i], n), 0, 0);
+                    if (has_y2) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y2, (int)at(mrow[i] < (int)p.rows2 ? mrow[i] : -1, y2row[i], n), 0, 0);
                 }
+            if (want_guard) {            // the row's maximum over the wave's 64 columns: this lane's 32 and those of lane ^ 32
+                rowmax = max(rowmax, (unsigned)__shfl_xor((int)rowmax, 32));
+                gmin = rowmax ? min(gmin, rowmax) : gmin;
             }
         }
         if (p.y_amax && plain && !defer) {
@@ -779,8 +772,9 @@ __device__ __forceinline__ void gconv3_body(const GParams &p, const unsigned blo
             for (int o = 32; o > 0; o >>= 1) ymax = max(ymax, (unsigned)__shfl_xor((int)ymax, o));
             unsigned inv = 0u;
             if (want_guard) {           // ~bits order the other way round: the largest ~maximum is the smallest row maximum
-                inv = gmin == 0xffffffffu ? 0u : ~gmin;          // (lanes 0 / 32: every row of the wave over its columns 0-15)
-                inv = max(inv, (unsigned)__shfl_xor((int)inv, 32));
+                inv = gmin == 0xffffffffu ? 0u : ~gmin;          // (a lane: its two rows over the wave's 64 columns)
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) inv = max(inv, (unsigned)__shfl_xor((int)inv, o));
             }
             // ONE publisher per workgroup (round 6; was one per wave): the tiles of a one-round launch end together, so looking
             // before the atomic does not thin them out -- 2 048 waves queued on the two words of a slot at the end of a dense
@@ -802,14 +796,14 @@ __device__ __forceinline__ void gconv3_body(const GParams &p, const unsigned blo
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + li;
-            if (n >= p.N) continue;
-            const float bsv = p.bias ? p.bias[n] : 0.f;
+            const int64_t m = Vs[wm * 64 + i * 32 + li];          // (transposed accumulators: the lane is the row, the register the column)
+            if (m < 0) continue;
             const int res_mod = (int)p.res_mod;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = Vs[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
-                if (m < 0) continue;
+                const int n = n0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (n >= p.N) continue;
+                const float bsv = p.bias ? p.bias[n] : 0.f;
                 if (p.splits > 1) {          // raw partial sum
                     p.partial[((int64_t)split * p.M + m) * p.N + n] = acc[i][j][r];
                     continue;
@@ -1201,7 +1195,10 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
         const int64_t rows_y = p.M;
         p.epi_fast = (rows_y < (1 << 24) && rows_y * (p.splits > 1 ? p.N : p.ldy) * 4 < lim && p.ldy * 4 < (1 << 24) &&
                       (!p.res || (p.res_mod > 0 && p.res_mod < (1 << 24) && imin(p.res_mod, rows_y) * p.ldres * 4 < lim && p.ldres * 4 < (1 << 24))) &&
-                      (!p.Y2 || (p.rows2 * p.ldy2 * 4 < lim && p.ldy2 * 4 < (1 << 24)))) ? 1 : 0;
+                      (!p.Y2 || (p.rows2 * p.ldy2 * 4 < lim && p.ldy2 * 4 < (1 << 24))) &&
+                      // ... and 16 bytes per access: four consecutive columns of a row
+                      p.N % 4 == 0 && (p.splits > 1 ? aligned16(p.partial) : (p.ldy % 4 == 0 && aligned16(p.Y))) && (!p.bias || aligned16(p.bias)) &&
+                      (!p.res || (p.ldres % 4 == 0 && aligned16(p.res))) && (!p.Y2 || (p.ldy2 % 4 == 0 && aligned16(p.Y2)))) ? 1 : 0;
         static const int epi = getenv("HPL_SPLIT3_EPILOGUE") ? atoi(getenv("HPL_SPLIT3_EPILOGUE")) : 1;
         if (!epi) p.epi_fast = 0;
     }

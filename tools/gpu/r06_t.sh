@@ -1,7 +1,7 @@
-# round 6: the epilogues without the per-block load -> wait -> store round trips (wide kernel: residual loads hoisted / skipped; fp32 kernel: skipped
+# round 6: transposed accumulators, 16-byte epilogue accesses, against the build of the commit before (libhplbcl_before_epi.so)
 # when there is no residual) against the build before (hplflownet_amd/libhplbcl_before_epi.so)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r06s; mkdir -p $O
+O=gpurun_out/r06t; mkdir -p $O
 export TMPDIR=/tmp
 python -m pytest tests/test_gpu_split3.py tests/test_gpu_kernels.py tests/test_gpu_layers.py tests/test_gpu_plan.py tests/test_gpu_bench_size.py tests/test_gpu_train_plan.py tests/test_variants.py -x -q > $O/pytest_first.txt 2>&1; echo "first rc=$?"; tail -3 $O/pytest_first.txt
 HPL_LIB=$PWD/hplflownet_amd/libhplbcl_probe.so python tools/tile_phase_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/tile_phase_probe.txt
