@@ -52,3 +52,16 @@ def test_shared_parameter_is_refused():
     m.bcn3_.bias = m.bcn2_.bias                 # one slice bias feeding two Up layers that both run
     with pytest.raises(HplError, match='second gradient contribution'):
         _emit(m)
+
+
+@pytest.mark.parametrize('arch', ['HPLFlowNet', 'HPLFlowNetShallow'])
+def test_range_guard_covers_the_forward_and_only_the_forward(arch):
+    """HPL_FLAG_NOGUARD (include/hpl_bcl.h): every gather-GEMM of the backward program runs without the fp16-pair form's range guard
+    (gradient matrices have quiet rows by nature: the guard ran the wide data gradients twice), no op of the forward does."""
+    from hplflownet_amd.train_plan import F_NOGUARD, OP_GCONV
+    P, _, nf = _emit(_model(arch))
+    fwd = [o for o in P.ops[:nf] if o.kind == OP_GCONV]
+    bwd = [o for o in P.ops[nf:] if o.kind == OP_GCONV]
+    assert fwd and bwd and F_NOGUARD == 32
+    assert not any(o.flags & F_NOGUARD for o in fwd)
+    assert all(o.flags & F_NOGUARD for o in bwd)
