@@ -50,11 +50,18 @@ def main():
         ss.append('%s: %.1f µs per launch in the forward trace (%.1f–%.1f), `trace_frac` %s; back to back %.1f µs, frac %.3f'
                   % (n, tv.get('us_per_launch', 0), tv.get('min_us', 0), tv.get('max_us', 0), ('%.3f' % v['trace_frac']) if 'trace_frac' in v else 'n/a',
                      v.get('kernel_us', 0), v.get('frac', 0)))
+    avg = None
+    for ln in open(P('kernel_stats.txt')):
+        if 'k_gconv3w<8, 4, 2' in ln and 'true>' not in ln:
+            avg = float(ln[100:].split()[2])
+            break
+    dom = ('rocprofv3 average of `k_gconv3w<8,4,2>` over the default bench run %.1f µs (round 5: 351.8), fabric traffic %s per launch (930), %.1f pairs/s over the '
+           "driver's 20 steps, %.1f over ≥ 1 s" % (avg, ('%.0f MB' % (tb / 1e6)) if isinstance(tb, (int, float)) else 'n/a', d['value'], d['steady']['value']))
     text = open(os.path.join(ROOT, 'DESIGN.md')).read()
     gp = open(P('pytest_gpu.txt')).read()
     m = re.search(r'(\d+) passed', gp)
     for key, val in (('HEADLINE', head), ('KERNEL_TABLE', '\n'.join(rows)), ('TRAFFIC', traffic), ('SPLAT_SLICE', ';\n'.join(ss) + '.'),
-                     ('LATTICE_MS', '%.2f' % lat['lattice_build_ms']), ('NGPU', m.group(1) if m else '?')):
+                     ('LATTICE_MS', '%.2f' % lat['lattice_build_ms']), ('NGPU', m.group(1) if m else '?'), ('DOM', dom)):
         text, n = re.subn(r'<!--%s-->.*?<!--/%s-->' % (key, key), lambda _m: '<!--%s-->%s<!--/%s-->' % (key, val, key), text, flags=re.S)
         assert n >= 1, key
     open(os.path.join(ROOT, 'DESIGN.md'), 'w').write(text)
