@@ -14,8 +14,8 @@ def build_probe():
     src = open(os.path.join(csrc, 'gconv3.hip')).read()
 
     def once(old, new):
-        assert src.count(old) == 1, old
-        return src.replace(old, new)
+        assert src.count(old) >= 1, old
+        return src.replace(old, new, 1)
     a = "    using S2 = std::integral_constant<int, 2>;\n    if (nsl > 0) {"
     src = once(a, "    long long probe_p1 = 0; if (probe) probe_p1 = (long long)__builtin_readcyclecounter();\n" + a)
     b = "    if constexpr (PL == 2) {        // undo the operand scales"
@@ -29,11 +29,28 @@ def build_probe():
                "        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 6, (unsigned long long)nsl);\n"
                "        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe),")
     open(os.path.join(csrc, '_probe_gconv3.hip'), 'w').write(src)
+    # the fp32 kernel (csrc/gconv.hip, k_gconv) the same way
+    src = open(os.path.join(csrc, 'gconv.hip')).read()
+    a = "    __syncthreads();\n    int cur = 0;\n    // One contraction step t (compile-time flags)."
+    src = once(a, "    long long probe_p1 = 0; if (probe) probe_p1 = (long long)__builtin_readcyclecounter();\n" + a)
+    b = "    // ---- epilogue.  C/D layout of the 32x32 MFMA"
+    src = once(b, "    long long probe_p2 = 0; if (probe) probe_p2 = (long long)__builtin_readcyclecounter();\n" + b)
+    c = "            }\n        }\n    if (probe) {\n        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe),"
+    src = once(c, "            }\n        }\n    if (probe) {\n        const long long probe_e = (long long)__builtin_readcyclecounter();\n"
+               "        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 2, (unsigned long long)(probe_p1 - probe_c));\n"
+               "        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 3, (unsigned long long)(probe_p2 - probe_p1));\n"
+               "        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 4, (unsigned long long)(probe_e - probe_p2));\n"
+               "        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 5, 1ull);\n"
+               "        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe) + 6, (unsigned long long)nsl);\n"
+               "        atomicAdd(reinterpret_cast<unsigned long long *>(p.clock_probe),")
+    open(os.path.join(csrc, '_probe_gconv.hip'), 'w').write(src)
     from hplflownet_amd import build
     build.build()
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    subprocess.check_call([hipcc] + build.FLAGS + ['-c', os.path.join(csrc, '_probe_gconv3.hip'), '-o', os.path.join(csrc, '_probe_gconv3.o')])
-    objs = [os.path.join(csrc, f.replace('.hip', '.o')) for f in build.SOURCES if f != 'gconv3.hip'] + [os.path.join(csrc, '_probe_gconv3.o')]
+    for n in ('_probe_gconv3', '_probe_gconv'):
+        subprocess.check_call([hipcc] + build.FLAGS + ['-c', os.path.join(csrc, n + '.hip'), '-o', os.path.join(csrc, n + '.o')])
+    objs = [os.path.join(csrc, f.replace('.hip', '.o')) for f in build.SOURCES if f not in ('gconv3.hip', 'gconv.hip')] + \
+        [os.path.join(csrc, '_probe_gconv3.o'), os.path.join(csrc, '_probe_gconv.o')]
     out = os.path.join(ROOT, 'hplflownet_amd', 'libhplbcl_probe.so')
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
     print(out)
@@ -95,3 +112,32 @@ for name, lvl, C, O, f0, f1, Md in cases:
     n = max(1, p[5])
     ghz = p[0] / max(1, p[1]) * 0.1          # cycles per 100-MHz tick
     print('%-22s %8.1f %6d | %43s %9.0f %9.0f %9.0f %9.0f | %8.1f %8.2f' % (name, s.elapsed_time(e) * 1e3, -(-M // 128) * -(-O // 256), '', p[2] / n, p[3] / n, p[4] / n, p[0] / n, p[6] / n, ghz), flush=True)
+
+# ---- the fp32 kernel (csrc/gconv.hip) on the narrow stencils of the Down path: both clouds of a level, 64 -> 64 channels, 15 taps
+print()
+print('%-22s %8s %6s | per probed tile, shader cycles: %9s %9s %9s %9s | %8s %8s' % ('fp32 launch', 'us', 'wgs', 'prologue', 'loop', 'epilogue', 'total', 'slices', 'GHz'))
+for lvl in (0, 1, 2, 3, 4):
+    tb = lat.levels[lvl].blur.pair
+    nbr = tb.t
+    F, M = nbr.shape
+    C = O = 64
+    perm = ops.tap_order(nbr) if M >= 16384 else None
+    t64 = ops.tile_index(nbr, perm, BM=64) if perm is not None else None
+    A = torch.randn(M, C, device=dev)
+    Wt = torch.zeros(ops.round_up(F * C, 32), O, device=dev)
+    Wt[:F * C] = torch.randn(F * C, O, device=dev) / (F * C) ** 0.5
+    y = torch.empty(M, O, device=dev)
+    for sk in (False, True):
+        fn = lambda: ops.gconv_raw(A, nbr, M, C, F, Wt, O, out=y, row_perm=perm, tiles=t64, split_k=sk)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        PROBE.zero_()
+        on[0] = True
+        s.record(); fn(); e.record(); torch.cuda.synchronize()
+        on[0] = False
+        p = PROBE.tolist()
+        n = max(1, p[5])
+        print('%-22s %8.1f %6s | %43s %9.0f %9.0f %9.0f %9.0f | %8.1f %8.2f' % ('level %d%s M=%d' % (lvl, ' split-K' if sk else '', M), s.elapsed_time(e) * 1e3, '', '',
+                                                                               p[2] / n, p[3] / n, p[4] / n, p[0] / n, p[6] / n, p[0] / max(1, p[1]) * 0.1), flush=True)
