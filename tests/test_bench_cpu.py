@@ -105,3 +105,14 @@ def test_emit_writes_the_detail_file_and_prints_one_line(tmp_path, capsys):
         assert json.load(f)['kernels'].keys() == full['kernels'].keys()          # the per-class tables live there
     bench.emit(full, str(tmp_path / 'no' / 'such' / 'dir' / 'x.json'))         # an unwritable place costs the file, not the line
     check_contract_line(capsys.readouterr().out.strip())
+
+
+def test_design_md_quotes_the_committed_profile_set():
+    """The generated regions of DESIGN.md (tools/design_fill.py) are filled -- no placeholder left -- and quote the driver-command
+    record that is committed under profiles/."""
+    import re
+    text = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    assert '@@' not in text
+    m = re.search(r'<!--HEADLINE-->\*\*([\d.]+) point-pairs/s\*\*', text)
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r06_bench_driver_cmd_detail.json')))
+    assert m and abs(float(m.group(1)) - d['value']) < 0.06
