@@ -1161,6 +1161,10 @@ bool hpl_gc::launch_split3(GParams &p, hipStream_t s) {
     // its padding costs more than it gains (N = 580, the data gradient of bcn1_: 3 x 256 = 768 vs 5 x 128 = 640 columns)
     constexpr int pct = 108;      // (round 5, fp16 pairs: 135 -- the 256-wide tile for the data gradients too -- 539 -> 600 us, 332 -> 380 us)
     const bool bn256 = splitk > 1 || (wide == 256 && cdiv(p.N, 256) * 256 * 100 <= cdiv(p.N, 128) * 128 * pct);
+    // (round 6: the 128-wide tile for dense launches whose 128 x 256 tiles cover at most half of the CUs -- the last 1x1 convs on the
+    // points, 64 x 2 tiles; bcn3_'s dense convs, 74 x 1 -- i.e. twice the workgroups with half of the matrix-pipe work each: single
+    // forward 3.12-3.24 -> 3.09-3.12 ms, pipelined rate 443-456 -> 440-451 pairs/s in one call, profiles/r06z_narrow_fill_ab.txt.
+    // The gathered rows are staged twice; in the loop other pairs' launches fill the idle CUs anyway.  Not kept.)
     const int BN = bn256 ? 256 : 128;
     p.tiles_n = (int)cdiv(p.N, BN);
     if (p.tile_bm != BM3) p.tile_idx = nullptr;

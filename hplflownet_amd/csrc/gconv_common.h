@@ -202,7 +202,19 @@ __device__ __forceinline__ bool guard_tripped(const float *a_amax, const unsigne
 }
 constexpr int RESID_SHIFT = 24;          // residual scale 2^24: (a s - hi - lo) 2^24 < 2^15.01 for every a s < 2^15
 // the cheap part of launch_split3's test (the callers decide with it whether to compute the largest magnitude of A)
-inline bool split3_maybe(int64_t M, int C, int F, int N) { return C >= 32 && N >= 256 && M >= 1024 && F <= 15; }
+inline bool split3_maybe(int64_t M, int C, int F, int N) {
+    if (!(C >= 32 && N >= 256 && M >= 1024 && F <= 15)) return false;
+    // ... and the shape tests of launch_split3 (round 6: the 1x1 convs of level 3 -- 1 787 rows -- had their operand reduced, 7 us
+    // each, and then ran on the fp32 kernel): dense launches below 8 192 rows that do not fill half the CUs with 128 x 256 tiles, and
+    // mid-size stencils that cannot be split over K into one round of workgroups, stay on the fp32 MFMA
+    const int64_t tiles256 = ((M + 127) / 128) * ((N + 255) / 256);
+    if (tiles256 >= 128) return true;
+    if (F == 1) return M >= 8192;
+    if (M >= 16384) return true;
+    const int64_t nk = ((int64_t)F * C + BK - 1) / BK;
+    const int64_t by_tiles = 256 / tiles256, by_k = nk / 16;
+    return N % 256 == 0 && (by_tiles < by_k ? by_tiles : by_k) >= 2;
+}
 
 // weight gradient (gconv.hip: fp32 MFMA; wgrad3.hip: split operands on the bf16 MFMA)
 struct WParams {

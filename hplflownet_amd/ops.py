@@ -155,6 +155,21 @@ GROUP_TILE_BM = 128 if SPLIT3 else 64
 SPLIT3_MIN_N, SPLIT3_MIN_C = 256, 32
 
 
+def split3_maybe(M, C, F, N):
+    """csrc/gconv_common.h split3_maybe: can this launch run on the split-operand kernel at all?  (Launches that cannot
+    skip the reduction of their operand's magnitude and run on the fp32 MFMA.)"""
+    if not (C >= SPLIT3_MIN_C and N >= SPLIT3_MIN_N and M >= 1024 and F <= 15):
+        return False
+    tiles = -(-M // 128) * -(-N // 256)
+    if tiles >= 128:
+        return True
+    if F == 1:
+        return M >= 8192
+    if M >= 16384:
+        return True
+    return N % 256 == 0 and min(256 // tiles, -(-F * C // 32) // 16) >= 2
+
+
 def tile_index(nbr, perm, BM=TILE_BM):
     """int32 [F<=15, M] table + row order (or None) -> (tile_idx int32 [tiles, F, BM], tile_mask int32 [tiles, 8]):
     the gather indices and tap masks of every BM-row tile, precomputed once per lattice (hpl_tile_index)."""
@@ -361,7 +376,7 @@ def gconv_raw(A, nbr, M, C, F, Wt, N, bias=None, act=ACT_NONE, res=None, res_mod
     if Wt3 is not None:           # weight_split3 of the image Wt is a row range of (same first row)
         if Wt3.P == 3:
             d.Wt3, d.wt3_plane_stride, d.wt3_planes = ptr(Wt3.planes), Wt3.planes.stride(0), 3
-        elif C >= SPLIT3_MIN_C and N >= SPLIT3_MIN_N and M >= 1024 and F <= 15 and scat is None:
+        elif scat is None and split3_maybe(M, C, F, N):
             # fp16 pairs: the launch scales A by its largest magnitude (csrc/gconv_common.h split3_maybe: launches that cannot
             # qualify skip the reduction and run on the fp32 MFMA)
             if guard:

@@ -26,6 +26,13 @@ def test_header_symbols_exported():
     assert lib.hpl_version() >= 100
 
 
+def test_library_is_not_older_than_its_sources():
+    """The built library travels to the GPU box with the working tree (`gpurun`, the driver's GPU tiers): a kernel edit without a
+    rebuild would be measured as the old kernel under the new source's name.  build.needs_build() compares the modification times."""
+    from hplflownet_amd import build
+    assert not build.needs_build(), 'hplflownet_amd/libhplbcl.so is older than csrc/ or include/hpl_bcl.h: run __graft_entry__.build()'
+
+
 def test_gconv_desc_layout_matches_header():
     hdr = header_text()
     struct = hdr[hdr.index('typedef struct hpl_gconv_desc {'):hdr.index('} hpl_gconv_desc;')]

@@ -116,3 +116,21 @@ def test_design_md_quotes_the_committed_profile_set():
     m = re.search(r'<!--HEADLINE-->\*\*([\d.]+) point-pairs/s\*\*', text)
     d = json.load(open(os.path.join(ROOT, 'profiles', 'r06_bench_driver_cmd_detail.json')))
     assert m and abs(float(m.group(1)) - d['value']) < 0.06
+
+
+def test_split3_maybe_covers_every_launch_the_split_kernel_takes():
+    """ops.split3_maybe / gconv_common.h split3_maybe decide whether a launch's operand magnitude is reduced at all: it must say
+    yes wherever launch_split3 (mirrored by bench.split3_takes) takes the launch, and no for the shapes round 6 found reduced in
+    vain (the 1x1 convs of level 3: 1 787 rows)."""
+    from hplflownet_amd import ops
+    if not ops.SPLIT3:
+        return
+    for M in (1024, 1787, 3574, 8191, 8192, 9433, 16383, 16384, 25841, 34631, 69262):
+        for N in (64, 128, 256, 512, 580, 1024):
+            for C in (32, 64, 128, 260, 324, 388, 580, 1024):
+                for F in (1, 7, 8, 15):
+                    if bench.split3_takes(M, N, C, F):
+                        assert ops.split3_maybe(M, C, F, N), (M, N, C, F)
+    assert not ops.split3_maybe(1787, 512, 1, 256) and not ops.split3_maybe(1787, 256, 1, 512)
+    assert ops.split3_maybe(1787, 260, 15, 256)           # level 3's stencil: split over K into one round of workgroups
+    assert ops.split3_maybe(9433, 256, 1, 256) and ops.split3_maybe(8192, 1024, 1, 512)

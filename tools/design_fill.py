@@ -15,12 +15,17 @@ def main():
     lat = d['single_pair_latency_ms']
     tr = d.get('train') or {}
     pw = d.get('power') or {}
-    head = ('**%.1f point-pairs/s** over the driver\'s 20 steps (%.3f ms per step), %.1f over the ≥ 1 s behind them (`steady`), %.1f over 200 steps '
+    runs = ''
+    if os.path.exists(P('driver_cmd_runs.txt')):          # tools/gpu/driver_cmd_runs.sh: five runs on one box, the median run is the record
+        m = re.search(r'median run: \d+ \(([\d.]+) pairs/s\); min ([\d.]+), max ([\d.]+)', open(P('driver_cmd_runs.txt')).read())
+        if m:
+            runs = ' (the median of five runs of that command on one box: %s–%s, `%s_driver_cmd_runs.txt`)' % (m.group(2), m.group(3), R)
+    head = ('**%.1f point-pairs/s** over the driver\'s 20 steps%s (%.3f ms per step), %.1f over the ≥ 1 s behind them (`steady`), %.1f over 200 steps '
             '(`python bench.py`, `%s_bench_plain.json`; steady %.1f), forward alone %.1f pairs/s; one pair alone: lattice %.2f ms + forward %.2f ms; '
             'exact bf16 triples %.1f pairs/s; training step %.2f ms; CPU port %.3f pairs/s on %d threads (× %.0f); EPE3D differs from the CPU oracle '
             'by %.1e; board %s W of %s at %s MHz.  Boxes of the pool differ by ± 5 %% (this file\'s A/Bs: 435–478 pairs/s for the same '
             'build over 300 steps); round 5\'s driver record: 428.9.'
-            % (d['value'], d['ms_per_step'], d['steady']['value'], pl['value'], R, pl['steady']['value'], d['forward_only']['pairs_per_s'],
+            % (d['value'], runs, d['ms_per_step'], d['steady']['value'], pl['value'], R, pl['steady']['value'], d['forward_only']['pairs_per_s'],
                lat['lattice_build_ms'], lat['forward_ms'], d['exact_bf16x3']['value'], tr.get('ms_per_step', float('nan')),
                d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['value'] / d['cpu_baseline']['value'], d['epe3d']['abs_delta'],
                pw.get('package_w'), pw.get('limit_w'), pw.get('sclk_mhz')))
