@@ -1,7 +1,7 @@
 # The randomised parity runs behind DESIGN.md section 2 (run on the GPU box from the repo root): lattices (fused / staged builders against
 # the C oracle), single layers, whole models (inference and training path), bench-size pairs on more seeds, the dense-surface cloud.
 cd $GRAFT_REPO_ROOT
-R=${1:-r05}
+R=${1:-r06}
 mkdir -p gpurun_out
 {
 echo "== stress_lattice --native --cases 200"; python tests/stress/stress_lattice.py --native --cases 200 2>&1 | tail -4
